@@ -1,0 +1,38 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    """npz -> dict; 0-d string arrays are JSON payloads (shape tables)."""
+    out = {}
+    with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
+        for k in z.files:
+            v = z[k]
+            out[k] = json.loads(str(v)) if v.dtype.kind == "U" and v.ndim == 0 else v
+    return out
+
+
+def rel_l2(a, b):
+    import torch
+    a = torch.as_tensor(a, dtype=torch.float64).flatten()
+    b = torch.as_tensor(b, dtype=torch.float64).flatten()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden

@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the *reference* (read-only at /root/reference).
+
+Run in the build container only (``python tools/make_golden.py``); the GPU box never sees
+the reference.  The reference's own files are imported, never copied; the only stand-ins
+are for third-party modules that are absent here and that the hot path never executes
+(omegaconf via general.py:5; wandb/torchvision/viz/metrics via sampling.py:3-11).
+Weights and inputs come from oracle/synth.py so the tests can regenerate them.
+"""
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("FLOCODER_REFERENCE", "/root/reference")
+sys.path.insert(0, REPO)
+from oracle.synth import synth_input, synth_state_dict  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def _stand_in(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def import_reference():
+    _stand_in("omegaconf", OmegaConf=type("OmegaConf", (), {}))
+    _stand_in("wandb")
+    tv = _stand_in("torchvision")
+    tv.transforms = _stand_in("torchvision.transforms", ToTensor=object)
+    sys.path.insert(0, REF)
+    import flocoder  # noqa: F401  (package __init__ is empty)
+    _stand_in("flocoder.viz", save_img_grid=None)
+    _stand_in("flocoder.metrics", g2rgb=None, compute_sample_metrics=None)
+    from flocoder import unet, sampling
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location("ref_" + name, os.path.join(REF, "flocoder", name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    return unet, sampling, load("ot"), load("inpainting")
+
+
+def shapes_of(module):
+    return {k: list(v.shape) for k, v in module.state_dict().items()}
+
+
+def load_synth(module, seed):
+    shapes = shapes_of(module)
+    module.load_state_dict(synth_state_dict(shapes, seed))
+    return shapes
+
+
+def npz(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    conv = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        elif isinstance(v, (dict, list)):
+            v = np.array(json.dumps(v))
+        conv[k] = v
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **conv)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+UNET_CASES = [  # tag, dim, n_classes, mask_cond, B, seed
+    ("d32c102", 32, 102, False, 2, 1),
+    ("d16c10", 16, 10, False, 3, 2),
+    ("d8mask", 8, 0, True, 2, 3),
+]
+
+
+@torch.no_grad()
+def main():
+    torch.set_num_threads(8)
+    unet, sampling, ot, inpainting = import_reference()
+
+    # ---- G1: sinusoidal embedding ---------------------------------------------------
+    times = torch.tensor([0.999, 1.0, 37.5, 250.0, 499.5, 750.25, 998.0, 999.0])
+    npz("g1_sinusoidal", times=times, emb32=unet.SinusoidalPositionEmbeddings(32)(times),
+        emb16=unet.SinusoidalPositionEmbeddings(16)(times))
+
+    # ---- G2: individual modules -----------------------------------------------------
+    out = {}
+    B = 2
+    mods = {
+        "block": (unet.Block(32, 64, groups=4), (B, 32, 16, 16)),
+        "resnet_same": (unet.ResnetBlock(32, 32, time_emb_dim=256, groups=4), (B, 32, 32, 32)),
+        "resnet_proj": (unet.ResnetBlock(96, 64, time_emb_dim=256, groups=4), (B, 96, 16, 16)),
+        "linattn": (unet.LinearAttention(32), (B, 32, 32, 32)),
+        "linattn_small": (unet.LinearAttention(128), (B, 128, 4, 4)),
+        "attn": (unet.Attention(256), (B, 256, 4, 4)),
+        "down": (unet.Downsample(32, 64), (B, 32, 32, 32)),
+        "up": (unet.Upsample(64, 32), (B, 64, 8, 8)),
+    }
+    shapes_all = {}
+    for tag, (mod, xs) in mods.items():
+        mod.eval()
+        shapes_all[tag] = load_synth(mod, seed=11)
+        x = synth_input("g2." + tag, xs, seed=11)
+        if tag.startswith("resnet"):
+            temb = synth_input("g2.temb." + tag, (B, 256), seed=11)
+            y = mod(x, temb)
+        elif tag == "block":
+            sc = synth_input("g2.scale", (B, 64, 1, 1), seed=11, scale=0.3)
+            sh = synth_input("g2.shift", (B, 64, 1, 1), seed=11, scale=0.3)
+            y = mod(x, (sc, sh))
+            out["block_noss"] = mod(x)
+        else:
+            y = mod(x)
+        out[tag] = y
+    npz("g2_modules", shapes=shapes_all, **out)
+
+    # ---- G3: full U-Net forward -----------------------------------------------------
+    for tag, dim, ncls, mask_cond, B, seed in UNET_CASES:
+        H = dim
+        m = unet.Unet(dim=dim, channels=4, dim_mults=(1, 2, 4, 8), n_classes=ncls, mask_cond=mask_cond).eval()
+        shapes = load_synth(m, seed)
+        x = synth_input("g3.x." + tag, (B, 4, H, H), seed)
+        t = torch.tensor([0.001, 0.37, 0.9][:B]) * 999
+        arrays = dict(shapes=shapes, t=t)
+        if ncls:
+            cls = torch.tensor([3, ncls - 1, 0][:B])
+            arrays["cls"] = cls
+            arrays["v_class"] = m(x, t, {"class_cond": cls})
+            arrays["v_noclass"] = m(x, t, {"class_cond": None})
+            arrays["v_none"] = m(x, t, None)
+        if mask_cond:
+            mask = torch.sigmoid(synth_input("g3.mask." + tag, (B, 4, H, H), seed, scale=2.0))
+            arrays["mask"] = mask
+            arrays["v_mask"] = m(x, t, {"class_cond": None, "mask_cond": mask})
+            arrays["v_ones"] = m(x, t, {"mask_cond": torch.ones_like(mask)})
+            arrays["v_none"] = m(x, t, None)
+        npz("g3_unet_" + tag, **arrays)
+
+    # ---- G4: time grids -------------------------------------------------------------
+    grids = {f"rk4_{n}": sampling.warp_time(torch.linspace(0, 1, n)) for n in (3, 5, 16, 64, 100)}
+    grids["rand_in"] = synth_input("g4.rand", (64,), 0).abs().clamp(max=1.0)
+    grids["rand_out"] = sampling.warp_time(grids["rand_in"])
+    npz("g4_timegrids", **grids)
+
+    # ---- G5 / G6: RK4 (live) and Euler (legacy formula) trajectories, dim=16 model --------
+    m = unet.Unet(dim=16, channels=4, dim_mults=(1, 2, 4, 8), n_classes=10).eval()
+    shapes = load_synth(m, seed=5)
+    B = 2
+    src = synth_input("g5.src", (B, 4, 16, 16), 5)
+    cls = torch.tensor([7, 2])
+    arrays = dict(shapes=shapes, cls=cls)
+    for cfg in (0.0, 3.0):
+        lat, nfe = sampling.generate_latents_rk4(m, (B, 4, 16, 16), n_steps=5, cond={"class_cond": cls},
+                                                 cfg_strength=cfg, source=src.clone())
+        arrays[f"rk4_n5_cfg{int(cfg)}"] = lat
+        arrays[f"rk4_n5_cfg{int(cfg)}_nfe"] = np.int64(nfe)
+    lat, nfe = sampling.generate_latents_rk4(m, (B, 4, 16, 16), n_steps=4, cond={}, cfg_strength=3.0,
+                                             source=src.clone())
+    arrays["rk4_n4_nocond"] = lat
+    init = synth_input("g5.init", (B, 4, 16, 16), 5)
+    lat, nfe = sampling.generate_latents_rk4(m, (B, 4, 16, 16), n_steps=8, cond={"class_cond": cls}, cfg_strength=3.0,
+                                             source=src.clone(), init_latents=init, init_strength=0.5)
+    arrays["rk4_n8_init05"] = lat
+    arrays["rk4_n8_init05_nfe"] = np.int64(nfe)
+
+    def legacy_euler(model, x0, n, ids, eps=0.001):   # legacy/train_sd_flowers.py:50-67, cond as dict (Q15)
+        x = x0.detach().clone()
+        dt = 1.0 / n
+        for i in range(n):
+            num_t = i / n * (1 - eps) + eps
+            t = torch.ones(x.shape[0]) * num_t
+            pred = model(x, t * 999, {"class_cond": ids})
+            x = x.detach().clone() + pred * dt
+        return x
+    for n in (4, 16):
+        arrays[f"euler_n{n}"] = legacy_euler(m, src, n, cls)
+    npz("g5_trajectories", **arrays)
+
+    # ---- G7: greedy OT pairing ------------------------------------------------------
+    arrays = {}
+    for B, D in ((8, 64), (64, 64), (256, 1024)):
+        s = synth_input(f"g7.s{B}", (B, D), 7)
+        t = synth_input(f"g7.t{B}", (B, D), 7)
+        arrays[f"perm_{B}_{D}"] = ot.compute_ot_pairing(s, t)
+    # ties: duplicated targets must resolve to the first unused index
+    s = synth_input("g7.tie.s", (6, 16), 7)
+    t = s[[2, 2, 0, 0, 5, 1]].clone()
+    arrays["tie_src"], arrays["tie_tgt"], arrays["tie_perm"] = s, t, ot.compute_ot_pairing(s, t)
+    npz("g7_ot", **arrays)
+
+    # ---- G8: mask encoder + blending ------------------------------------------------
+    me = inpainting.MaskEncoder().eval()
+    shapes = load_synth(me, seed=8)
+    mp = (synth_input("g8.mask", (2, 1, 128, 128), 8) > 0.3).float()
+    ml = me(mp)
+    srcl, noise = synth_input("g8.src", (2, 4, 8, 8), 8), synth_input("g8.noise", (2, 4, 8, 8), 8)
+    npz("g8_mask_encoder", shapes=shapes, mask_latents=ml, mask_latents_bool=me(mp.bool()),
+        blended=inpainting.mask_blending(srcl, ml, noise))
+
+
+if __name__ == "__main__":
+    main()
