@@ -1,0 +1,171 @@
+// Attention cores of the velocity U-Net on NHWC qkv tensors [B][n][3*heads*32] (channel = which*heads*32 + head*32 + d,
+// the layout to_qkv's 1x1 conv produces; unet.py:110-113,137-140).  dim_head is fixed at 32 (unet.py:100,126).
+#include "common.h"
+
+namespace fc {
+
+constexpr int DH = 32;
+
+// ---------------------------------------------------------------------------------------------------
+// LinearAttention part 1 (unet.py:143,146): ctx[d][e] = sum_n softmax_n(k)[d][n] * v[e][n].   grid (B*heads)
+// Pass 1 finds max_n k[d][n]; pass 2 walks n in tiles of 64 staged in LDS, accumulating the 32x32 context
+// (4 entries per thread) and the softmax denominators in registers.
+__global__ void __launch_bounds__(256) linattn_ctx_kernel(const float* qkv, float* ctx, int n, int heads) {
+    __shared__ float red[8][DH];
+    __shared__ float kmax[DH];
+    __shared__ __attribute__((aligned(16))) float ek[64][DH];
+    __shared__ __attribute__((aligned(16))) float vv[64][DH];
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads, tid = threadIdx.x;
+    const int C3 = 3 * heads * DH;
+    const float* kb = qkv + (size_t)b * n * C3 + heads * DH + h * DH;
+    const float* vb = kb + heads * DH;
+    {   // pass 1
+        const int d = tid & 31, grp = tid >> 5;
+        float m = -INFINITY;
+        for (int i = grp; i < n; i += 8) m = fmaxf(m, kb[(size_t)i * C3 + d]);
+        red[grp][d] = m;
+        __syncthreads();
+        if (tid < DH) {
+            float mm = red[0][tid];
+#pragma unroll
+            for (int g = 1; g < 8; ++g) mm = fmaxf(mm, red[g][tid]);
+            kmax[tid] = mm;
+        }
+        __syncthreads();
+    }
+    const int d = tid >> 3, e0 = (tid & 7) * 4;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f, ksum = 0.f;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int cnt = min(64, n - i0);
+        for (int j = tid; j < 64 * 8; j += 256) {   // 64 rows x 8 float4
+            const int r = j >> 3, c4 = (j & 7) * 4;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), v4 = kv;
+            if (r < cnt) {
+                kv = *reinterpret_cast<const float4*>(kb + (size_t)(i0 + r) * C3 + c4);
+                v4 = *reinterpret_cast<const float4*>(vb + (size_t)(i0 + r) * C3 + c4);
+                kv.x = __expf(kv.x - kmax[c4]); kv.y = __expf(kv.y - kmax[c4 + 1]);
+                kv.z = __expf(kv.z - kmax[c4 + 2]); kv.w = __expf(kv.w - kmax[c4 + 3]);
+            }
+            *reinterpret_cast<float4*>(&ek[r][c4]) = kv;
+            *reinterpret_cast<float4*>(&vv[r][c4]) = v4;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int r = 0; r < 64; ++r) {
+            const float kd = ek[r][d];
+            const float4 v4 = *reinterpret_cast<const float4*>(&vv[r][e0]);
+            acc0 += kd * v4.x; acc1 += kd * v4.y; acc2 += kd * v4.z; acc3 += kd * v4.w;
+            ksum += kd;
+        }
+        __syncthreads();
+    }
+    const float inv = 1.0f / ksum;
+    float* o = ctx + ((size_t)blockIdx.x * DH + d) * DH + e0;
+    *reinterpret_cast<float4*>(o) = make_float4(acc0 * inv, acc1 * inv, acc2 * inv, acc3 * inv);
+}
+
+int linattn_ctx_launch(const float* qkv, float* ctx, int B, int n, int heads, hipStream_t s) {
+    hipLaunchKernelGGL(linattn_ctx_kernel, dim3(B * heads), dim3(256), 0, s, qkv, ctx, n, heads);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LinearAttention part 2 (unet.py:142,145,148): out[n][h*32+e] = sum_d ctx[h][d][e] * softmax_d(q[n][h,:])[d] * 32^-1/2.
+// grid (ceil(n / PIX), B); one thread per (pixel, head); the sample's contexts sit in LDS.
+__global__ void __launch_bounds__(256) linattn_apply_kernel(const float* qkv, const float* ctx, float* out, int n, int heads, int pix_per) {
+    extern __shared__ __attribute__((aligned(16))) float cs[];  // [heads][32][32]
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int C3 = 3 * heads * DH, CO = heads * DH;
+    for (int i = tid; i < heads * DH * DH; i += 256) cs[i] = ctx[(size_t)b * heads * DH * DH + i];
+    __syncthreads();
+    const float scale = 0.17677669529663687f;  // 32^-0.5
+    for (int j = tid; j < pix_per * heads; j += 256) {
+        const int h = j % heads, pix = blockIdx.x * pix_per + j / heads;
+        if (pix >= n) continue;
+        const float* qp = qkv + ((size_t)b * n + pix) * C3 + h * DH;
+        float q[DH];
+#pragma unroll
+        for (int i = 0; i < DH; i += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(qp + i);
+            q[i] = t.x; q[i + 1] = t.y; q[i + 2] = t.z; q[i + 3] = t.w;
+        }
+        float m = q[0];
+#pragma unroll
+        for (int i = 1; i < DH; ++i) m = fmaxf(m, q[i]);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < DH; ++i) { q[i] = __expf(q[i] - m); sum += q[i]; }
+        const float f = scale / sum;
+        const float* ch = cs + h * DH * DH;
+        float* op = out + ((size_t)b * n + pix) * CO + h * DH;
+#pragma unroll
+        for (int e = 0; e < DH; e += 4) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int dd = 0; dd < DH; ++dd) {
+                const float4 c4 = *reinterpret_cast<const float4*>(ch + dd * DH + e);
+                acc.x += c4.x * q[dd]; acc.y += c4.y * q[dd]; acc.z += c4.z * q[dd]; acc.w += c4.w * q[dd];
+            }
+            *reinterpret_cast<float4*>(op + e) = make_float4(acc.x * f, acc.y * f, acc.z * f, acc.w * f);
+        }
+    }
+}
+
+int linattn_apply_launch(const float* qkv, const float* ctx, float* out, int B, int n, int heads, hipStream_t s) {
+    const int pix_per = 256 / heads > 0 ? 256 / heads : 1;
+    hipLaunchKernelGGL(linattn_apply_kernel, dim3(cdiv(n, pix_per), B), dim3(256), (size_t)heads * DH * DH * sizeof(float), s, qkv, ctx,
+                       out, n, heads, pix_per);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Softmax attention for the bottleneck (unet.py:114-121), n <= 64 tokens.   grid (B*heads)
+// out[i][h*32+d] = sum_j softmax_j(q_i . k_j * 32^-1/2) v[j][d]
+__global__ void __launch_bounds__(256) attn_small_kernel(const float* qkv, float* out, int n, int heads) {
+    __shared__ float qs[64][DH + 1], ks[64][DH + 1], vs[64][DH + 1], sim[64][65];
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads, tid = threadIdx.x;
+    const int C3 = 3 * heads * DH, CO = heads * DH;
+    const float* base = qkv + (size_t)b * n * C3 + h * DH;
+    const float scale = 0.17677669529663687f;
+    for (int i = tid; i < n * DH; i += 256) {
+        const int r = i / DH, c = i % DH;
+        qs[r][c] = base[(size_t)r * C3 + c] * scale;
+        ks[r][c] = base[(size_t)r * C3 + heads * DH + c];
+        vs[r][c] = base[(size_t)r * C3 + 2 * heads * DH + c];
+    }
+    __syncthreads();
+    for (int i = tid; i < n * n; i += 256) {
+        const int r = i / n, c = i % n;
+        float s = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < DH; ++dd) s += qs[r][dd] * ks[c][dd];
+        sim[r][c] = s;
+    }
+    __syncthreads();
+    for (int r = tid; r < n; r += 256) {
+        float m = sim[r][0];
+        for (int c = 1; c < n; ++c) m = fmaxf(m, sim[r][c]);
+        float sum = 0.f;
+        for (int c = 0; c < n; ++c) { const float e = __expf(sim[r][c] - m); sim[r][c] = e; sum += e; }
+        const float inv = 1.0f / sum;
+        for (int c = 0; c < n; ++c) sim[r][c] *= inv;
+    }
+    __syncthreads();
+    for (int i = tid; i < n * DH; i += 256) {
+        const int r = i / DH, dd = i % DH;
+        float s = 0.f;
+        for (int c = 0; c < n; ++c) s += sim[r][c] * vs[c][dd];
+        out[((size_t)b * n + r) * CO + h * DH + dd] = s;
+    }
+}
+
+int attn_small_launch(const float* qkv, float* out, int B, int n, int heads, hipStream_t s) {
+    if (n > 64) return fail(FC_E_SHAPE, "attn_small: more than 64 tokens");
+    hipLaunchKernelGGL(attn_small_kernel, dim3(B * heads), dim3(256), 0, s, qkv, out, n, heads);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+}  // namespace fc

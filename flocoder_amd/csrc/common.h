@@ -1,0 +1,164 @@
+// Shared declarations for the gfx950 kernels and the native plan builder.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/flocoder_amd.h"
+
+namespace fc {
+
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define FC_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return ::fc::fail(FC_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));       \
+    } while (0)
+
+#define FC_TRY(expr)                \
+    do {                            \
+        int _r = (expr);            \
+        if (_r != FC_OK) return _r; \
+    } while (0)
+
+static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm statistics travel between kernels as per-tile partials: stats[b][g][t] = (mean_t, M2_t),
+// every slot t covering exactly n_t elements.  Producers never use atomics, consumers combine the T
+// slots in a fixed order (Chan's parallel update with equal counts), so results are run-to-run
+// bit-identical.
+// ---------------------------------------------------------------------------------------------
+struct StatsRef {
+    float* p = nullptr;  // [B][G][T][2]
+    int G = 0, T = 0;
+    float n_t = 0.f;
+};
+
+// How a consumer turns a stored raw tensor into its logical input while staging it:
+//   mode 0: identity          mode 1: GroupNorm affine            mode 2: GroupNorm affine, FiLM, SiLU
+struct SrcXform {
+    int mode = 0;
+    const float* stats = nullptr;
+    int G = 1, T = 1;
+    float n_t = 1.f;
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    const float* ss = nullptr;  // [B][ss_stride]: scale at ss[c], shift at ss[C + c]   (unet.py:92 chunk(2,dim=1))
+    int ss_stride = 0;
+    float eps = 1e-5f;
+};
+
+struct ConvSrc {
+    const float* p = nullptr;  // NHWC [B][Hs][Ws][C]
+    int C = 0;
+    SrcXform xf;
+};
+
+struct ConvArgs {
+    ConvSrc s0, s1;           // s1.C == 0: no channel concat
+    const float* w = nullptr;  // packed [KS*KS][Cin][Cout]
+    const float* bias = nullptr;
+    float* out = nullptr;      // NHWC [B][H][W][Cout]
+    int out_act = 0;           // 1: SiLU on (acc + bias) before `add`
+    const float* add = nullptr;  // NHWC [B][H][W][Cout] added last (residuals)
+    float* stats_out = nullptr;  // partial GroupNorm stats of `out` (after bias, before act/add)
+    int Gout = 0;
+    // fused 1x1 projection of the (untransformed) centre tap: ResnetBlock.res_conv, unet.py:86,96
+    const float* res_w = nullptr;  // [Cin][Cout]
+    const float* res_b = nullptr;
+    float* res_out = nullptr;
+    int B = 0, H = 0, W = 0;   // output extent
+    int Hs = 0, Ws = 0;        // source extent (before the optional nearest x2)
+    int Cin = 0, Cout = 0;
+    int KS = 1, pad = 0, stride = 1, ups = 0;
+    int w_batch_stride = 0;    // != 0: per-sample weights (w + b*stride), tiles then hold one sample
+};
+
+// Tile configurations of the implicit-GEMM kernel (see conv_igemm.hip).
+enum ConvTile { TILE_AUTO = -1, TILE_M128N32 = 0, TILE_M128N64 = 1, TILE_M64N32K2 = 2, TILE_M32N32K4 = 3, TILE_M64N64K2 = 4,
+                TILE_COUNT = 5 };
+
+struct ConvGeom {  // filled by conv_plan(): what a consumer must know about `stats_out`
+    int tile = 0, grid = 0, T = 0;
+    float n_t = 0.f;
+    size_t lds = 0;
+};
+int conv_init();
+int conv_plan(const ConvArgs& a, int tile, ConvGeom* g);
+int conv_launch(const ConvArgs& a, int tile, hipStream_t s);
+
+// ---- elementwise / small kernels (elementwise.hip, attention.hip, temb.hip) -------------------
+struct FinalizeArgs {       // y = act(gn(h)) + res, optional GroupNorm(1) partials of y
+    const float* h = nullptr;
+    SrcXform xf;            // mode 1 or 2 (ss may be null)
+    const float* res = nullptr;
+    float* y = nullptr;
+    float* stats_out = nullptr;  // G = 1
+    int B = 0, HW = 0, C = 0;
+};
+int finalize_blocks_per_sample(int HW, int C);
+int finalize_launch(const FinalizeArgs& a, hipStream_t s);
+int gn_stats_launch(const float* x_nhwc, float* stats /*[B][G][1][2]*/, int B, int HW, int C, int G, hipStream_t s);
+
+int init_conv_launch(const float* x_nchw, int x_batch_mod, const float* w /*[Cin][Cout]*/, const float* bias, float* out_nhwc,
+                     int B, int Cin, int HW, int Cout, hipStream_t s);
+int final_conv_launch(const float* x_nhwc, const float* w /*[Cin][Cout]*/, const float* bias, float* out_nchw, int B, int Cin,
+                      int HW, int Cout, hipStream_t s);
+int nchw_to_nhwc_launch(const float* src, float* dst, int B, int C, int HW, int Cpad, int src_batch_mod, hipStream_t s);
+int nhwc_to_nchw_launch(const float* src, float* dst, int B, int C, int HW, int Cpad, hipStream_t s);
+int bilinear_nhwc_launch(const float* src, float* dst, int B, int C, int Hs, int Ws, int Hd, int Wd, hipStream_t s);
+
+struct TembArgs {
+    const float* time = nullptr;       // [B]
+    const int64_t* class_ids = nullptr;  // [B] or null; id < 0 -> no class term
+    int class_batch_mod = 0;           // ids index = b % mod (CFG second half passes null_from)
+    int null_from = 0;                 // rows >= null_from get no class embedding (CFG), 0 = off
+    const float* freqs = nullptr;      // [dim/2] exp(-k ln(1e4)/(dim/2-1))
+    const float *w1t, *b1, *w2t, *b2;  // time_mlp.1 [dim][td], time_mlp.3 [td][td]  (transposed: [in][out])
+    const float *emb, *cw1t, *cb1, *cw2t, *cb2;  // class_cond_mlp.{0,1,3}
+    int n_classes = 0;
+    float* t_out = nullptr;            // [B][td]
+    int B = 0, dim = 0, td = 0;
+};
+int temb_launch(const TembArgs& a, hipStream_t s);
+// ss[b][j] = sum_i silu(t[b][i]) * wt[i][j] + bias[j]   for the concatenation of every ResnetBlock.mlp
+int ss_launch(const float* t, const float* wt, const float* bias, float* ss, int B, int td, int S, hipStream_t s);
+
+// Linear attention core (unet.py:142-149) on qkv NHWC [B][n][3*heads*32]
+int linattn_ctx_launch(const float* qkv, float* ctx /*[B][heads][32][32]*/, int B, int n, int heads, hipStream_t s);
+int linattn_apply_launch(const float* qkv, const float* ctx, float* out /*[B][n][heads*32]*/, int B, int n, int heads,
+                         hipStream_t s);
+// Softmax attention core (unet.py:114-121), n <= 64
+int attn_small_launch(const float* qkv, float* out, int B, int n, int heads, hipStream_t s);
+
+// ---- ODE state updates on the NCHW boundary tensors (ode.hip) -----------------------------------
+// Device-resident integrator state: `step` (interval counter), `ts` (time grid), `sc` = {t, dt} of the
+// interval in flight.  All arithmetic is fp32 in the reference's operation order (sampling.py:43-48,74),
+// with FMA contraction disabled, so a step is reproducible against the CPU oracle to rounding.
+// First kernel of a step: reads ts[*step], publishes sc/tvec, then advances the counter.
+int ode_time_launch(int* step, const float* ts, float t_scale, int rk4, float* sc, float* tvec, int rows, hipStream_t s);
+// v = cfg_on ? v_nc + cfg*(v_c - v_nc) : v   with v2 = [v_c ; v_nc] (n elements each)
+int ode_euler_update_launch(float* x, const float* v2, int n, int cfg_on, float cfg, float dt, hipStream_t s);
+// k_out = v ; xs = y + (full ? dt*k : dt*k/2) ; tvec[:] = (t + (tsel==1 ? dt/2 : dt)) * t_scale
+int ode_rk4_stage_launch(const float* sc, const float* y, float* xs, float* k_out, const float* v2, int n, int cfg_on, float cfg,
+                         int full, int tsel, float t_scale, float* tvec, int rows, hipStream_t s);
+// y += (dt/6) * (k1 + 2*k2 + 2*k3 + v)
+int ode_rk4_final_launch(const float* sc, float* y, const float* k1, const float* k2, const float* k3, const float* v2, int n,
+                         int cfg_on, float cfg, hipStream_t s);
+
+// ---- weight packing (pack.hip) ----------------------------------------------------------------
+int pack_conv_launch(const float* oihw, float* dst /*[KK][I][O]*/, int O, int I, int KH, int KW, hipStream_t s);
+int pack_s2d_conv_launch(const float* oi, float* dst /*[4][C][O]*/, int O, int C, hipStream_t s);  // Downsample: (c p1 p2) -> 2x2 s2
+int pack_transpose_launch(const float* src /*[R][Cc]*/, float* dst /*[Cc][R]*/, int R, int Cc, int dst_ld, int dst_col0,
+                          hipStream_t s);
+
+// ---- OT (ot.hip) ------------------------------------------------------------------------------
+int ot_launch(const float* src, const float* tgt, int B, int64_t D, float* dist, int64_t* perm, hipStream_t s);
+
+}  // namespace fc

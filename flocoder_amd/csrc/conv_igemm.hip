@@ -1,0 +1,505 @@
+// Implicit-GEMM convolution for gfx950 on the exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32).
+//
+//   out[b,y,x,:] = bias + sum_{ky,kx,c} W[ky,kx,c,:] * X(b, y*s-p+ky, x*s-p+kx, c)
+//
+// X is the *logical* input: up to two NHWC tensors concatenated along C, each optionally passed through
+// "GroupNorm affine (+FiLM) (+SiLU)" while it is staged, optionally nearest-x2 upsampled -- so torch.cat,
+// nn.Upsample, the space-to-depth Rearrange, GroupNorm, the scale/shift modulation and SiLU of the
+// reference's Block/ResnetBlock (unet.py:42-96) never exist as separate passes over HBM.
+//
+// Work decomposition (one 256-thread workgroup = 4 wave64):
+//   M tile = TB samples x TH rows x TW cols of output pixels (BM = 32*MT*WM of them), N tile = BN output
+//   channels, K = KS*KS*Cin walked in chunks of CC input channels.  Per chunk the workgroup stages
+//     patch[TB][PH][PW][CC(+1 pad)]   the input window incl. halo, transformed, zero outside the image
+//     wl[KS*KS][CC][BN]               the weight slab
+//   in LDS once; the 9 taps then read the patch at constant offsets, so each input element is fetched
+//   from L2/HBM once per (tile, chunk) rather than once per tap.  Waves are laid out WM x WN x WK: WK > 1
+//   splits the K steps of a chunk across waves (small-M layers would otherwise leave 3 of 4 SIMDs idle
+//   behind one wave's 64-cycle MFMA issue), partial accumulators meet in LDS in the epilogue.
+//   MFMA operand maps (cdna_hip_programming.md 3): A lane l = A[row l&31][k l>>5], B lane l = B[k l>>5][col l&31],
+//   D reg r = D[row (r&3)+8*(r>>2)+4*(l>>5)][col l&31].
+//
+// Epilogue: + bias, per-tile GroupNorm partials (mean, M2) of the result written without atomics, optional
+// SiLU, optional residual add, optional second accumulator = 1x1 projection of the centre tap
+// (ResnetBlock.res_conv shares conv1's staged input).
+#include "common.h"
+
+namespace fc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvDev {
+    ConvArgs a;
+    int TWl, THl, TB, PH, PW, P;
+    int tiles_x, tiles_y, ntiles, nblocks;
+    int cpg, cpgt, NPG, rps;     // output-stats geometry
+    int act0, act1, any_xf;
+    int o_pixoff, o_pixtb, o_gstat, o_aff, o_patch, o_wl, o_wres, o_red, o_part;
+};
+
+__device__ __forceinline__ float silu_f(float z) { return z / (1.0f + __expf(-z)); }
+
+// bijective XCD remap (cdna_hip_programming.md 5 "XCD swizzle must be bijective"): blocks that share an
+// XCD (bid % 8) get a contiguous run of tile ids, so n-tiles of one m-tile and neighbouring m-tiles hit
+// the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <int WM, int WN, int WK, int MT, int NT, int CC>
+__global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvDev p) {
+    constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN, CS = CC + 1, KSTEPS = CC / 2, KPW = KSTEPS / WK, Q = CC / 4;
+    static_assert(WM * WN * WK == 4, "4 waves per workgroup");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const ConvArgs& a = p.a;
+    int* pixoff = reinterpret_cast<int*>(smem + p.o_pixoff);
+    int* pixtb = reinterpret_cast<int*>(smem + p.o_pixtb);
+    float* gstat = smem + p.o_gstat;
+    float2* aff = reinterpret_cast<float2*>(smem + p.o_aff);
+    float* patch = smem + p.o_patch;
+    float* wl = smem + p.o_wl;
+    float* wres = smem + p.o_wres;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
+
+    const int bid = xcd_remap(blockIdx.x, p.nblocks);
+    const int nt_i = bid % p.ntiles, mt_i = bid / p.ntiles;
+    const int tx = mt_i % p.tiles_x, ty = (mt_i / p.tiles_x) % p.tiles_y, bg = mt_i / (p.tiles_x * p.tiles_y);
+    const int TW = 1 << p.TWl, TH = 1 << p.THl;
+    const int b0 = bg * p.TB, y0 = ty * TH, x0 = tx * TW, n0 = nt_i * BN;
+    const int KS = a.KS, KK = KS * KS, PW = p.PW, PHW = p.PH * p.PW;
+    const int C0 = a.s0.C, C1 = a.s1.C, Cin = a.Cin, Cout = a.Cout;
+    const bool has_res = a.res_out != nullptr;
+
+    // ---- one-time tables: where each patch pixel lives in the source, and the GroupNorm moments ----
+    {
+        const int Hin = a.Hs << a.ups, Win = a.Ws << a.ups;
+        for (int i = tid; i < p.P; i += 256) {
+            const int tb = i / PHW, r = i - tb * PHW, py = r / PW, px = r - py * PW;
+            const int iy = y0 * a.stride - a.pad + py, ix = x0 * a.stride - a.pad + px, b = b0 + tb;
+            int off = -1;
+            if (b < a.B && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) off = (b * a.Hs + (iy >> a.ups)) * a.Ws + (ix >> a.ups);
+            pixoff[i] = off;
+            pixtb[i] = tb;
+        }
+        if (p.any_xf) {
+            const int G0 = a.s0.xf.mode ? a.s0.xf.G : 0, G1 = a.s1.xf.mode ? a.s1.xf.G : 0;
+            for (int i = tid; i < p.TB * (G0 + G1); i += 256) {
+                const bool first = i < p.TB * G0;
+                const SrcXform& xf = first ? a.s0.xf : a.s1.xf;
+                const int j = first ? i : i - p.TB * G0;
+                const int tb = j / xf.G, g = j - tb * xf.G, b = b0 + tb;
+                float mean = 0.f, rstd = 0.f;
+                if (b < a.B) {
+                    const float* sp = xf.stats + (size_t)(b * xf.G + g) * xf.T * 2;
+                    float sm = 0.f;
+                    for (int t = 0; t < xf.T; ++t) sm += sp[2 * t];
+                    mean = sm / (float)xf.T;
+                    float m2 = 0.f, dv = 0.f;
+                    for (int t = 0; t < xf.T; ++t) {
+                        const float d = sp[2 * t] - mean;
+                        m2 += sp[2 * t + 1];
+                        dv += d * d;
+                    }
+                    const float var = (m2 + xf.n_t * dv) / (xf.n_t * (float)xf.T);
+                    rstd = 1.0f / sqrtf(var + xf.eps);
+                }
+                gstat[2 * i] = mean;
+                gstat[2 * i + 1] = rstd;
+            }
+        }
+    }
+
+    // ---- per-lane operand bases ----
+    int abase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = (wm * MT + mt) * 32 + l31;
+        const int tw = m & (TW - 1), th = (m >> p.TWl) & (TH - 1), tb = m >> (p.TWl + p.THl);
+        abase[mt] = (tb * PHW + th * a.stride * PW + tw * a.stride) * CS + half;
+    }
+    const int bbase = half * BN + wn * NT * 32 + l31;
+    const int kk0 = wk * KPW;
+
+    f32x16 acc[MT][NT], accr[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[mt][nt][r] = 0.f; accr[mt][nt][r] = 0.f; }
+
+    const float* wbase = a.w + (size_t)b0 * a.w_batch_stride;
+
+    for (int c0 = 0; c0 < Cin; c0 += CC) {
+        // (a) per-(sample, channel) affine of this chunk:  x -> A*x + B  == GroupNorm, FiLM folded in
+        if (p.any_xf) {
+            const int G0n = a.s0.xf.mode ? a.s0.xf.G : 0;
+            for (int i = tid; i < p.TB * CC; i += 256) {
+                const int tb = i / CC, c = c0 + (i - tb * CC), b = b0 + tb;
+                float A = 1.f, Bv = 0.f;
+                if (c < Cin && b < a.B) {
+                    const bool first = c < C0;
+                    const SrcXform& xf = first ? a.s0.xf : a.s1.xf;
+                    if (xf.mode) {
+                        const int cs = first ? c : c - C0, Cs = first ? C0 : C1;
+                        const int g = cs / (Cs / xf.G);
+                        const float* gs = gstat + 2 * ((first ? 0 : p.TB * G0n) + tb * xf.G + g);
+                        A = gs[1] * xf.gamma[cs];
+                        Bv = xf.beta[cs] - gs[0] * A;
+                        if (xf.ss) {
+                            const float sc = xf.ss[(size_t)b * xf.ss_stride + cs] + 1.0f;
+                            const float sh = xf.ss[(size_t)b * xf.ss_stride + Cs + cs];
+                            A *= sc;
+                            Bv = Bv * sc + sh;
+                        }
+                    }
+                }
+                aff[i] = make_float2(A, Bv);
+            }
+        }
+        __syncthreads();  // previous chunk's MFMAs are done with patch/wl; aff + tables visible
+
+        // (b) stage the input window ...
+        for (int e = tid; e < p.P * Q; e += 256) {
+            const int pix = e / Q, q = e - pix * Q, c = c0 + 4 * q;
+            const int po = pixoff[pix];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (po >= 0 && c < Cin) {
+                const bool first = c < C0;
+                v = first ? *reinterpret_cast<const float4*>(a.s0.p + (size_t)po * C0 + c)
+                          : *reinterpret_cast<const float4*>(a.s1.p + (size_t)po * C1 + (c - C0));
+                if (p.any_xf) {
+                    const float2* ab = aff + pixtb[pix] * CC + 4 * q;
+                    v.x = ab[0].x * v.x + ab[0].y;
+                    v.y = ab[1].x * v.y + ab[1].y;
+                    v.z = ab[2].x * v.z + ab[2].y;
+                    v.w = ab[3].x * v.w + ab[3].y;
+                    if (first ? p.act0 : p.act1) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+                }
+            }
+            float* d = patch + pix * CS + 4 * q;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        // ... and the weight slab [tap][c][BN]
+        for (int e = tid; e < KK * CC * (BN / 4); e += 256) {
+            const int n4 = e % (BN / 4), c = (e / (BN / 4)) % CC, tap = e / (BN / 4 * CC);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c0 + c < Cin && n0 + 4 * n4 < Cout)
+                v = *reinterpret_cast<const float4*>(wbase + ((size_t)tap * Cin + c0 + c) * Cout + n0 + 4 * n4);
+            *reinterpret_cast<float4*>(wl + (tap * CC + c) * BN + 4 * n4) = v;
+        }
+        if (has_res) {
+            for (int e = tid; e < CC * (BN / 4); e += 256) {
+                const int n4 = e % (BN / 4), c = e / (BN / 4);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c0 + c < Cin && n0 + 4 * n4 < Cout)
+                    v = *reinterpret_cast<const float4*>(a.res_w + (size_t)(c0 + c) * Cout + n0 + 4 * n4);
+                *reinterpret_cast<float4*>(wres + c * BN + 4 * n4) = v;
+            }
+        }
+        __syncthreads();
+
+        // (c) MFMA over taps x this wave's K steps
+        for (int ky = 0; ky < KS; ++ky) {
+            for (int kx = 0; kx < KS; ++kx) {
+                const int tapoff = (ky * PW + kx) * CS;
+                const float* wt = wl + (ky * KS + kx) * CC * BN + bbase;
+#pragma unroll
+                for (int kk = 0; kk < KPW; ++kk) {
+                    const int k = 2 * (kk0 + kk);
+                    float av[MT], bv[NT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) av[mt] = patch[abase[mt] + tapoff + k];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bv[nt] = wt[k * BN + nt * 32];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+                }
+                if (has_res && ky == a.pad && kx == a.pad) {
+#pragma unroll
+                    for (int kk = 0; kk < KPW; ++kk) {
+                        const int k = 2 * (kk0 + kk);
+                        float av[MT], bv[NT];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) av[mt] = patch[abase[mt] + tapoff + k];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) bv[nt] = wres[(k + half) * BN + wn * NT * 32 + l31 + nt * 32];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                accr[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], accr[mt][nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue ----
+    if (WK > 1) {  // meet the K-split partials in LDS (patch/wl are dead now)
+        __syncthreads();
+        float* red = smem + p.o_red;
+        constexpr int TILE = 16 * 64;
+        const int slot = ((wm * WN + wn) * (WK - 1) + (wk - 1)) * MT * NT * (has_res ? 2 : 1);
+        if (wk > 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float* d = red + (size_t)(slot + mt * NT + nt) * TILE + lane;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) d[r * 64] = acc[mt][nt][r];
+                    if (has_res) {
+                        float* dr = red + (size_t)(slot + MT * NT + mt * NT + nt) * TILE + lane;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dr[r * 64] = accr[mt][nt][r];
+                    }
+                }
+        }
+        __syncthreads();
+        if (wk == 0) {
+            for (int k2 = 1; k2 < WK; ++k2) {
+                const int sl = ((wm * WN + wn) * (WK - 1) + (k2 - 1)) * MT * NT * (has_res ? 2 : 1);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float* d = red + (size_t)(sl + mt * NT + nt) * TILE + lane;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[mt][nt][r] += d[r * 64];
+                        if (has_res) {
+                            const float* dr = red + (size_t)(sl + MT * NT + mt * NT + nt) * TILE + lane;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) accr[mt][nt][r] += dr[r * 64];
+                        }
+                    }
+            }
+        }
+    }
+
+    const bool owner = (wk == 0);
+    float* partS = smem + p.o_part;               // [BM/16][BN]
+    float* partQ = partS + (BM / 16) * BN;        // [BM/16][BN]
+    float* colS = partQ + (BM / 16) * BN;         // [TB][BN]
+    float* colQ = colS + p.TB * BN;
+    if (a.stats_out) __syncthreads();             // patch/wl (aliased by part*) are dead for every wave
+
+    if (owner) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int ncol = (wn * NT + nt) * 32 + l31, n = n0 + ncol;
+                const bool nok = n < Cout;
+                const float bias = (a.bias && nok) ? a.bias[n] : 0.f;
+                const float rbias = (has_res && a.res_b && nok) ? a.res_b[n] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] += bias;
+                if (a.stats_out) {
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        float s = 0.f, q = 0.f;
+#pragma unroll
+                        for (int r = 8 * hh; r < 8 * hh + 8; ++r) { const float v = acc[mt][nt][r]; s += v; q += v * v; }
+                        s += __shfl_xor(s, 32);
+                        q += __shfl_xor(q, 32);
+                        if (half == 0) {
+                            const int hb = (wm * MT + mt) * 2 + hh;
+                            partS[hb * BN + ncol] = s;
+                            partQ[hb * BN + ncol] = q;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int tw = m & (TW - 1), th = (m >> p.TWl) & (TH - 1), tb = m >> (p.TWl + p.THl);
+                    const int b = b0 + tb;
+                    if (nok && b < a.B) {
+                        const size_t o = ((size_t)(b * a.H + y0 + th) * a.W + x0 + tw) * Cout + n;
+                        float v = acc[mt][nt][r];
+                        if (a.out_act) v = silu_f(v);
+                        if (a.add) v += a.add[o];
+                        a.out[o] = v;
+                        if (has_res) a.res_out[o] = accr[mt][nt][r] + rbias;
+                    }
+                }
+            }
+    }
+
+    if (a.stats_out) {
+        __syncthreads();
+        const int hb_per = p.rps >> 4;  // 16-row half-blocks per sample in this tile
+        for (int i = tid; i < p.TB * BN; i += 256) {
+            const int tb = i / BN, col = i - tb * BN;
+            float s = 0.f, q = 0.f;
+            for (int h = 0; h < hb_per; ++h) { s += partS[(tb * hb_per + h) * BN + col]; q += partQ[(tb * hb_per + h) * BN + col]; }
+            colS[i] = s;
+            colQ[i] = q;
+        }
+        __syncthreads();
+        const int ncols = min(BN, Cout - n0), GT = ncols / p.cpgt;
+        for (int i = tid; i < p.TB * GT; i += 256) {
+            const int tb = i / GT, gl = i - tb * GT, b = b0 + tb;
+            if (b >= a.B) continue;
+            float s = 0.f, q = 0.f;
+            for (int c = 0; c < p.cpgt; ++c) { s += colS[tb * BN + gl * p.cpgt + c]; q += colQ[tb * BN + gl * p.cpgt + c]; }
+            const float n = (float)(p.rps * p.cpgt), mean = s / n;
+            const int g = n0 / p.cpg + (p.cpg >= BN ? 0 : gl);
+            const int nsub = (p.cpg >= BN) ? (n0 % p.cpg) / BN : 0;
+            const int msub = (p.TB > 1) ? 0 : ty * p.tiles_x + tx;
+            const int T = (p.TB > 1 ? 1 : p.tiles_x * p.tiles_y) * p.NPG;
+            float* d = a.stats_out + ((size_t)(b * a.Gout + g) * T + msub * p.NPG + nsub) * 2;
+            d[0] = mean;
+            d[1] = q - s * mean;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <int WM, int WN, int WK, int MT, int NT, int CC>
+struct TileTraits {
+    static constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN, cc = CC, wk = WK, mtnt = MT * NT, wmwn = WM * WN;
+};
+
+struct TileInfo { int BM, BN, CC, WK, MTNT, WMWN; };
+static const TileInfo kTiles[TILE_COUNT] = {
+    {128, 32, 32, 1, 1, 4},  // TILE_M128N32
+    {128, 64, 16, 1, 2, 4},  // TILE_M128N64
+    {64, 32, 32, 2, 1, 2},   // TILE_M64N32K2
+    {32, 32, 32, 4, 1, 1},   // TILE_M32N32K4
+    {64, 64, 16, 2, 2, 2},   // TILE_M64N64K2
+};
+
+static int align4(int v) { return (v + 3) & ~3; }
+
+static int conv_geometry(const ConvArgs& a, int tile, ConvDev* d, ConvGeom* g) {
+    if (tile < 0 || tile >= TILE_COUNT) return fail(FC_E_ARG, "conv: bad tile id");
+    const TileInfo& t = kTiles[tile];
+    if (!is_pow2(a.H) || !is_pow2(a.W)) return fail(FC_E_SHAPE, "conv: H and W must be powers of two");
+    if ((a.s0.C & 3) || (a.s1.C & 3) || (a.Cout & 3)) return fail(FC_E_SHAPE, "conv: channel counts must be multiples of 4");
+    if (a.s0.C + a.s1.C != a.Cin) return fail(FC_E_ARG, "conv: Cin != C0 + C1");
+    if (a.stride != 1 && a.stride != 2) return fail(FC_E_SHAPE, "conv: stride must be 1 or 2");
+    if (a.ups && a.stride != 1) return fail(FC_E_SHAPE, "conv: upsample needs stride 1");
+    if (a.res_out && (a.s0.xf.mode || a.s1.xf.mode)) return fail(FC_E_ARG, "conv: fused res needs untransformed input");
+    if (a.res_out && (a.pad >= a.KS)) return fail(FC_E_ARG, "conv: fused res needs a centre tap");
+    const int TW = a.W < 16 ? a.W : 16;
+    int TH = t.BM / TW;
+    if (TH > a.H) TH = a.H;
+    const int TB = t.BM / (TH * TW);
+    if (a.w_batch_stride && TB != 1) return fail(FC_E_SHAPE, "conv: per-sample weights need >= BM pixels per sample");
+    ConvDev& p = *d;
+    p.a = a;
+    p.TWl = ilog2(TW); p.THl = ilog2(TH); p.TB = TB;
+    p.PH = TH * a.stride + a.KS - a.stride;
+    p.PW = TW * a.stride + a.KS - a.stride;
+    p.P = TB * p.PH * p.PW;
+    p.tiles_x = a.W / TW; p.tiles_y = a.H / TH;
+    p.ntiles = cdiv(a.Cout, t.BN);
+    p.nblocks = cdiv(a.B, TB) * p.tiles_x * p.tiles_y * p.ntiles;
+    p.act0 = a.s0.xf.mode == 2; p.act1 = a.s1.xf.mode == 2;
+    p.any_xf = (a.s0.xf.mode != 0) || (a.s1.xf.mode != 0);
+    p.rps = TB > 1 ? a.H * a.W : t.BM;
+    p.cpg = p.cpgt = p.NPG = 1;
+    g->T = 0; g->n_t = 0.f;
+    if (a.stats_out) {
+        if (a.Gout <= 0 || a.Cout % a.Gout) return fail(FC_E_ARG, "conv: Cout not divisible by groups");
+        if (p.rps % 16) return fail(FC_E_SHAPE, "conv: fused GroupNorm partials need >= 16 pixels per sample");
+        p.cpg = a.Cout / a.Gout;
+        if (!is_pow2(p.cpg)) return fail(FC_E_SHAPE, "conv: channels per group must be a power of two");
+        p.cpgt = p.cpg < t.BN ? p.cpg : t.BN;
+        p.NPG = p.cpg >= t.BN ? p.cpg / t.BN : 1;
+        g->T = (TB > 1 ? 1 : p.tiles_x * p.tiles_y) * p.NPG;
+        g->n_t = (float)(p.rps * p.cpgt);
+    }
+    // LDS carve (in floats)
+    int o = 0;
+    p.o_pixoff = o; o += align4(p.P);
+    p.o_pixtb = o; o += align4(p.P);
+    const int G0 = a.s0.xf.mode ? a.s0.xf.G : 0, G1 = a.s1.xf.mode ? a.s1.xf.G : 0;
+    p.o_gstat = o; o += align4(2 * TB * (G0 + G1));
+    p.o_aff = o; o += align4(2 * TB * t.CC);
+    p.o_patch = o;
+    int main_sz = align4(p.P * (t.CC + 1));
+    p.o_wl = o + main_sz; main_sz += a.KS * a.KS * t.CC * t.BN;
+    p.o_wres = o + main_sz; if (a.res_out) main_sz += t.CC * t.BN;
+    // epilogue scratch aliases patch/wl
+    int epi = 0;
+    p.o_red = o;
+    if (t.WK > 1) epi = t.WMWN * (t.WK - 1) * t.MTNT * (a.res_out ? 2 : 1) * 1024;
+    p.o_part = o + epi;
+    if (a.stats_out) epi += 2 * (t.BM / 16) * t.BN + 2 * TB * t.BN;
+    o += main_sz > epi ? main_sz : epi;
+    g->tile = tile; g->grid = p.nblocks; g->lds = (size_t)o * sizeof(float);
+    if (g->lds > 160 * 1024) return fail(FC_E_SHAPE, "conv: tile does not fit in LDS");
+    return FC_OK;
+}
+
+static int auto_tile(const ConvArgs& a) {
+    const long M = (long)a.B * a.H * a.W;
+    const int hw = a.H * a.W;
+    auto blocks = [&](int t) { return (M / kTiles[t].BM) * cdiv(a.Cout, kTiles[t].BN); };
+    auto ok = [&](int t) { return !(a.w_batch_stride && hw < kTiles[t].BM) && M >= kTiles[t].BM; };
+    if (a.Cout >= 64 && ok(TILE_M128N64) && blocks(TILE_M128N64) >= 512) return TILE_M128N64;
+    if (ok(TILE_M128N32) && blocks(TILE_M128N32) >= 384) return TILE_M128N32;
+    if (a.Cout >= 64 && ok(TILE_M64N64K2) && blocks(TILE_M64N64K2) >= 384) return TILE_M64N64K2;
+    if (ok(TILE_M64N32K2) && blocks(TILE_M64N32K2) >= 256) return TILE_M64N32K2;
+    return TILE_M32N32K4;
+}
+
+int conv_plan(const ConvArgs& a, int tile, ConvGeom* g) {
+    ConvDev d;
+    if (tile == TILE_AUTO) tile = auto_tile(a);
+    return conv_geometry(a, tile, &d, g);
+}
+
+template <int WM, int WN, int WK, int MT, int NT, int CC>
+static int launch_t(const ConvDev& d, const ConvGeom& g, hipStream_t s) {
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, WK, MT, NT, CC>), dim3(g.grid), dim3(256), g.lds, s, d);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+template <int WM, int WN, int WK, int MT, int NT, int CC>
+static int allow_big_lds() {
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, WK, MT, NT, CC>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return FC_OK;
+}
+
+// Once per process, before any launch or graph capture: let every instantiation use the full 160 KiB of LDS.
+int conv_init() {
+    static bool done = false;
+    if (done) return FC_OK;
+    FC_TRY((allow_big_lds<4, 1, 1, 1, 1, 32>()));
+    FC_TRY((allow_big_lds<4, 1, 1, 1, 2, 16>()));
+    FC_TRY((allow_big_lds<2, 1, 2, 1, 1, 32>()));
+    FC_TRY((allow_big_lds<1, 1, 4, 1, 1, 32>()));
+    FC_TRY((allow_big_lds<2, 1, 2, 1, 2, 16>()));
+    done = true;
+    return FC_OK;
+}
+
+int conv_launch(const ConvArgs& a, int tile, hipStream_t s) {
+    ConvDev d;
+    ConvGeom g;
+    if (tile == TILE_AUTO) tile = auto_tile(a);
+    FC_TRY(conv_geometry(a, tile, &d, &g));
+    switch (tile) {
+        case TILE_M128N32: return launch_t<4, 1, 1, 1, 1, 32>(d, g, s);
+        case TILE_M128N64: return launch_t<4, 1, 1, 1, 2, 16>(d, g, s);
+        case TILE_M64N32K2: return launch_t<2, 1, 2, 1, 1, 32>(d, g, s);
+        case TILE_M32N32K4: return launch_t<1, 1, 4, 1, 1, 32>(d, g, s);
+        case TILE_M64N64K2: return launch_t<2, 1, 2, 1, 2, 16>(d, g, s);
+    }
+    return fail(FC_E_ARG, "conv: bad tile id");
+}
+
+}  // namespace fc

@@ -1,0 +1,264 @@
+// HBM-bound helper kernels: GroupNorm finalisation with residual, the boundary 1x1 convolutions that
+// change layout (NCHW <-> NHWC), layout converters, bilinear resize, standalone GroupNorm statistics.
+#include "common.h"
+
+namespace fc {
+
+__device__ __forceinline__ float silu_e(float z) { return z / (1.0f + __expf(-z)); }
+
+__device__ __forceinline__ float block_sum(float v, float* red /*[4]*/) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// combine T equal-count (mean, M2) partials of group g of sample b
+__device__ __forceinline__ void combine_partials(const SrcXform& xf, int b, int g, float* mean_out, float* rstd_out) {
+    const float* sp = xf.stats + (size_t)(b * xf.G + g) * xf.T * 2;
+    float sm = 0.f;
+    for (int t = 0; t < xf.T; ++t) sm += sp[2 * t];
+    const float mean = sm / (float)xf.T;
+    float m2 = 0.f, dv = 0.f;
+    for (int t = 0; t < xf.T; ++t) {
+        const float d = sp[2 * t] - mean;
+        m2 += sp[2 * t + 1];
+        dv += d * d;
+    }
+    const float var = (m2 + xf.n_t * dv) / (xf.n_t * (float)xf.T);
+    *mean_out = mean;
+    *rstd_out = 1.0f / sqrtf(var + xf.eps);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// y = act(GroupNorm(h) [FiLM]) + res ; optional GroupNorm(1) partials of y.   grid (bps, B)
+// Closes Block/ResnetBlock (unet.py:66-72,96) and Residual(PreNorm(LinearAttention)) (unet.py:39,133).
+__global__ void __launch_bounds__(256) finalize_kernel(const FinalizeArgs a, int bps) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* gm = sm;                 // [G][2]
+    float* A = sm + 2 * a.xf.G;     // [C]
+    float* Bv = A + a.C;            // [C]
+    __shared__ float red[4];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int g = tid; g < a.xf.G; g += 256) combine_partials(a.xf, b, g, &gm[2 * g], &gm[2 * g + 1]);
+    __syncthreads();
+    const int cpg = a.C / a.xf.G;
+    for (int c = tid; c < a.C; c += 256) {
+        const int g = c / cpg;
+        float s = gm[2 * g + 1] * a.xf.gamma[c];
+        float t = a.xf.beta[c] - gm[2 * g] * s;
+        if (a.xf.ss) {
+            const float sc = a.xf.ss[(size_t)b * a.xf.ss_stride + c] + 1.0f;
+            const float sh = a.xf.ss[(size_t)b * a.xf.ss_stride + a.C + c];
+            s *= sc;
+            t = t * sc + sh;
+        }
+        A[c] = s;
+        Bv[c] = t;
+    }
+    __syncthreads();
+    const int per = a.HW * a.C / bps;  // elements of this block (multiple of 4)
+    const size_t base = (size_t)b * a.HW * a.C + (size_t)blockIdx.x * per;
+    const bool act = a.xf.mode == 2;
+    float s = 0.f, q = 0.f;
+    for (int i = 4 * tid; i < per; i += 1024) {
+        const int c = (int)((blockIdx.x * (size_t)per + i) % a.C);
+        float4 v = *reinterpret_cast<const float4*>(a.h + base + i);
+        v.x = A[c] * v.x + Bv[c];
+        v.y = A[c + 1] * v.y + Bv[c + 1];
+        v.z = A[c + 2] * v.z + Bv[c + 2];
+        v.w = A[c + 3] * v.w + Bv[c + 3];
+        if (act) { v.x = silu_e(v.x); v.y = silu_e(v.y); v.z = silu_e(v.z); v.w = silu_e(v.w); }
+        if (a.res) {
+            const float4 r = *reinterpret_cast<const float4*>(a.res + base + i);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        *reinterpret_cast<float4*>(a.y + base + i) = v;
+        s += (v.x + v.y) + (v.z + v.w);
+        q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    if (a.stats_out) {
+        const float S = block_sum(s, red);
+        const float Q = block_sum(q, red);
+        if (tid == 0) {
+            const float mean = S / (float)per;
+            float* d = a.stats_out + ((size_t)b * bps + blockIdx.x) * 2;
+            d[0] = mean;
+            d[1] = Q - S * mean;
+        }
+    }
+}
+
+int finalize_blocks_per_sample(int HW, int C) {
+    int per = HW * C;  // elements per sample
+    int bps = 1;
+    while (bps < 64 && per / (bps * 2) >= 4096 && (per / (bps * 2)) % 4 == 0) bps *= 2;
+    return bps;
+}
+
+int finalize_launch(const FinalizeArgs& a, hipStream_t s) {
+    if (a.C & 3) return fail(FC_E_SHAPE, "finalize: C must be a multiple of 4");
+    if (!a.xf.mode || !a.xf.stats) return fail(FC_E_ARG, "finalize: needs GroupNorm statistics");
+    const int bps = finalize_blocks_per_sample(a.HW, a.C);
+    const size_t lds = (size_t)(2 * a.xf.G + 2 * a.C) * sizeof(float);
+    hipLaunchKernelGGL(finalize_kernel, dim3(bps, a.B), dim3(256), lds, s, a, bps);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Standalone GroupNorm statistics (T = 1) for tensors with fewer than 16 pixels per sample, where the
+// conv epilogue cannot produce them.  grid (G, B)
+__global__ void __launch_bounds__(256) gn_stats_kernel(const float* x, float* stats, int HW, int C, int G) {
+    __shared__ float red[4];
+    const int b = blockIdx.y, g = blockIdx.x, cpg = C / G, n = HW * cpg;
+    const float* xb = x + (size_t)b * HW * C + g * cpg;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += xb[(size_t)(i / cpg) * C + i % cpg];
+    const float mean = block_sum(s, red) / (float)n;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) { const float d = xb[(size_t)(i / cpg) * C + i % cpg] - mean; q += d * d; }
+    const float M2 = block_sum(q, red);
+    if (threadIdx.x == 0) { stats[((size_t)b * G + g) * 2] = mean; stats[((size_t)b * G + g) * 2 + 1] = M2; }
+}
+
+int gn_stats_launch(const float* x, float* stats, int B, int HW, int C, int G, hipStream_t s) {
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(G, B), dim3(256), 0, s, x, stats, HW, C, G);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// init_conv (unet.py:185-186,295): 1x1 conv reading the NCHW boundary tensor, writing NHWC.
+__global__ void __launch_bounds__(256) init_conv_kernel(const float* x, int bmod, const float* w, const float* bias, float* out,
+                                                        int B, int Cin, int HW, int Cout) {
+    const int q = Cout / 4;
+    const size_t total = (size_t)B * HW * q;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int co = (int)(i % q) * 4;
+        const size_t bp = i / q;
+        const int pix = (int)(bp % HW), b = (int)(bp / HW);
+        const float* xb = x + (size_t)(b % bmod) * Cin * HW + pix;
+        float4 acc = bias ? *reinterpret_cast<const float4*>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float xv = xb[(size_t)ci * HW];
+            const float4 wv = *reinterpret_cast<const float4*>(w + (size_t)ci * Cout + co);
+            acc.x += xv * wv.x; acc.y += xv * wv.y; acc.z += xv * wv.z; acc.w += xv * wv.w;
+        }
+        *reinterpret_cast<float4*>(out + bp * Cout + co) = acc;
+    }
+}
+
+int init_conv_launch(const float* x, int bmod, const float* w, const float* bias, float* out, int B, int Cin, int HW, int Cout,
+                     hipStream_t s) {
+    if (Cout & 3) return fail(FC_E_SHAPE, "init_conv: Cout must be a multiple of 4");
+    const size_t total = (size_t)B * HW * (Cout / 4);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(init_conv_kernel, dim3(grid), dim3(256), 0, s, x, bmod, w, bias, out, B, Cin, HW, Cout);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+// final_conv (unet.py:286,372): 1x1 conv reading NHWC, writing the NCHW boundary tensor.
+__global__ void __launch_bounds__(256) final_conv_kernel(const float* x, const float* w, const float* bias, float* out, int B, int Cin,
+                                                         int HW, int Cout) {
+    extern __shared__ float wsm[];  // [Cin][Cout] + [Cout]
+    for (int i = threadIdx.x; i < Cin * Cout; i += 256) wsm[i] = w[i];
+    for (int i = threadIdx.x; i < Cout; i += 256) wsm[Cin * Cout + i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+    const size_t total = (size_t)B * HW;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int pix = (int)(i % HW), b = (int)(i / HW);
+        const float* xp = x + i * Cin;
+        for (int co0 = 0; co0 < Cout; co0 += 4) {
+            float acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = (co0 + j < Cout) ? wsm[Cin * Cout + co0 + j] : 0.f;
+            for (int ci = 0; ci < Cin; ci += 4) {
+                const float4 xv = *reinterpret_cast<const float4*>(xp + ci);
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (co0 + j < Cout) acc[j] += xs[k] * wsm[(ci + k) * Cout + co0 + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (co0 + j < Cout) out[((size_t)b * Cout + co0 + j) * HW + pix] = acc[j];
+        }
+    }
+}
+
+int final_conv_launch(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int HW, int Cout, hipStream_t s) {
+    if (Cin & 3) return fail(FC_E_SHAPE, "final_conv: Cin must be a multiple of 4");
+    const size_t total = (size_t)B * HW;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(final_conv_kernel, dim3(grid), dim3(256), (size_t)(Cin * Cout + Cout) * sizeof(float), s, x, w, bias, out, B,
+                       Cin, HW, Cout);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* src, float* dst, int B, int C, int HW, int Cpad, int bmod) {
+    const size_t total = (size_t)B * HW * Cpad;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % Cpad);
+        const size_t bp = i / Cpad;
+        const int pix = (int)(bp % HW), b = (int)(bp / HW);
+        dst[i] = c < C ? src[((size_t)(b % bmod) * C + c) * HW + pix] : 0.f;
+    }
+}
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const float* src, float* dst, int B, int C, int HW, int Cpad) {
+    const size_t total = (size_t)B * C * HW;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int pix = (int)(i % HW);
+        const size_t bc = i / HW;
+        const int c = (int)(bc % C), b = (int)(bc / C);
+        dst[i] = src[((size_t)b * HW + pix) * Cpad + c];
+    }
+}
+static int grid_for(size_t total) { size_t g = (total + 255) / 256; return (int)(g < 8192 ? (g ? g : 1) : 8192); }
+
+int nchw_to_nhwc_launch(const float* src, float* dst, int B, int C, int HW, int Cpad, int bmod, hipStream_t s) {
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((size_t)B * HW * Cpad)), dim3(256), 0, s, src, dst, B, C, HW, Cpad,
+                       bmod > 0 ? bmod : B);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+int nhwc_to_nchw_launch(const float* src, float* dst, int B, int C, int HW, int Cpad, hipStream_t s) {
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((size_t)B * C * HW)), dim3(256), 0, s, src, dst, B, C, HW, Cpad);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+// F.interpolate(mode='bilinear', align_corners=False) on NHWC (unet.py:338,362)
+__global__ void __launch_bounds__(256) bilinear_kernel(const float* src, float* dst, int B, int C, int Hs, int Ws, int Hd, int Wd) {
+    const size_t total = (size_t)B * Hd * Wd * C;
+    const float sy = (float)Hs / (float)Hd, sx = (float)Ws / (float)Wd;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int x = (int)(r % Wd); r /= Wd;
+        const int y = (int)(r % Hd), b = (int)(r / Hd);
+        float fy = ((float)y + 0.5f) * sy - 0.5f, fx = ((float)x + 0.5f) * sx - 0.5f;
+        fy = fy < 0.f ? 0.f : fy; fx = fx < 0.f ? 0.f : fx;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float* sb = src + (size_t)b * Hs * Ws * C + c;
+        const float v00 = sb[((size_t)y0 * Ws + x0) * C], v01 = sb[((size_t)y0 * Ws + x1) * C];
+        const float v10 = sb[((size_t)y1 * Ws + x0) * C], v11 = sb[((size_t)y1 * Ws + x1) * C];
+        dst[i] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+    }
+}
+int bilinear_nhwc_launch(const float* src, float* dst, int B, int C, int Hs, int Ws, int Hd, int Wd, hipStream_t s) {
+    hipLaunchKernelGGL(bilinear_kernel, dim3(grid_for((size_t)B * Hd * Wd * C)), dim3(256), 0, s, src, dst, B, C, Hs, Ws, Hd, Wd);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+}  // namespace fc

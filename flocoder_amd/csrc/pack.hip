@@ -1,0 +1,58 @@
+// Weight re-layout from the reference's state_dict tensors to the kernels' operand layouts.  Runs once per
+// fc_unet_load_params (and once per optimiser step when training), HBM-bound and tiny.
+#include "common.h"
+
+namespace fc {
+
+// OIHW -> [KH*KW][I][O]
+__global__ void __launch_bounds__(256) pack_conv_kernel(const float* src, float* dst, int O, int I, int KK) {
+    const size_t total = (size_t)O * I * KK;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int o = (int)(i % O);
+        const size_t r = i / O;
+        const int ci = (int)(r % I), tap = (int)(r / I);
+        dst[i] = src[((size_t)o * I + ci) * KK + tap];
+    }
+}
+
+// Downsample (unet.py:52-53): Rearrange 'b c (h p1) (w p2) -> b (c p1 p2) h w' followed by a 1x1 conv over 4C
+// channels is a 2x2 stride-2 conv over C channels: dst[tap = p1*2+p2][c][o] = src[o][c*4 + p1*2 + p2].
+__global__ void __launch_bounds__(256) pack_s2d_kernel(const float* src, float* dst, int O, int C) {
+    const size_t total = (size_t)O * C * 4;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int o = (int)(i % O);
+        const size_t r = i / O;
+        const int c = (int)(r % C), tap = (int)(r / C);
+        dst[i] = src[(size_t)o * 4 * C + c * 4 + tap];
+    }
+}
+
+// src [R][Cc] -> dst[c][dst_col0 + r] with leading dimension dst_ld  (Linear [out][in] -> [in][out], optionally
+// into a slice of a wider concatenated matrix)
+__global__ void __launch_bounds__(256) pack_transpose_kernel(const float* src, float* dst, int R, int Cc, int dst_ld, int dst_col0) {
+    const size_t total = (size_t)R * Cc;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i % R), c = (int)(i / R);
+        dst[(size_t)c * dst_ld + dst_col0 + r] = src[(size_t)r * Cc + c];
+    }
+}
+
+static int pgrid(size_t total) { size_t g = (total + 255) / 256; return (int)(g < 4096 ? (g ? g : 1) : 4096); }
+
+int pack_conv_launch(const float* oihw, float* dst, int O, int I, int KH, int KW, hipStream_t s) {
+    hipLaunchKernelGGL(pack_conv_kernel, dim3(pgrid((size_t)O * I * KH * KW)), dim3(256), 0, s, oihw, dst, O, I, KH * KW);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+int pack_s2d_conv_launch(const float* oi, float* dst, int O, int C, hipStream_t s) {
+    hipLaunchKernelGGL(pack_s2d_kernel, dim3(pgrid((size_t)O * C * 4)), dim3(256), 0, s, oi, dst, O, C);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+int pack_transpose_launch(const float* src, float* dst, int R, int Cc, int dst_ld, int dst_col0, hipStream_t s) {
+    hipLaunchKernelGGL(pack_transpose_kernel, dim3(pgrid((size_t)R * Cc)), dim3(256), 0, s, src, dst, R, Cc, dst_ld, dst_col0);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+}  // namespace fc

@@ -1,0 +1,827 @@
+// Native runtime of the velocity U-Net: parameter table with the reference's state_dict names, weight
+// packing, a static launch plan over a fixed activation arena, and the hipGraph-captured ODE step.
+//
+// Topology follows Unet._forward (unet.py:289-372); every kernel launch below cites the reference lines it
+// covers.  The plan is built once per (max_batch, H, W) -- buffers never move, so one integration step can be
+// captured in a hipGraph and replayed (the reference's per-call host syncs are gone).
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+
+namespace fc {
+
+static thread_local std::string g_err;
+void set_error(const std::string& m) { g_err = m; }
+int fail(int code, const std::string& m) { g_err = m; return code; }
+const char* last_error() { return g_err.c_str(); }
+
+struct Param {
+    std::string name;
+    int64_t shape[4] = {0, 0, 0, 0};
+    int64_t numel = 0, offset = 0;
+};
+
+struct Act { float* p = nullptr; int C = 0, H = 0, W = 0; };
+struct Stat { float* p = nullptr; int G = 0, T = 0; float n_t = 0.f; };
+
+struct FwdCtx {             // per-call inputs of one U-Net forward
+    const float* x = nullptr;          // NCHW [x_mod][C][H][W]
+    int x_mod = 0;                     // row b reads sample b % x_mod (CFG: both halves share x)
+    const float* time = nullptr;       // [B]
+    const int64_t* ids = nullptr;      // [ids_mod] or null
+    int ids_mod = 0, null_from = 0;
+    const float* mask = nullptr;       // NCHW [x_mod][C][H][W] or null
+    int mask_fuse = 0;                 // run mask_fusion_conv (mask present and not all ones)
+    float* out = nullptr;              // NCHW [B][C][H][W]
+    int B = 0;
+};
+using Op = std::function<int(const FwdCtx&, hipStream_t)>;
+
+struct PackOp { int kind; int64_t src, dst; int a, b, c, d; };  // kind 0 conv OIHW, 1 s2d, 2 transpose(R=a,Cc=b,ld=c,col0=d), 3 copy(a)
+
+}  // namespace fc
+
+using namespace fc;
+
+struct fc_unet {
+    fc_unet_config cfg{};
+    int device = 0;
+    int td = 0, heads = 4;
+    std::vector<int> chans;  // [dim, dim*m0, dim*m1, ...]
+    std::vector<Param> params;
+    std::unordered_map<std::string, int> pidx;
+    int64_t raw_numel = 0, packed_numel = 0;
+    float *raw = nullptr, *packed = nullptr;
+    std::unordered_map<std::string, int64_t> pk;  // name -> offset into packed
+    std::vector<PackOp> packops;
+    int S = 0;                                    // total scale/shift width
+    std::unordered_map<std::string, int> ss_off;  // resblock prefix -> column offset
+    float* freqs = nullptr;
+    bool loaded = false;
+
+    // plan
+    int maxB = 0, H = 0, W = 0;
+    std::vector<Op> ops;
+    std::vector<void*> allocs;
+    double flops = 0.0;
+    float *t_emb = nullptr, *ss = nullptr;
+    std::map<std::string, fc::Act> named;   // debug taps: block outputs by reference module name
+
+    // integrator state (library-owned so captured graphs never see caller pointers)
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    int* step = nullptr;
+    float *ts_dev = nullptr, *sc = nullptr, *tvec = nullptr;
+    int ts_cap = 0;
+    float *y = nullptr, *xs = nullptr, *k1 = nullptr, *k2 = nullptr, *k3 = nullptr, *v2 = nullptr, *mask_own = nullptr;
+    int64_t* ids_own = nullptr;
+    std::map<std::tuple<int, int, int, int, uint32_t, uint32_t, uint32_t, int>, hipGraphExec_t> graphs;
+
+    const float* R(const std::string& n) const { return raw + params[pidx.at(n)].offset; }
+    const float* P(const std::string& n) const { return packed + pk.at(n); }
+    bool has(const std::string& n) const { return pidx.count(n) != 0; }
+};
+
+namespace fc {
+
+// ------------------------------------------------------------------------------------------- parameters
+static void declare(fc_unet* u, const std::string& name, std::initializer_list<int64_t> shape) {
+    Param p;
+    p.name = name;
+    p.numel = 1;
+    int i = 0;
+    for (int64_t s : shape) { p.shape[i++] = s; p.numel *= s; }
+    p.offset = u->raw_numel;
+    u->raw_numel += (p.numel + 3) & ~3ll;  // keep every tensor 16-byte aligned inside `raw`
+    u->pidx[name] = (int)u->params.size();
+    u->params.push_back(p);
+}
+static int64_t pk_alloc(fc_unet* u, const std::string& name, int64_t numel) {
+    const int64_t off = u->packed_numel;
+    u->pk[name] = off;
+    u->packed_numel += (numel + 3) & ~3ll;
+    return off;
+}
+static void decl_conv(fc_unet* u, const std::string& n, int O, int I, int K, bool bias = true) {
+    declare(u, n + ".weight", {O, I, K, K});
+    if (bias) declare(u, n + ".bias", {O});
+    const int64_t dst = pk_alloc(u, n + ".weight", (int64_t)O * I * K * K);
+    u->packops.push_back({0, u->params[u->pidx[n + ".weight"]].offset, dst, O, I, K, K});
+}
+static void decl_linear_t(fc_unet* u, const std::string& n, int O, int I) {  // stored transposed [I][O]
+    declare(u, n + ".weight", {O, I});
+    declare(u, n + ".bias", {O});
+    const int64_t dst = pk_alloc(u, n + ".weight", (int64_t)O * I);
+    u->packops.push_back({2, u->params[u->pidx[n + ".weight"]].offset, dst, O, I, O, 0});
+}
+static void decl_norm(fc_unet* u, const std::string& n, int C) {
+    declare(u, n + ".weight", {C});
+    declare(u, n + ".bias", {C});
+}
+static void decl_resblock(fc_unet* u, const std::string& p, int cin, int cout) {
+    declare(u, p + ".mlp.1.weight", {2 * cout, u->td});
+    declare(u, p + ".mlp.1.bias", {2 * cout});
+    u->ss_off[p] = u->S;
+    u->S += 2 * cout;
+    decl_conv(u, p + ".block1.proj", cout, cin, 3);
+    decl_norm(u, p + ".block1.norm", cout);
+    decl_conv(u, p + ".block2.proj", cout, cout, 3);
+    decl_norm(u, p + ".block2.norm", cout);
+    if (cin != cout) decl_conv(u, p + ".res_conv", cout, cin, 1);
+}
+static void decl_linattn(fc_unet* u, const std::string& p, int C) {
+    const int hid = u->heads * 32;
+    decl_conv(u, p + ".fn.fn.to_qkv", 3 * hid, C, 1, false);   // PreNorm registers fn before norm (unet.py:156-157)
+    decl_conv(u, p + ".fn.fn.to_out.0", C, hid, 1);
+    decl_norm(u, p + ".fn.fn.to_out.1", C);
+    decl_norm(u, p + ".fn.norm", C);
+}
+
+static int declare_all(fc_unet* u) {
+    const fc_unet_config& c = u->cfg;
+    const int dim = c.dim, ch = c.channels, L = c.n_levels;
+    u->td = dim * 8;  // unet.py:197
+    u->chans.assign(1, dim);
+    for (int i = 0; i < L; ++i) u->chans.push_back(dim * c.dim_mults[i]);
+    const std::vector<int>& cs = u->chans;
+    decl_conv(u, "init_conv", dim, ch, 1);
+    decl_linear_t(u, "time_mlp.1", u->td, dim);
+    decl_linear_t(u, "time_mlp.3", u->td, u->td);
+    if (c.n_classes > 0) {
+        declare(u, "class_cond_mlp.0.weight", {c.n_classes, u->td});
+        decl_linear_t(u, "class_cond_mlp.1", u->td, u->td);
+        decl_linear_t(u, "class_cond_mlp.3", u->td, u->td);
+    }
+    if (c.mask_cond) {  // unet.py:214-235
+        decl_conv(u, "mask_fusion_conv.0", 2 * dim, dim + ch, 5);
+        decl_conv(u, "mask_fusion_conv.2", 2 * dim, 2 * dim, 3);
+        decl_conv(u, "mask_fusion_conv.4", dim, 2 * dim, 3);
+        for (int i = 0; i < 2 && i < L; ++i) decl_conv(u, "down_mask_fusions." + std::to_string(i) + ".0", cs[i], cs[i] + ch, 3);
+        for (int i = 0; i < 2 && i < L; ++i) decl_conv(u, "up_mask_fusions." + std::to_string(i) + ".0", cs[L - i], cs[L - i] + ch, 3);
+    }
+    for (int i = 0; i < L; ++i) {  // unet.py:242-258
+        const std::string p = "downs." + std::to_string(i);
+        decl_resblock(u, p + ".0", cs[i], cs[i]);
+        decl_resblock(u, p + ".1", cs[i], cs[i]);
+        decl_linattn(u, p + ".2", cs[i]);
+        if (i == L - 1) decl_conv(u, p + ".3", cs[i + 1], cs[i], 3);
+        else {
+            declare(u, p + ".3.1.weight", {cs[i + 1], 4 * cs[i], 1, 1});
+            declare(u, p + ".3.1.bias", {cs[i + 1]});
+            const int64_t dst = pk_alloc(u, p + ".3.1.weight", (int64_t)cs[i + 1] * 4 * cs[i]);
+            u->packops.push_back({1, u->params[u->pidx[p + ".3.1.weight"]].offset, dst, cs[i + 1], cs[i], 0, 0});
+        }
+    }
+    for (int i = 0; i < L; ++i) {  // unet.py:265-281, (dim_in, dim_out) = reversed(in_out)[i]
+        const std::string p = "ups." + std::to_string(i);
+        const int din = cs[L - 1 - i], dout = cs[L - i];
+        decl_resblock(u, p + ".0", dout + din, dout);
+        decl_resblock(u, p + ".1", dout + din, dout);
+        decl_linattn(u, p + ".2", dout);
+        decl_conv(u, i == L - 1 ? p + ".3" : p + ".3.1", din, dout, 3);
+    }
+    const int mid = cs[L];
+    decl_resblock(u, "mid_block1", mid, mid);
+    decl_conv(u, "mid_attn.fn.fn.to_qkv", 3 * u->heads * 32, mid, 1, false);
+    decl_conv(u, "mid_attn.fn.fn.to_out", mid, u->heads * 32, 1);
+    decl_norm(u, "mid_attn.fn.norm", mid);
+    decl_resblock(u, "mid_block2", mid, mid);
+    decl_resblock(u, "final_res_block", 2 * dim, dim);
+    decl_conv(u, "final_conv", ch, dim, 1);
+    // concatenated scale/shift projection of every ResnetBlock: wt [td][S], bias [S]
+    pk_alloc(u, "__ss_wt", (int64_t)u->td * u->S);
+    pk_alloc(u, "__ss_bias", u->S);
+    for (auto& kv : u->ss_off) {
+        const Param& w = u->params[u->pidx[kv.first + ".mlp.1.weight"]];
+        const Param& b = u->params[u->pidx[kv.first + ".mlp.1.bias"]];
+        u->packops.push_back({2, w.offset, u->pk["__ss_wt"], (int)w.shape[0], u->td, u->S, kv.second});
+        u->packops.push_back({3, b.offset, u->pk["__ss_bias"] + kv.second, (int)b.numel, 0, 0, 0});
+    }
+    return FC_OK;
+}
+
+static int run_pack(fc_unet* u, hipStream_t s) {
+    for (const PackOp& o : u->packops) {
+        const float* src = u->raw + o.src;
+        float* dst = u->packed + o.dst;
+        switch (o.kind) {
+            case 0: FC_TRY(pack_conv_launch(src, dst, o.a, o.b, o.c, o.d, s)); break;
+            case 1: FC_TRY(pack_s2d_conv_launch(src, dst, o.a, o.b, s)); break;
+            case 2: FC_TRY(pack_transpose_launch(src, dst, o.a, o.b, o.c, o.d, s)); break;
+            case 3: FC_HIP(hipMemcpyAsync(dst, src, (size_t)o.a * sizeof(float), hipMemcpyDeviceToDevice, s)); break;
+        }
+    }
+    return FC_OK;
+}
+
+// ------------------------------------------------------------------------------------------- plan builder
+struct Builder {
+    fc_unet* u;
+    int B;  // max batch
+    int err = FC_OK;
+
+    float* dmalloc(size_t floats) {
+        void* p = nullptr;
+        if (hipMalloc(&p, (floats ? floats : 1) * sizeof(float)) != hipSuccess) { err = fail(FC_E_HIP, "hipMalloc failed while reserving the arena"); return nullptr; }
+        u->allocs.push_back(p);
+        return static_cast<float*>(p);
+    }
+    Act act(int C, int H, int W) { Act a; a.C = C; a.H = H; a.W = W; a.p = dmalloc((size_t)B * H * W * C); return a; }
+    Stat stat(int G, int T, float n_t) { Stat s; s.G = G; s.T = T; s.n_t = n_t; s.p = dmalloc((size_t)B * G * T * 2); return s; }
+
+    static SrcXform xf_of(const Stat& st, int mode, const float* gamma, const float* beta, const float* ss = nullptr, int ss_stride = 0) {
+        SrcXform x;
+        x.mode = mode; x.stats = st.p; x.G = st.G; x.T = st.T; x.n_t = st.n_t;
+        x.gamma = gamma; x.beta = beta; x.ss = ss; x.ss_stride = ss_stride;
+        return x;
+    }
+
+    // Emits one implicit-GEMM launch (plus a standalone statistics pass when the output has < 16 pixels per sample).
+    // `want_G` > 0 asks for GroupNorm partials of the output; returns them in *st.
+    void conv(ConvArgs a, const Act& out, int want_G, Stat* st) {
+        if (err) return;
+        a.B = B; a.H = out.H; a.W = out.W; a.Cout = out.C; a.out = out.p;
+        a.Cin = a.s0.C + a.s1.C;
+        const bool fused = want_G > 0 && (out.H * out.W) % 16 == 0;
+        ConvGeom g;
+        if (fused) { a.Gout = want_G; a.stats_out = reinterpret_cast<float*>(1); }  // placeholder: geometry only
+        if ((err = conv_plan(a, TILE_AUTO, &g)) != FC_OK) return;
+        if (fused) { *st = stat(want_G, g.T, g.n_t); a.stats_out = st->p; }
+        const int tile = g.tile;
+        u->flops += 2.0 * out.H * out.W * a.KS * a.KS * (double)a.Cin * a.Cout;
+        if (a.res_out) u->flops += 2.0 * out.H * out.W * (double)a.Cin * a.Cout;
+        u->ops.push_back([a, tile](const FwdCtx& c, hipStream_t s) { ConvArgs b = a; b.B = c.B; return conv_launch(b, tile, s); });
+        if (want_G > 0 && !fused) {
+            *st = stat(want_G, 1, (float)(out.H * out.W * (out.C / want_G)));
+            float* sp = st->p; const float* xp = out.p; const int HW = out.H * out.W, C = out.C, G = want_G;
+            u->ops.push_back([=](const FwdCtx& c, hipStream_t s) { return gn_stats_launch(xp, sp, c.B, HW, C, G, s); });
+        }
+    }
+
+    // ResnetBlock (unet.py:76-96): conv1 [+res_conv] | conv2 with GN+FiLM+SiLU folded into its loader | finalize.
+    Act resblock(const std::string& p, const Act& x, const Act* skip, int cout, bool want_gn1, Stat* gn1) {
+        const int G = u->cfg.groups, cin = x.C + (skip ? skip->C : 0);
+        Act h1 = act(cout, x.H, x.W), h2 = act(cout, x.H, x.W), out = act(cout, x.H, x.W), rb;
+        Stat st1, st2;
+        ConvArgs a;
+        a.s0.p = x.p; a.s0.C = x.C;
+        if (skip) { a.s1.p = skip->p; a.s1.C = skip->C; }
+        a.Hs = x.H; a.Ws = x.W; a.KS = 3; a.pad = 1;
+        a.w = u->P(p + ".block1.proj.weight"); a.bias = u->R(p + ".block1.proj.bias");
+        if (cin != cout) {
+            rb = act(cout, x.H, x.W);
+            a.res_w = u->P(p + ".res_conv.weight"); a.res_b = u->R(p + ".res_conv.bias"); a.res_out = rb.p;
+        }
+        conv(a, h1, G, &st1);
+        ConvArgs b;
+        b.s0.p = h1.p; b.s0.C = cout;
+        b.s0.xf = xf_of(st1, 2, u->R(p + ".block1.norm.weight"), u->R(p + ".block1.norm.bias"), u->ss + u->ss_off.at(p), u->S);
+        b.Hs = x.H; b.Ws = x.W; b.KS = 3; b.pad = 1;
+        b.w = u->P(p + ".block2.proj.weight"); b.bias = u->R(p + ".block2.proj.bias");
+        conv(b, h2, G, &st2);
+        FinalizeArgs f;
+        f.h = h2.p; f.xf = xf_of(st2, 2, u->R(p + ".block2.norm.weight"), u->R(p + ".block2.norm.bias"));
+        f.res = (cin != cout) ? rb.p : x.p; f.y = out.p; f.HW = x.H * x.W; f.C = cout;
+        if (want_gn1) {
+            const int bps = finalize_blocks_per_sample(f.HW, f.C);
+            *gn1 = stat(1, bps, (float)(f.HW * f.C / bps));
+            f.stats_out = gn1->p;
+        }
+        if (!err) u->ops.push_back([f](const FwdCtx& c, hipStream_t s) { FinalizeArgs g = f; g.B = c.B; return finalize_launch(g, s); });
+        u->named[p] = out; u->named[p + ".h1"] = h1; u->named[p + ".h2"] = h2;
+        return out;
+    }
+
+    // Residual(PreNorm(LinearAttention)) (unet.py:125-161,250): qkv conv with GroupNorm(1) in its loader | context |
+    // apply | to_out conv | GroupNorm(1) + residual.
+    Act linattn(const std::string& p, const Act& x, const Stat& gn1) {
+        const int hid = u->heads * 32, n = x.H * x.W, heads = u->heads;
+        Act qkv = act(3 * hid, x.H, x.W), lao = act(hid, x.H, x.W), yb = act(x.C, x.H, x.W), out = act(x.C, x.H, x.W);
+        float* ctx = dmalloc((size_t)B * heads * 32 * 32);
+        ConvArgs a;
+        a.s0.p = x.p; a.s0.C = x.C; a.s0.xf = xf_of(gn1, 1, u->R(p + ".fn.norm.weight"), u->R(p + ".fn.norm.bias"));
+        a.Hs = x.H; a.Ws = x.W; a.KS = 1; a.pad = 0;
+        a.w = u->P(p + ".fn.fn.to_qkv.weight");
+        conv(a, qkv, 0, nullptr);
+        const float* qp = qkv.p; float* lp = lao.p;
+        if (!err) {
+            u->ops.push_back([=](const FwdCtx& c, hipStream_t s) { return linattn_ctx_launch(qp, ctx, c.B, n, heads, s); });
+            u->ops.push_back([=](const FwdCtx& c, hipStream_t s) { return linattn_apply_launch(qp, ctx, lp, c.B, n, heads, s); });
+            u->flops += 2.0 * 2.0 * n * 32 * 32 * heads;
+        }
+        ConvArgs o;
+        o.s0.p = lao.p; o.s0.C = hid; o.Hs = x.H; o.Ws = x.W; o.KS = 1; o.pad = 0;
+        o.w = u->P(p + ".fn.fn.to_out.0.weight"); o.bias = u->R(p + ".fn.fn.to_out.0.bias");
+        Stat sty;
+        conv(o, yb, 1, &sty);
+        FinalizeArgs f;
+        f.h = yb.p; f.xf = xf_of(sty, 1, u->R(p + ".fn.fn.to_out.1.weight"), u->R(p + ".fn.fn.to_out.1.bias"));
+        f.res = x.p; f.y = out.p; f.HW = n; f.C = x.C;
+        if (!err) u->ops.push_back([f](const FwdCtx& c, hipStream_t s) { FinalizeArgs g = f; g.B = c.B; return finalize_launch(g, s); });
+        u->named[p] = out; u->named[p + ".qkv"] = qkv; u->named[p + ".lao"] = lao; u->named[p + ".y"] = yb;
+        return out;
+    }
+
+    // Residual(PreNorm(Attention)) (unet.py:99-122,262)
+    Act midattn(const Act& x, const Stat& gn1) {
+        const int hid = u->heads * 32, n = x.H * x.W, heads = u->heads;
+        Act qkv = act(3 * hid, x.H, x.W), ao = act(hid, x.H, x.W), out = act(x.C, x.H, x.W);
+        ConvArgs a;
+        a.s0.p = x.p; a.s0.C = x.C; a.s0.xf = xf_of(gn1, 1, u->R("mid_attn.fn.norm.weight"), u->R("mid_attn.fn.norm.bias"));
+        a.Hs = x.H; a.Ws = x.W; a.KS = 1;
+        a.w = u->P("mid_attn.fn.fn.to_qkv.weight");
+        conv(a, qkv, 0, nullptr);
+        const float* qp = qkv.p; float* ap = ao.p;
+        if (!err) {
+            u->ops.push_back([=](const FwdCtx& c, hipStream_t s) { return attn_small_launch(qp, ap, c.B, n, heads, s); });
+            u->flops += 2.0 * 2.0 * n * n * 32 * heads;
+        }
+        ConvArgs o;
+        o.s0.p = ao.p; o.s0.C = hid; o.Hs = x.H; o.Ws = x.W; o.KS = 1;
+        o.w = u->P("mid_attn.fn.fn.to_out.weight"); o.bias = u->R("mid_attn.fn.fn.to_out.bias");
+        o.add = x.p;
+        conv(o, out, 0, nullptr);
+        u->named["mid_attn"] = out;
+        return out;
+    }
+
+    // x + SiLU(conv3x3(cat[x, bilinear(mask)]))  (unet.py:336-340,360-364); a plain copy when no mask is given
+    Act mask_inject(const std::string& name, const Act& x, const Act& mask_nhwc) {
+        Act mr = act(mask_nhwc.C, x.H, x.W), out = act(x.C, x.H, x.W);
+        const float* mp = mask_nhwc.p; float* rp = mr.p;
+        const int C = mask_nhwc.C, Hs = mask_nhwc.H, Ws = mask_nhwc.W, Hd = x.H, Wd = x.W;
+        ConvArgs a;
+        a.s0.p = x.p; a.s0.C = x.C; a.s1.p = mr.p; a.s1.C = C;
+        a.Hs = x.H; a.Ws = x.W; a.KS = 3; a.pad = 1; a.out_act = 1; a.add = x.p;
+        a.w = u->P(name + ".weight"); a.bias = u->R(name + ".bias");
+        a.B = B; a.H = x.H; a.W = x.W; a.Cout = x.C; a.out = out.p; a.Cin = x.C + C;
+        ConvGeom g;
+        if ((err = conv_plan(a, TILE_AUTO, &g)) != FC_OK) return out;
+        const int tile = g.tile;
+        const size_t bytes_per = (size_t)x.H * x.W * x.C * sizeof(float);
+        const float* xp = x.p; float* op = out.p;
+        u->ops.push_back([=](const FwdCtx& c, hipStream_t s) -> int {
+            if (!c.mask) { FC_HIP(hipMemcpyAsync(op, xp, bytes_per * c.B, hipMemcpyDeviceToDevice, s)); return FC_OK; }
+            FC_TRY(bilinear_nhwc_launch(mp, rp, c.B, C, Hs, Ws, Hd, Wd, s));
+            ConvArgs b = a; b.B = c.B;
+            return conv_launch(b, tile, s);
+        });
+        return out;
+    }
+};
+
+static void free_plan(fc_unet* u) {
+    for (auto& kv : u->graphs) (void)hipGraphExecDestroy(kv.second);
+    u->graphs.clear();
+    for (void* p : u->allocs) (void)hipFree(p);
+    u->allocs.clear();
+    u->named.clear();
+    u->ops.clear();
+    u->maxB = 0;
+}
+
+static int build_plan(fc_unet* u, int maxB, int H, int W) {
+    free_plan(u);
+    const fc_unet_config& c = u->cfg;
+    const int L = c.n_levels, dim = c.dim, ch = c.channels, HW = H * W;
+    if (!is_pow2(H) || !is_pow2(W) || (H >> (L - 1)) < 1 || (W >> (L - 1)) < 1)
+        return fail(FC_E_SHAPE, "unet: latent height/width must be powers of two >= 2^(levels-1)");
+    if ((ch & 3) || (dim & 3)) return fail(FC_E_SHAPE, "unet: channels and dim must be multiples of 4");
+    Builder b{u, maxB};
+    u->flops = 0.0;
+    u->t_emb = b.dmalloc((size_t)maxB * u->td);
+    u->ss = b.dmalloc((size_t)maxB * u->S);
+    const std::vector<int>& cs = u->chans;
+    const int td = u->td, S = u->S, ncls = c.n_classes;
+
+    // -- conditioning (unet.py:310-316 and every ResnetBlock.mlp) --
+    {
+        TembArgs t;
+        t.freqs = u->freqs;
+        t.w1t = u->P("time_mlp.1.weight"); t.b1 = u->R("time_mlp.1.bias");
+        t.w2t = u->P("time_mlp.3.weight"); t.b2 = u->R("time_mlp.3.bias");
+        t.emb = t.cw1t = t.cb1 = t.cw2t = t.cb2 = nullptr;
+        if (ncls > 0) {
+            t.emb = u->R("class_cond_mlp.0.weight");
+            t.cw1t = u->P("class_cond_mlp.1.weight"); t.cb1 = u->R("class_cond_mlp.1.bias");
+            t.cw2t = u->P("class_cond_mlp.3.weight"); t.cb2 = u->R("class_cond_mlp.3.bias");
+        }
+        t.n_classes = ncls; t.t_out = u->t_emb; t.dim = dim; t.td = td;
+        u->ops.push_back([t](const FwdCtx& cx, hipStream_t s) {
+            TembArgs a = t; a.B = cx.B; a.time = cx.time; a.class_ids = cx.ids; a.class_batch_mod = cx.ids_mod; a.null_from = cx.null_from;
+            return temb_launch(a, s);
+        });
+        const float *te = u->t_emb, *wt = u->P("__ss_wt"), *sb = u->P("__ss_bias");
+        float* ss = u->ss;
+        u->ops.push_back([=](const FwdCtx& cx, hipStream_t s) { return ss_launch(te, wt, sb, ss, cx.B, td, S, s); });
+        u->flops += 2.0 * ((double)dim * td + (double)td * td * (ncls > 0 ? 3 : 1) + (double)td * S);
+    }
+
+    // -- init_conv (unet.py:295) and mask fusion (unet.py:298-305) --
+    Act x0 = b.act(dim, H, W);
+    u->named["init"] = x0;
+    Act mask_nhwc;
+    {
+        const float *w = u->P("init_conv.weight"), *bias = u->R("init_conv.bias");
+        float* x0p = x0.p;
+        u->flops += 2.0 * HW * ch * dim;
+        if (!c.mask_cond) {
+            u->ops.push_back([=](const FwdCtx& cx, hipStream_t s) { return init_conv_launch(cx.x, cx.x_mod, w, bias, x0p, cx.B, ch, HW, dim, s); });
+        } else {
+            Act xi = b.act(dim, H, W), f1 = b.act(2 * dim, H, W), f2 = b.act(2 * dim, H, W);
+            mask_nhwc = b.act(ch, H, W);
+            float *xip = xi.p, *mp = mask_nhwc.p;
+            u->ops.push_back([=](const FwdCtx& cx, hipStream_t s) -> int {
+                if (cx.mask) FC_TRY(nchw_to_nhwc_launch(cx.mask, mp, cx.B, ch, HW, ch, cx.x_mod, s));
+                return init_conv_launch(cx.x, cx.x_mod, w, bias, cx.mask_fuse ? xip : x0p, cx.B, ch, HW, dim, s);
+            });
+            ConvArgs a[3];
+            const char* names[3] = {"mask_fusion_conv.0", "mask_fusion_conv.2", "mask_fusion_conv.4"};
+            const Act* srcs[3] = {&xi, &f1, &f2};
+            const Act* dsts[3] = {&f1, &f2, &x0};
+            int tiles[3];
+            for (int i = 0; i < 3 && !b.err; ++i) {
+                a[i].s0.p = srcs[i]->p; a[i].s0.C = srcs[i]->C;
+                if (i == 0) { a[i].s1.p = mask_nhwc.p; a[i].s1.C = ch; }
+                a[i].Hs = H; a[i].Ws = W; a[i].KS = i == 0 ? 5 : 3; a[i].pad = i == 0 ? 2 : 1; a[i].out_act = i < 2;
+                a[i].w = u->P(std::string(names[i]) + ".weight"); a[i].bias = u->R(std::string(names[i]) + ".bias");
+                a[i].B = maxB; a[i].H = H; a[i].W = W; a[i].Cout = dsts[i]->C; a[i].out = dsts[i]->p; a[i].Cin = a[i].s0.C + a[i].s1.C;
+                ConvGeom g;
+                b.err = conv_plan(a[i], TILE_AUTO, &g);
+                tiles[i] = g.tile;
+            }
+            if (b.err) return b.err;
+            const ConvArgs a0 = a[0], a1 = a[1], a2 = a[2];
+            const int t0 = tiles[0], t1 = tiles[1], t2 = tiles[2];
+            u->ops.push_back([=](const FwdCtx& cx, hipStream_t s) -> int {
+                if (!cx.mask_fuse) return FC_OK;
+                ConvArgs q = a0; q.B = cx.B; FC_TRY(conv_launch(q, t0, s));
+                q = a1; q.B = cx.B; FC_TRY(conv_launch(q, t1, s));
+                q = a2; q.B = cx.B; return conv_launch(q, t2, s);
+            });
+        }
+    }
+
+    // -- down path (unet.py:326-343) --
+    std::vector<Act> skips;
+    Act x = x0;
+    for (int i = 0; i < L && !b.err; ++i) {
+        const std::string p = "downs." + std::to_string(i);
+        Stat gn1;
+        x = b.resblock(p + ".0", x, nullptr, cs[i], false, nullptr);
+        skips.push_back(x);
+        x = b.resblock(p + ".1", x, nullptr, cs[i], true, &gn1);
+        x = b.linattn(p + ".2", x, gn1);
+        skips.push_back(x);
+        if (c.mask_cond && i < 2) x = b.mask_inject("down_mask_fusions." + std::to_string(i) + ".0", x, mask_nhwc);
+        ConvArgs a;
+        a.s0.p = x.p; a.s0.C = x.C; a.Hs = x.H; a.Ws = x.W;
+        if (i == L - 1) {
+            a.KS = 3; a.pad = 1; a.w = u->P(p + ".3.weight"); a.bias = u->R(p + ".3.bias");
+            Act o = b.act(cs[i + 1], x.H, x.W);
+            b.conv(a, o, 0, nullptr);
+            x = o;
+            u->named[p + ".3"] = o;
+        } else {
+            a.KS = 2; a.pad = 0; a.stride = 2; a.w = u->P(p + ".3.1.weight"); a.bias = u->R(p + ".3.1.bias");
+            Act o = b.act(cs[i + 1], x.H / 2, x.W / 2);
+            b.conv(a, o, 0, nullptr);
+            x = o;
+            u->named[p + ".3"] = o;
+        }
+    }
+    // -- bottleneck (unet.py:345-347) --
+    {
+        Stat gn1;
+        x = b.resblock("mid_block1", x, nullptr, cs[L], true, &gn1);
+        if (!b.err) x = b.midattn(x, gn1);
+        if (!b.err) x = b.resblock("mid_block2", x, nullptr, cs[L], false, nullptr);
+    }
+    // -- up path (unet.py:350-367) --
+    for (int i = 0; i < L && !b.err; ++i) {
+        const std::string p = "ups." + std::to_string(i);
+        const int din = cs[L - 1 - i], dout = cs[L - i];
+        Stat gn1;
+        Act s1 = skips.back(); skips.pop_back();
+        x = b.resblock(p + ".0", x, &s1, dout, false, nullptr);
+        Act s2 = skips.back(); skips.pop_back();
+        x = b.resblock(p + ".1", x, &s2, dout, true, &gn1);
+        x = b.linattn(p + ".2", x, gn1);
+        if (c.mask_cond && i < 2) x = b.mask_inject("up_mask_fusions." + std::to_string(i) + ".0", x, mask_nhwc);
+        ConvArgs a;
+        a.s0.p = x.p; a.s0.C = x.C; a.Hs = x.H; a.Ws = x.W; a.KS = 3; a.pad = 1;
+        if (i == L - 1) {
+            a.w = u->P(p + ".3.weight"); a.bias = u->R(p + ".3.bias");
+            Act o = b.act(din, x.H, x.W);
+            b.conv(a, o, 0, nullptr);
+            x = o;
+        } else {  // nn.Upsample(nearest x2) folded into the conv's loader (unet.py:42-46)
+            a.ups = 1; a.w = u->P(p + ".3.1.weight"); a.bias = u->R(p + ".3.1.bias");
+            Act o = b.act(din, x.H * 2, x.W * 2);
+            b.conv(a, o, 0, nullptr);
+            x = o;
+        }
+        u->named[p + ".3"] = x;
+    }
+    if (b.err) return b.err;
+    // -- head (unet.py:369-372) --
+    x = b.resblock("final_res_block", x, &x0, dim, false, nullptr);
+    if (b.err) return b.err;
+    {
+        const float *xp = x.p, *w = u->P("final_conv.weight"), *bias = u->R("final_conv.bias");
+        u->ops.push_back([=](const FwdCtx& cx, hipStream_t s) { return final_conv_launch(xp, w, bias, cx.out, cx.B, dim, HW, ch, s); });
+        u->flops += 2.0 * HW * dim * ch;
+    }
+    // -- integrator state --
+    const size_t nstate = (size_t)maxB * ch * HW;
+    u->y = b.dmalloc(nstate); u->xs = b.dmalloc(nstate);
+    u->k1 = b.dmalloc(nstate); u->k2 = b.dmalloc(nstate); u->k3 = b.dmalloc(nstate);
+    u->v2 = b.dmalloc(nstate); u->mask_own = b.dmalloc(nstate);
+    u->tvec = b.dmalloc(maxB);
+    u->sc = b.dmalloc(4);
+    u->step = reinterpret_cast<int*>(b.dmalloc(4));
+    u->ids_own = reinterpret_cast<int64_t*>(b.dmalloc(2 * (size_t)maxB));
+    if (b.err) return b.err;
+    u->maxB = maxB; u->H = H; u->W = W;
+    return FC_OK;
+}
+
+static int run_forward(fc_unet* u, const FwdCtx& c, hipStream_t s) {
+    for (const Op& op : u->ops) FC_TRY(op(c, s));
+    return FC_OK;
+}
+
+}  // namespace fc
+
+// =============================================================================================== C ABI
+extern "C" {
+
+int fc_abi_version(void) { return FC_ABI_VERSION; }
+const char* fc_last_error(void) { return fc::last_error(); }
+
+int fc_check_device(int device) {
+    hipDeviceProp_t prop;
+    FC_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(FC_E_ARCH, std::string("flocoder_amd kernels are built for gfx950 only; device reports ") + prop.gcnArchName);
+    return FC_OK;
+}
+
+int fc_unet_create(const fc_unet_config* cfg, int device, fc_unet** out) {
+    if (!cfg || !out) return fail(FC_E_ARG, "fc_unet_create: null argument");
+    if (cfg->n_levels < 1 || cfg->n_levels > 8 || cfg->dim < 4 || cfg->channels < 1 || cfg->groups < 1)
+        return fail(FC_E_ARG, "fc_unet_create: bad config");
+    for (int i = 0; i < cfg->n_levels; ++i)
+        if (cfg->dim_mults[i] < 1 || !is_pow2(cfg->dim * cfg->dim_mults[i] / cfg->groups) || (cfg->dim * cfg->dim_mults[i]) % cfg->groups)
+            return fail(FC_E_SHAPE, "fc_unet_create: channels per GroupNorm group must be a power of two");
+    std::unique_ptr<fc_unet> u(new fc_unet);
+    u->cfg = *cfg;
+    u->device = device;
+    FC_TRY(declare_all(u.get()));
+    if (device < 0) {  // description only: parameter table without touching a GPU
+        *out = u.release();
+        return FC_OK;
+    }
+    FC_TRY(fc_check_device(device));
+    FC_HIP(hipSetDevice(device));
+    FC_TRY(conv_init());
+    FC_HIP(hipMalloc(reinterpret_cast<void**>(&u->raw), (size_t)u->raw_numel * sizeof(float)));
+    FC_HIP(hipMalloc(reinterpret_cast<void**>(&u->packed), (size_t)u->packed_numel * sizeof(float)));
+    FC_HIP(hipMemset(u->raw, 0, (size_t)u->raw_numel * sizeof(float)));
+    const int half = cfg->dim / 2;
+    std::vector<float> fr(half);
+    const double lf = std::log(10000.0) / (half - 1);  // unet.py:26
+    for (int k = 0; k < half; ++k) fr[k] = (float)std::exp((double)((float)k * (float)-lf));
+    FC_HIP(hipMalloc(reinterpret_cast<void**>(&u->freqs), half * sizeof(float)));
+    FC_HIP(hipMemcpy(u->freqs, fr.data(), half * sizeof(float), hipMemcpyHostToDevice));
+    FC_HIP(hipStreamCreateWithFlags(&u->stream, hipStreamNonBlocking));
+    FC_HIP(hipEventCreateWithFlags(&u->ev_in, hipEventDisableTiming));
+    FC_HIP(hipEventCreateWithFlags(&u->ev_out, hipEventDisableTiming));
+    *out = u.release();
+    return FC_OK;
+}
+
+void fc_unet_destroy(fc_unet* u) {
+    if (!u) return;
+    if (u->device < 0) { delete u; return; }
+    (void)hipSetDevice(u->device);
+    (void)hipDeviceSynchronize();
+    free_plan(u);
+    if (u->ts_dev) (void)hipFree(u->ts_dev);
+    if (u->raw) (void)hipFree(u->raw);
+    if (u->packed) (void)hipFree(u->packed);
+    if (u->freqs) (void)hipFree(u->freqs);
+    if (u->stream) (void)hipStreamDestroy(u->stream);
+    if (u->ev_in) (void)hipEventDestroy(u->ev_in);
+    if (u->ev_out) (void)hipEventDestroy(u->ev_out);
+    delete u;
+}
+
+int fc_unet_param_count(const fc_unet* u) { return u ? (int)u->params.size() : 0; }
+
+int fc_unet_param_info(const fc_unet* u, int i, const char** name, int64_t shape[4], int64_t* offset) {
+    if (!u || i < 0 || i >= (int)u->params.size()) return fail(FC_E_ARG, "fc_unet_param_info: index out of range");
+    const Param& p = u->params[i];
+    if (name) *name = p.name.c_str();
+    if (shape) for (int k = 0; k < 4; ++k) shape[k] = p.shape[k];
+    if (offset) *offset = p.offset;
+    return FC_OK;
+}
+
+int64_t fc_unet_param_numel(const fc_unet* u) { return u ? u->raw_numel : 0; }
+
+int fc_unet_set_time_freqs(fc_unet* u, const float* freqs_host, int n) {
+    if (!u || !freqs_host || n != u->cfg.dim / 2) return fail(FC_E_ARG, "fc_unet_set_time_freqs: expected dim/2 entries");
+    FC_HIP(hipMemcpy(u->freqs, freqs_host, n * sizeof(float), hipMemcpyHostToDevice));
+    return FC_OK;
+}
+
+int fc_unet_load_params(fc_unet* u, const float* flat, int64_t numel, int on_device, void* stream) {
+    if (!u || !flat) return fail(FC_E_ARG, "fc_unet_load_params: null argument");
+    if (u->device < 0) return fail(FC_E_STATE, "unet: created with device < 0 (description only)");
+    if (numel != u->raw_numel) return fail(FC_E_ARG, "fc_unet_load_params: expected " + std::to_string(u->raw_numel) + " floats (padded table layout)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    FC_HIP(hipSetDevice(u->device));
+    FC_HIP(hipMemcpyAsync(u->raw, flat, (size_t)numel * sizeof(float), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    FC_TRY(run_pack(u, s));
+    if (!on_device) FC_HIP(hipStreamSynchronize(s));  // the host buffer may be freed by the caller on return
+    u->loaded = true;
+    return FC_OK;
+}
+
+int fc_unet_reserve(fc_unet* u, int max_batch, int height, int width) {
+    if (!u || max_batch < 1) return fail(FC_E_ARG, "fc_unet_reserve: bad argument");
+    if (u->device < 0) return fail(FC_E_STATE, "unet: created with device < 0 (description only)");
+    if (u->maxB >= max_batch && u->H == height && u->W == width) return FC_OK;
+    FC_HIP(hipSetDevice(u->device));
+    FC_HIP(hipDeviceSynchronize());
+    const int r = build_plan(u, max_batch, height, width);
+    if (r != FC_OK) free_plan(u);
+    return r;
+}
+
+static int check_ready(const fc_unet* u, int rows, int H, int W) {
+    if (!u) return fail(FC_E_ARG, "null fc_unet");
+    if (u->device < 0) return fail(FC_E_STATE, "unet: created with device < 0 (description only)");
+    if (!u->loaded) return fail(FC_E_STATE, "unet: weights not loaded (fc_unet_load_params)");
+    if (u->maxB < rows || u->H != H || u->W != W)
+        return fail(FC_E_STATE, "unet: no plan for this shape; call fc_unet_reserve(rows >= " + std::to_string(rows) + ")");
+    return FC_OK;
+}
+
+int fc_unet_forward(fc_unet* u, const float* x, const float* time, const int64_t* ids, const float* mask, int mask_is_ones, float* out,
+                    int B, int H, int W, void* stream) {
+    FC_TRY(check_ready(u, B, H, W));
+    if (!x || !time || !out || B < 1) return fail(FC_E_ARG, "fc_unet_forward: null argument");
+    FwdCtx c;
+    c.x = x; c.x_mod = B; c.time = time; c.ids = ids; c.ids_mod = B; c.null_from = 0;
+    c.mask = u->cfg.mask_cond ? mask : nullptr;
+    c.mask_fuse = (c.mask && !mask_is_ones) ? 1 : 0;
+    c.out = out; c.B = B;
+    return run_forward(u, c, static_cast<hipStream_t>(stream));
+}
+
+int fc_unet_plan_launches(const fc_unet* u) { return u ? (int)u->ops.size() : 0; }
+double fc_unet_flops_per_sample(const fc_unet* u) { return u ? u->flops : 0.0; }
+
+// -------------------------------------------------------------------------------- integrator
+static uint32_t fbits(float f) { uint32_t v; std::memcpy(&v, &f, 4); return v; }
+
+// enqueue one integration step on `s` (captured into a graph by the caller)
+static int enqueue_step(fc_unet* u, int method, int B, bool cfg_on, float cfg, float dt_euler, float t_scale, bool has_ids, int mask_mode,
+                        hipStream_t s) {
+    const int rows = cfg_on ? 2 * B : B, n = B * u->cfg.channels * u->H * u->W;
+    FwdCtx c;
+    c.x_mod = B; c.time = u->tvec; c.ids = has_ids ? u->ids_own : nullptr; c.ids_mod = B; c.null_from = cfg_on ? B : 0;
+    c.mask = mask_mode ? u->mask_own : nullptr; c.mask_fuse = mask_mode == 1;
+    c.out = u->v2; c.B = rows;
+    FC_TRY(ode_time_launch(u->step, u->ts_dev, t_scale, method == FC_METHOD_RK4, u->sc, u->tvec, rows, s));
+    if (method == FC_METHOD_EULER) {
+        c.x = u->y;
+        FC_TRY(run_forward(u, c, s));
+        return ode_euler_update_launch(u->y, u->v2, n, cfg_on, cfg, dt_euler, s);
+    }
+    c.x = u->y;
+    FC_TRY(run_forward(u, c, s));                                                                                        // k1 = f(y, t)
+    FC_TRY(ode_rk4_stage_launch(u->sc, u->y, u->xs, u->k1, u->v2, n, cfg_on, cfg, 0, 1, t_scale, u->tvec, rows, s));      // y + dt*k1/2, t+dt/2
+    c.x = u->xs;
+    FC_TRY(run_forward(u, c, s));                                                                                        // k2
+    FC_TRY(ode_rk4_stage_launch(u->sc, u->y, u->xs, u->k2, u->v2, n, cfg_on, cfg, 0, 1, t_scale, u->tvec, rows, s));      // y + dt*k2/2, t+dt/2
+    FC_TRY(run_forward(u, c, s));                                                                                        // k3
+    FC_TRY(ode_rk4_stage_launch(u->sc, u->y, u->xs, u->k3, u->v2, n, cfg_on, cfg, 1, 2, t_scale, u->tvec, rows, s));      // y + dt*k3, t+dt
+    FC_TRY(run_forward(u, c, s));                                                                                        // k4
+    return ode_rk4_final_launch(u->sc, u->y, u->k1, u->k2, u->k3, u->v2, n, cfg_on, cfg, s);
+}
+
+int fc_unet_integrate(fc_unet* u, int method, float* x_dev, int B, int H, int W, const float* ts_host, int n_points, float dt_euler,
+                      float t_scale, const int64_t* ids, float cfg_strength, const float* mask, int mask_is_ones, void* stream) {
+    if (!u || !x_dev || !ts_host || B < 1 || n_points < 1) return fail(FC_E_ARG, "fc_unet_integrate: bad argument");
+    if (method != FC_METHOD_EULER && method != FC_METHOD_RK4) return fail(FC_E_ARG, "fc_unet_integrate: unknown method");
+    const bool has_ids = ids != nullptr && u->cfg.n_classes > 0;
+    const bool cfg_on = has_ids && cfg_strength != 0.0f;   // sampling.py:69
+    const int rows = cfg_on ? 2 * B : B;
+    FC_TRY(check_ready(u, rows, H, W));
+    const int mask_mode = (mask && u->cfg.mask_cond) ? (mask_is_ones ? 2 : 1) : 0;
+    const int n_steps = method == FC_METHOD_RK4 ? n_points - 1 : n_points;
+    hipStream_t caller = static_cast<hipStream_t>(stream), s = u->stream;
+    FC_HIP(hipSetDevice(u->device));
+    if (n_points > u->ts_cap) {  // grows only when a longer grid than ever before arrives
+        FC_HIP(hipStreamSynchronize(s));
+        if (u->ts_dev) FC_HIP(hipFree(u->ts_dev));
+        u->ts_cap = n_points < 1024 ? 1024 : n_points;
+        FC_HIP(hipMalloc(reinterpret_cast<void**>(&u->ts_dev), u->ts_cap * sizeof(float)));
+        for (auto& kv : u->graphs) (void)hipGraphExecDestroy(kv.second);
+        u->graphs.clear();  // captured graphs hold the old ts pointer
+    }
+    const size_t nbytes = (size_t)B * u->cfg.channels * H * W * sizeof(float);
+    // the library stream picks up after everything already queued on the caller's stream
+    FC_HIP(hipEventRecord(u->ev_in, caller));
+    FC_HIP(hipStreamWaitEvent(s, u->ev_in, 0));
+    // pageable source: the runtime stages it before returning, so ts_host may be freed by the caller right away
+    FC_HIP(hipMemcpyAsync(u->ts_dev, ts_host, n_points * sizeof(float), hipMemcpyHostToDevice, s));
+    FC_HIP(hipMemsetAsync(u->step, 0, sizeof(int), s));
+    FC_HIP(hipMemcpyAsync(u->y, x_dev, nbytes, hipMemcpyDeviceToDevice, s));
+    if (has_ids) FC_HIP(hipMemcpyAsync(u->ids_own, ids, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    if (mask_mode) FC_HIP(hipMemcpyAsync(u->mask_own, mask, nbytes, hipMemcpyDeviceToDevice, s));
+
+    static const bool no_graph = std::getenv("FLOCODER_AMD_NO_GRAPH") != nullptr;
+    if (no_graph) {
+        for (int i = 0; i < n_steps; ++i) FC_TRY(enqueue_step(u, method, B, cfg_on, cfg_strength, dt_euler, t_scale, has_ids, mask_mode, s));
+    } else {
+        const auto key = std::make_tuple(method, B, (int)cfg_on, mask_mode, fbits(cfg_strength), fbits(dt_euler), fbits(t_scale), (int)has_ids);
+        auto it = u->graphs.find(key);
+        if (it == u->graphs.end()) {
+            hipGraph_t graph = nullptr;
+            FC_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            const int r = enqueue_step(u, method, B, cfg_on, cfg_strength, dt_euler, t_scale, has_ids, mask_mode, s);
+            const hipError_t e = hipStreamEndCapture(s, &graph);
+            if (r != FC_OK) { if (graph) (void)hipGraphDestroy(graph); return r; }
+            if (e != hipSuccess) return fail(FC_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+            hipGraphExec_t exec = nullptr;
+            FC_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            FC_HIP(hipGraphDestroy(graph));
+            it = u->graphs.emplace(key, exec).first;
+        }
+        for (int i = 0; i < n_steps; ++i) FC_HIP(hipGraphLaunch(it->second, s));
+    }
+    FC_HIP(hipMemcpyAsync(x_dev, u->y, nbytes, hipMemcpyDeviceToDevice, s));
+    FC_HIP(hipEventRecord(u->ev_out, s));
+    FC_HIP(hipStreamWaitEvent(caller, u->ev_out, 0));
+    return FC_OK;
+}
+
+// ---- debug / test hooks --------------------------------------------------------------------------
+int fc_unet_debug_tensor(const fc_unet* u, const char* name, const float** ptr, int* C, int* H, int* W) {
+    if (!u || !name) return fail(FC_E_ARG, "fc_unet_debug_tensor: null argument");
+    auto it = u->named.find(name);
+    if (it == u->named.end()) return fail(FC_E_ARG, std::string("fc_unet_debug_tensor: no tap named ") + name);
+    *ptr = it->second.p; *C = it->second.C; *H = it->second.H; *W = it->second.W;
+    return FC_OK;
+}
+
+int fc_debug_copy(void* dst_dev, const void* src_dev, int64_t bytes, void* stream) {
+    FC_HIP(hipMemcpyAsync(dst_dev, src_dev, (size_t)bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    return FC_OK;
+}
+
+int fc_debug_conv(const float* src0, int c0, const float* src1, int c1, const float* w_oihw, const float* bias, const float* add,
+                  float* out, float* stats_out, int groups_out, int* stats_T, float* stats_nt, int batch, int hs, int ws, int cout,
+                  int ksize, int pad, int stride, int upsample, int out_act, int tile_cfg, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    FC_TRY(conv_init());
+    ConvArgs a;
+    a.s0.p = src0; a.s0.C = c0; a.s1.p = src1; a.s1.C = src1 ? c1 : 0;
+    a.Cin = a.s0.C + a.s1.C; a.Cout = cout; a.B = batch; a.Hs = hs; a.Ws = ws;
+    a.KS = ksize; a.pad = pad; a.stride = stride; a.ups = upsample;
+    a.H = upsample ? hs * 2 : (hs + 2 * pad - ksize) / stride + 1;
+    a.W = upsample ? ws * 2 : (ws + 2 * pad - ksize) / stride + 1;
+    a.bias = bias; a.add = add; a.out = out; a.out_act = out_act;
+    a.stats_out = stats_out; a.Gout = groups_out;
+    float* wp = nullptr;
+    FC_HIP(hipMalloc(reinterpret_cast<void**>(&wp), (size_t)cout * a.Cin * ksize * ksize * sizeof(float)));
+    int r = pack_conv_launch(w_oihw, wp, cout, a.Cin, ksize, ksize, s);
+    a.w = wp;
+    ConvGeom g;
+    if (r == FC_OK) r = conv_plan(a, tile_cfg, &g);
+    if (r == FC_OK) { if (stats_T) *stats_T = g.T; if (stats_nt) *stats_nt = g.n_t; r = conv_launch(a, g.tile, s); }
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(wp);
+    return r;
+}
+
+int fc_ot_pairing(const float* source_dev, const float* target_dev, int batch, int64_t dim, float* dist_ws_dev, int64_t* perm_out_dev,
+                  void* stream) {
+    if (!source_dev || !target_dev || !dist_ws_dev || !perm_out_dev) return fail(FC_E_ARG, "fc_ot_pairing: null argument");
+    return ot_launch(source_dev, target_dev, batch, dim, dist_ws_dev, perm_out_dev, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

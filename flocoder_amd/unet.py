@@ -1,0 +1,247 @@
+"""Velocity U-Net: host-side mirror of ``flocoder.unet.Unet`` (reference unet.py:164-377) over the gfx950 library.
+
+Same constructor, same ``forward(x, time, cond)`` protocol, same ``state_dict`` key names and shapes (so the
+reference's checkpoints load with ``load_state_dict``), same default initialisation *and RNG consumption order*
+(``torch.manual_seed(s); Unet(...)`` gives the reference's weights).  The arithmetic happens in
+``libflocoder_amd.so``; this class owns the parameters and hands them over.  There is no CPU path: calling it
+with CPU tensors raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import _binding as B
+
+# construction order of the reference's Unet.__init__ (unet.py:185-286); state_dict order differs (ups before mid)
+_CTOR_ORDER = ["init_conv", "time_mlp", "class_cond_mlp", "mask_fusion_conv", "down_mask_fusions", "up_mask_fusions",
+               "downs", "mid_block1", "mid_attn", "mid_block2", "ups", "final_res_block", "final_conv"]
+_STATE_ORDER = ["init_conv", "time_mlp", "class_cond_mlp", "mask_fusion_conv", "down_mask_fusions", "up_mask_fusions",
+                "downs", "ups", "mid_block1", "mid_attn", "mid_block2", "final_res_block", "final_conv"]
+
+
+def _make_config(dim, dim_mults, channels, groups, n_classes, mask_cond) -> B.fc_unet_config:
+    if len(dim_mults) > 8:
+        raise ValueError("at most 8 resolution levels")
+    cfg = B.fc_unet_config(dim=int(dim), channels=int(channels), n_levels=len(dim_mults), groups=int(groups),
+                           n_classes=max(0, int(n_classes)), mask_cond=int(bool(mask_cond)))
+    for i, m in enumerate(dim_mults):
+        cfg.dim_mults[i] = int(m)
+    return cfg
+
+
+def param_table(cfg: B.fc_unet_config) -> List[Tuple[str, Tuple[int, ...], int]]:
+    """(name, shape, offset into the flat padded vector) as the library lays parameters out.  Needs no GPU."""
+    lib = B.lib()
+    h = C.c_void_p()
+    B.check(lib.fc_unet_create(C.byref(cfg), -1, C.byref(h)))
+    try:
+        out = []
+        for i in range(lib.fc_unet_param_count(h)):
+            name, shape, off = C.c_char_p(), (C.c_int64 * 4)(), C.c_int64()
+            B.check(lib.fc_unet_param_info(h, i, C.byref(name), C.byref(shape), C.byref(off)))
+            out.append((name.value.decode(), tuple(int(s) for s in shape if s), int(off.value)))
+        return out
+    finally:
+        lib.fc_unet_destroy(h)
+
+
+class _Node(nn.Module):
+    """Parameter container; attribute names reproduce the reference's module tree."""
+
+
+class Unet(nn.Module):
+    def __init__(self, dim, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=4, n_classes=10, mask_cond=False,
+                 use_checkpoint=False):
+        super().__init__()
+        self.use_checkpoint = use_checkpoint      # accepted for signature parity; activations are never stored
+        self.channels = channels
+        self.out_dim = channels
+        self.class_condition = n_classes > 0
+        self.dim, self.dim_mults = int(dim), tuple(int(m) for m in dim_mults)
+        self._cfg = _make_config(dim, self.dim_mults, channels, resnet_block_groups, n_classes, mask_cond)
+        table = param_table(self._cfg)
+        self._table = table
+        self._flat_numel = max(off + int(math.prod(shape)) for _, shape, off in table)
+        self._flat_numel = (self._flat_numel + 3) // 4 * 4
+
+        # registration in state_dict order, initialisation in constructor order (RNG parity with the reference)
+        by_top: Dict[str, List[Tuple[str, Tuple[int, ...]]]] = {}
+        for name, shape, _ in table:
+            by_top.setdefault(name.split(".")[0], []).append((name, shape))
+        for top in _STATE_ORDER:
+            for name, shape in by_top.get(top, []):
+                self._register(name, shape)
+        with torch.no_grad():
+            for top in _CTOR_ORDER:
+                for name, shape in by_top.get(top, []):
+                    self._init(name, self.get_parameter(name), by_top[top])
+
+        self._handle: Optional[C.c_void_p] = None
+        self._handle_device: Optional[torch.device] = None
+        self._synced_version = None
+
+    # ------------------------------------------------------------------ parameters
+    def _register(self, name: str, shape: Tuple[int, ...]) -> None:
+        node = self
+        *path, leaf = name.split(".")
+        for part in path:
+            if not hasattr(node, part):
+                node.add_module(part, _Node())
+            node = getattr(node, part)
+        node.register_parameter(leaf, nn.Parameter(torch.empty(shape, dtype=torch.float32)))
+
+    @staticmethod
+    def _init(name: str, p: nn.Parameter, siblings) -> None:
+        """nn.Conv2d / nn.Linear / nn.Embedding / nn.GroupNorm defaults, drawn in the reference's order."""
+        leaf = name.rsplit(".", 1)[1]
+        if p.dim() == 1 and leaf == "weight":
+            p.fill_(1.0)                                        # GroupNorm gain
+        elif p.dim() == 1:
+            wname = name[: -len("bias")] + "weight"
+            wshape = next(s for n, s in siblings if n == wname)
+            if len(wshape) == 1:
+                p.zero_()                                       # GroupNorm bias
+            else:
+                bound = 1.0 / math.sqrt(math.prod(wshape[1:]))
+                p.uniform_(-bound, bound)                       # Conv2d / Linear bias
+        elif name == "class_cond_mlp.0.weight":
+            p.normal_(0.0, 1.0)                                 # nn.Embedding
+        else:
+            nn.init.kaiming_uniform_(p, a=math.sqrt(5))         # Conv2d / Linear weight
+
+    def _flat_params(self, device) -> torch.Tensor:
+        flat = torch.zeros(self._flat_numel, dtype=torch.float32, device=device)
+        sd = dict(self.named_parameters())
+        for name, shape, off in self._table:
+            flat[off:off + math.prod(shape)] = sd[name].detach().reshape(-1)
+        return flat
+
+    def _version(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    # ------------------------------------------------------------------ native object
+    def _native(self, device: torch.device):
+        lib = B.lib()
+        if self._handle is None or self._handle_device != device:
+            self._release()
+            h = C.c_void_p()
+            B.check(lib.fc_unet_create(C.byref(self._cfg), device.index or 0, C.byref(h)))
+            self._handle, self._handle_device, self._synced_version = h, device, None
+            half = self.dim // 2    # frequency table exactly as torch computes it (unet.py:26-27)
+            fr = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1))).contiguous()
+            B.check(lib.fc_unet_set_time_freqs(h, fr.numpy().ctypes.data_as(C.POINTER(C.c_float)), half))
+        ver = self._version()
+        if ver != self._synced_version:
+            flat = self._flat_params(device)
+            B.check(lib.fc_unet_load_params(self._handle, flat.data_ptr(), flat.numel(), 1, B.current_stream(device)))
+            torch.cuda.current_stream(device).synchronize()      # `flat` dies when this frame returns
+            self._synced_version = ver
+        return self._handle
+
+    def _release(self):
+        if getattr(self, "_handle", None) is not None:
+            B.lib().fc_unet_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def reserve(self, rows: int, height: int, width: int, device=None) -> None:
+        """Build the launch plan / activation arena for up to `rows` U-Net rows (a CFG sampler needs 2x batch)."""
+        device = torch.device(device) if device is not None else next(self.parameters()).device
+        B.check(B.lib().fc_unet_reserve(self._native(device), rows, height, width))
+
+    @property
+    def flops_per_sample(self) -> float:
+        return float(B.lib().fc_unet_flops_per_sample(self._handle)) if self._handle else 0.0
+
+    @property
+    def launches_per_forward(self) -> int:
+        return int(B.lib().fc_unet_plan_launches(self._handle)) if self._handle else 0
+
+    # ------------------------------------------------------------------ forward
+    @staticmethod
+    def _split_cond(cond):
+        if cond is None:
+            return None, None
+        if not isinstance(cond, dict):
+            # the reference dies here too (warnings.DeprecationWarning does not exist)
+            raise AttributeError("Non-dict cond signals are dead in the reference; use cond={'class_cond': ids}")
+        return cond.get("class_cond"), cond.get("mask_cond")
+
+    def forward(self, x: torch.Tensor, time: torch.Tensor, cond=None) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("flocoder_amd.Unet runs on MI355X (gfx950) only; there is no CPU path "
+                               "(the CPU restatement under oracle/ is test infrastructure).")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            raise NotImplementedError("flocoder_amd.Unet: backward kernels are not built yet; call under torch.no_grad() / .eval()")
+        dev = x.device
+        bsz, ch, h, w = x.shape
+        if ch != self.channels:
+            raise ValueError(f"expected {self.channels} input channels, got {ch}")
+        cls, mask = self._split_cond(cond)
+        x = x.contiguous().float()
+        time = time.to(device=dev, dtype=torch.float32).contiguous()
+        if time.shape != (bsz,):
+            raise ValueError("time must have shape [batch]")
+        if cls is not None and not self.class_condition:
+            cls = None                                            # hasattr(self,'class_cond_mlp') is False, unet.py:315
+        if cls is not None:
+            cls = cls.to(device=dev, dtype=torch.int64).contiguous()
+        ones = 0
+        if mask is not None and not self._cfg.mask_cond:
+            mask = None                                           # hasattr(self,'mask_fusion_conv') is False, unet.py:298
+        if mask is not None:
+            mask = mask.to(device=dev, dtype=torch.float32).contiguous()
+            if mask.shape != x.shape:
+                raise ValueError("mask_cond must have the shape of x (unet.py:302)")
+            ones = int(torch.allclose(mask, torch.ones_like(mask)))   # unet.py:301 (one host sync, as upstream)
+        hnd = self._native(dev)
+        B.check(B.lib().fc_unet_reserve(hnd, bsz, h, w))
+        out = torch.empty_like(x)
+        B.check(B.lib().fc_unet_forward(hnd, B.ptr(x), B.ptr(time), B.ptr(cls), B.ptr(mask), ones, B.ptr(out), bsz, h, w,
+                                        B.current_stream(dev)))
+        return out
+
+    # ------------------------------------------------------------------ integrators (used by flocoder_amd.sampling)
+    def integrate(self, method: str, x: torch.Tensor, ts: torch.Tensor, *, dt_euler: float = 0.0, t_scale: float = 999.0,
+                  class_ids: Optional[torch.Tensor] = None, cfg_strength: float = 0.0, mask: Optional[torch.Tensor] = None,
+                  mask_is_ones: bool = False) -> torch.Tensor:
+        """Integrate ``x`` in place along the fp32 grid ``ts`` with the hipGraph-captured step; returns ``x``."""
+        if not x.is_cuda:
+            raise RuntimeError("flocoder_amd integrators run on MI355X (gfx950) only")
+        dev = x.device
+        bsz, ch, h, w = x.shape
+        if not x.is_contiguous() or x.dtype != torch.float32:
+            raise ValueError("x must be a contiguous fp32 tensor (it is updated in place)")
+        code = {"euler": B.FC_METHOD_EULER, "rk4": B.FC_METHOD_RK4}[method]
+        if class_ids is not None and not self.class_condition:
+            class_ids = None
+        if class_ids is not None:
+            class_ids = class_ids.to(device=dev, dtype=torch.int64).contiguous()
+        if mask is not None and not self._cfg.mask_cond:
+            mask = None
+        if mask is not None:
+            mask = mask.to(device=dev, dtype=torch.float32).contiguous()
+        rows = bsz * (2 if (class_ids is not None and cfg_strength) else 1)
+        hnd = self._native(dev)
+        B.check(B.lib().fc_unet_reserve(hnd, rows, h, w))
+        ts_host = ts.detach().to("cpu", torch.float32).contiguous()
+        B.check(B.lib().fc_unet_integrate(hnd, code, B.ptr(x), bsz, h, w, ts_host.numpy().ctypes.data_as(C.POINTER(C.c_float)),
+                                          ts_host.numel(), float(dt_euler), float(t_scale), B.ptr(class_ids),
+                                          float(cfg_strength or 0.0), B.ptr(mask), int(mask_is_ones), B.current_stream(dev)))
+        return x
+
+    def debug_tensor(self, name: str) -> torch.Tensor:
+        """NHWC copy of an internal activation of the last forward (tests only)."""
+        p, c, h, w = C.c_void_p(), C.c_int(), C.c_int(), C.c_int()
+        B.check(B.lib().fc_unet_debug_tensor(self._handle, name.encode(), C.byref(p), C.byref(c), C.byref(h), C.byref(w)))
+        return p.value, c.value, h.value, w.value

@@ -1,0 +1,135 @@
+/*
+ * flocoder_amd.h -- C ABI of the MI355X (gfx950) implementation of flocoder's latent-flow hot path.
+ *
+ * The reference (drscotthawley/flocoder @ 2025-08-08) is pure Python and has no FFI; what it has are
+ * Python protocols.  Each entry point below names the reference interface it replaces (file:line in
+ * the reference tree) -- INTEGRATION.md shows the ctypes stub a maintainer would add on their side.
+ *
+ * Conventions
+ *   - every pointer marked "dev" is a DEVICE pointer owned by the caller (e.g. torch.Tensor.data_ptr());
+ *     "host" pointers are plain host memory.  fp32 throughout.  Boundary tensors are NCHW contiguous,
+ *     exactly the reference's layout; the library's internal activations are NHWC.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Launch functions enqueue work and
+ *     return; they never allocate, free or synchronise.  Allocation happens in *_create / *_reserve only.
+ *   - return value: 0 = FC_OK, negative = error; fc_last_error() gives the message (thread-local).
+ *   - objects are thread-compatible: use one object per host thread.
+ */
+#ifndef FLOCODER_AMD_H
+#define FLOCODER_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FC_OK 0
+#define FC_E_ARG (-1)    /* bad argument / unknown name                     -> Python ValueError   */
+#define FC_E_SHAPE (-2)  /* shape the kernels do not support / not reserved -> Python ValueError   */
+#define FC_E_ARCH (-3)   /* device is not gfx950                            -> Python RuntimeError */
+#define FC_E_HIP (-4)    /* a HIP runtime call failed                       -> Python RuntimeError */
+#define FC_E_STATE (-5)  /* weights not loaded, plan not built ...          -> Python RuntimeError */
+
+#define FC_ABI_VERSION 1
+
+int fc_abi_version(void);
+const char* fc_last_error(void);
+/* 0 if `device` is a gfx950 part, FC_E_ARCH otherwise. */
+int fc_check_device(int device);
+
+/* ------------------------------------------------------------------------------------------------
+ * Velocity U-Net  (replaces flocoder/unet.py:164-377  Unet.__init__ / Unet.forward)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct fc_unet fc_unet;
+
+typedef struct fc_unet_config {
+    int dim;             /* Unet(dim=...)            unet.py:167 */
+    int channels;        /* Unet(channels=...)       unet.py:169 */
+    int n_levels;        /* len(dim_mults)           unet.py:168 */
+    int dim_mults[8];
+    int groups;          /* resnet_block_groups      unet.py:170 */
+    int n_classes;       /* 0 = no class_cond_mlp    unet.py:172,181 */
+    int mask_cond;       /* inpainting branches      unet.py:173,214-235 */
+} fc_unet_config;
+
+/* device >= 0: a gfx950 HIP device.  device < 0: description only (parameter table, no GPU touched). */
+int fc_unet_create(const fc_unet_config* cfg, int device, fc_unet** out);
+void fc_unet_destroy(fc_unet* u);
+
+/* Parameter table, in the order fc_unet_load_params expects.  Names and shapes are the reference's
+ * state_dict keys; `shape` receives up to 4 dims, unused = 0. */
+int fc_unet_param_count(const fc_unet* u);
+int fc_unet_param_info(const fc_unet* u, int i, const char** name, int64_t shape[4], int64_t* offset);
+int64_t fc_unet_param_numel(const fc_unet* u);
+/* Copy the flat fp32 parameter vector (all params concatenated in table order) and re-pack it into the
+ * kernels' layouts.  `on_device` says whether `flat` is a device or a host pointer.
+ * Replaces Unet.load_state_dict (generate_samples.py:101-106). */
+int fc_unet_load_params(fc_unet* u, const float* flat, int64_t numel, int on_device, void* stream);
+
+/* Build the launch plan and allocate the activation arena for batches up to `max_batch` of HxW latents.
+ * `max_batch` counts U-Net rows: a CFG sampler of B samples needs 2B. */
+int fc_unet_reserve(fc_unet* u, int max_batch, int height, int width);
+
+/* v = Unet(x, time, cond)   (unet.py:374-377).
+ *   x_dev [B,C,H,W]; time_dev [B] (already multiplied by t_scale, sampling.py:63);
+ *   class_ids_dev [B] int64 or NULL (cond['class_cond'] is None), an id < 0 disables the class
+ *   embedding for that row; mask_dev [B,C,H,W] or NULL (cond['mask_cond']); mask_is_ones = the
+ *   reference's allclose(mask,1) bypass (unet.py:301) decided by the caller; out_dev [B,C,H,W]. */
+int fc_unet_forward(fc_unet* u, const float* x_dev, const float* time_dev, const int64_t* class_ids_dev,
+                    const float* mask_dev, int mask_is_ones, float* out_dev, int batch, int height, int width,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ODE integrators  (replace flocoder/sampling.py:36-122 rk4_step / v_func_cfg / generate_latents_rk4,
+ *                   and the legacy Euler loop legacy/train_sd_flowers.py:50-67)
+ * ---------------------------------------------------------------------------------------------- */
+#define FC_METHOD_EULER 0
+#define FC_METHOD_RK4 1
+
+/* Integrate x_dev [B,C,H,W] in place along the caller-supplied fp32 time grid.
+ *   RK4  : ts_host has n_points entries (= warp_time(linspace(...)), sampling.py:102-111); the loop runs
+ *          n_points-1 intervals with stages at t, t+dt/2, t+dt/2, t+dt  (sampling.py:43-48,116-117).
+ *   Euler: ts_host has n_points = N entries t_i = i/N*(1-eps)+eps; x += v*dt with dt_euler = 1/N
+ *          (train_sd_flowers.py:58-64).
+ *   t_scale multiplies every time value before it reaches the U-Net (999, sampling.py:57).
+ *   class_ids_dev/mask_dev as in fc_unet_forward.  cfg_strength != 0 with class ids present runs the
+ *   classifier-free-guidance pair as one 2B-row pass (sampling.py:69-74).
+ * One integration step is captured in a hipGraph the first time a (method, B, H, W, cfg, mask) variant
+ * is seen and replayed from then on; the time grid lives in device memory, so replays take any grid. */
+int fc_unet_integrate(fc_unet* u, int method, float* x_dev, int batch, int height, int width,
+                      const float* ts_host, int n_points, float dt_euler, float t_scale,
+                      const int64_t* class_ids_dev, float cfg_strength, const float* mask_dev, int mask_is_ones,
+                      void* stream);
+
+/* Number of kernel launches in one U-Net forward of the current plan, and its algorithmic FLOPs per
+ * sample (2 x MACs over every conv / linear / attention contraction). */
+int fc_unet_plan_launches(const fc_unet* u);
+double fc_unet_flops_per_sample(const fc_unet* u);
+
+/* The sinusoidal frequency table exp(-k ln(1e4)/(dim/2-1)) (unet.py:26-27).  The library builds it in double
+ * precision; a host that wants the exact fp32 values its own framework produces may override it. */
+int fc_unet_set_time_freqs(fc_unet* u, const float* freqs_host, int n);
+
+/* ---- debug / test hooks: not part of the drop-in surface --------------------------------------- */
+/* Device pointer + NHWC extent of an internal activation of the current plan, by reference module name
+ * ("downs.0.0", "downs.0.2", "mid_attn", "ups.3.3", ...). */
+int fc_unet_debug_tensor(const fc_unet* u, const char* name, const float** ptr, int* channels, int* height, int* width);
+int fc_debug_copy(void* dst_dev, const void* src_dev, int64_t bytes, void* stream);
+/* One implicit-GEMM launch on caller tensors (NHWC activations, OIHW weights as torch stores them).
+ * Synchronises; allocates a scratch weight buffer. stats_out [B][G][T][2] gets (mean, M2) partials, T and the
+ * per-slot count come back through stats_T / stats_nt. tile_cfg = -1 picks automatically. */
+int fc_debug_conv(const float* src0_nhwc, int c0, const float* src1_nhwc, int c1, const float* w_oihw_dev, const float* bias_dev,
+                  const float* add_nhwc, float* out_nhwc, float* stats_out, int groups_out, int* stats_T, float* stats_nt, int batch,
+                  int hs, int ws, int cout, int ksize, int pad, int stride, int upsample, int out_act, int tile_cfg, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Greedy OT pairing  (replaces flocoder/ot.py:63-84 compute_ot_pairing)
+ * ---------------------------------------------------------------------------------------------- */
+/* source_dev/target_dev [B,D] fp32; dist_ws_dev workspace of B*B floats; perm_out_dev [B] int64. */
+int fc_ot_pairing(const float* source_dev, const float* target_dev, int batch, int64_t dim, float* dist_ws_dev,
+                  int64_t* perm_out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOCODER_AMD_H */

@@ -130,10 +130,14 @@ def time_embedding(sd: SD, time: Tensor, class_cond: Optional[Tensor]) -> Tensor
     return t
 
 
-def unet_forward(sd: SD, x: Tensor, time: Tensor, cond: Optional[dict] = None) -> Tensor:
+def unet_forward(sd: SD, x: Tensor, time: Tensor, cond: Optional[dict] = None, taps: Optional[dict] = None) -> Tensor:
     """Unet._forward, unet.py:289-372.  ``cond`` is None or a dict with optional
     'class_cond' (int64 [B]) and 'mask_cond' ([B,C,H,W]); non-dict cond is dead upstream
-    (SURVEY Q15)."""
+    (SURVEY Q15).  ``taps`` (tests only) collects block outputs by reference module name."""
+    def tap(name, v):
+        if taps is not None:
+            taps[name] = v
+        return v
     m = unet_meta(sd)
     g, L = m["groups"], m["n_levels"]
     class_cond = cond.get("class_cond") if isinstance(cond, dict) else None
@@ -146,7 +150,7 @@ def unet_forward(sd: SD, x: Tensor, time: Tensor, cond: Optional[dict] = None) -
         f = F.silu(_conv(sd, "mask_fusion_conv.0", f, padding=2))
         f = F.silu(_conv(sd, "mask_fusion_conv.2", f, padding=1))
         x = _conv(sd, "mask_fusion_conv.4", f, padding=1)                  # replaces x, no residual
-    r = x
+    r = tap("init", x)
     t = time_embedding(sd, time, class_cond)
 
     def inject(x, prefix, i):                                               # unet.py:336-340,360-364
@@ -156,30 +160,32 @@ def unet_forward(sd: SD, x: Tensor, time: Tensor, cond: Optional[dict] = None) -
     skips = []
     for i in range(L):
         p = f"downs.{i}"
-        x = resnet_block(sd, p + ".0", x, t, g); skips.append(x)
-        x = resnet_block(sd, p + ".1", x, t, g)
-        x = _prenorm_residual(sd, p + ".2", x, linear_attention); skips.append(x)
+        x = tap(p + ".0", resnet_block(sd, p + ".0", x, t, g)); skips.append(x)
+        x = tap(p + ".1", resnet_block(sd, p + ".1", x, t, g))
+        x = tap(p + ".2", _prenorm_residual(sd, p + ".2", x, linear_attention)); skips.append(x)
         if use_mask and i < 2:
             x = inject(x, "down_mask_fusions", i)
         x = _conv(sd, p + ".3", x, padding=1) if i == L - 1 else space_to_depth_conv(sd, p + ".3.1", x)
+        tap(p + ".3", x)
 
-    x = resnet_block(sd, "mid_block1", x, t, g)
-    x = _prenorm_residual(sd, "mid_attn", x, full_attention)
-    x = resnet_block(sd, "mid_block2", x, t, g)
+    x = tap("mid_block1", resnet_block(sd, "mid_block1", x, t, g))
+    x = tap("mid_attn", _prenorm_residual(sd, "mid_attn", x, full_attention))
+    x = tap("mid_block2", resnet_block(sd, "mid_block2", x, t, g))
 
     for i in range(L):
         p = f"ups.{i}"
-        x = resnet_block(sd, p + ".0", torch.cat((x, skips.pop()), dim=1), t, g)
-        x = resnet_block(sd, p + ".1", torch.cat((x, skips.pop()), dim=1), t, g)
-        x = _prenorm_residual(sd, p + ".2", x, linear_attention)
+        x = tap(p + ".0", resnet_block(sd, p + ".0", torch.cat((x, skips.pop()), dim=1), t, g))
+        x = tap(p + ".1", resnet_block(sd, p + ".1", torch.cat((x, skips.pop()), dim=1), t, g))
+        x = tap(p + ".2", _prenorm_residual(sd, p + ".2", x, linear_attention))
         if use_mask and i < 2:
             x = inject(x, "up_mask_fusions", i)
         if i == L - 1:
             x = _conv(sd, p + ".3", x, padding=1)
         else:                                                               # Upsample, unet.py:42-46
             x = _conv(sd, p + ".3.1", F.interpolate(x, scale_factor=2, mode="nearest"), padding=1)
+        tap(p + ".3", x)
 
-    x = resnet_block(sd, "final_res_block", torch.cat((x, r), dim=1), t, g)
+    x = tap("final_res_block", resnet_block(sd, "final_res_block", torch.cat((x, r), dim=1), t, g))
     return _conv(sd, "final_conv", x)
 
 

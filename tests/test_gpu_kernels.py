@@ -1,0 +1,136 @@
+"""GPU parity of individual kernels through the C ABI debug hooks, against plain torch fp32 on the CPU.
+Tolerance: rel-L2 <= 1e-5 (fp32 MFMA = k-ordered fmaf chain; the CPU conv sums in another order)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+TILES = ["M128N32", "M128N64", "M64N32K2", "M32N32K4", "M64N64K2"]
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g) * scale
+
+
+def gn_ref(y, groups):
+    b, c, h, w = y.shape
+    yg = y.double().reshape(b, groups, -1)
+    return yg.mean(-1), yg.var(-1, unbiased=False)
+
+
+@pytest.mark.parametrize("tile", TILES)
+@pytest.mark.parametrize("shape", [
+    # B, Cin, Cout, H, W, ks, pad
+    (3, 32, 32, 32, 32, 3, 1),
+    (2, 64, 64, 16, 16, 3, 1),
+    (5, 128, 128, 4, 4, 3, 1),
+    (2, 256, 256, 8, 8, 3, 1),
+    (2, 32, 96, 16, 16, 1, 0),
+    (3, 12, 16, 8, 8, 5, 2),
+    (2, 8, 8, 2, 2, 3, 1),
+    (9, 16, 32, 1, 1, 3, 1),
+])
+def test_conv_tiles(tile, shape):
+    from flocoder_amd._ops import conv_debug
+    B, ci, co, H, W, ks, pad = shape
+    x, w, b = rnd(B, ci, H, W, seed=1), rnd(co, ci, ks, ks, seed=2, scale=(ci * ks * ks) ** -0.5), rnd(co, seed=3)
+    ref = F.conv2d(x, w, b, padding=pad)
+    out, _ = conv_debug(x.to(dev()), w.to(dev()), b.to(dev()), pad=pad, tile=tile)
+    assert out.shape == ref.shape
+    assert rel_l2(out.cpu(), ref) < TOL
+
+
+@pytest.mark.parametrize("tile", ["auto"] + TILES)
+def test_conv_concat_stats_act_add(tile):
+    """cat(x0,x1) -> conv3x3 -> (+bias, GroupNorm partials) -> SiLU -> + add."""
+    from flocoder_amd._ops import conv_debug
+    B, c0, c1, co, H = 3, 64, 32, 64, 16
+    x0, x1 = rnd(B, c0, H, H, seed=4), rnd(B, c1, H, H, seed=5)
+    w, b, add = rnd(co, c0 + c1, 3, 3, seed=6, scale=0.03), rnd(co, seed=7), rnd(B, co, H, H, seed=8)
+    pre = F.conv2d(torch.cat([x0, x1], 1), w, b, padding=1)
+    ref = F.silu(pre) + add
+    for groups in (4, 1):
+        out, (mean, var) = conv_debug(x0.to(dev()), w.to(dev()), b.to(dev()), x1=x1.to(dev()), add=add.to(dev()), pad=1, out_act=True,
+                                      groups_out=groups, tile=tile)
+        assert rel_l2(out.cpu(), ref) < TOL
+        rm, rv = gn_ref(pre, groups)
+        assert rel_l2(mean.cpu(), rm) < 1e-4 and rel_l2(var.cpu(), rv) < 1e-5
+
+
+@pytest.mark.parametrize("tile", ["auto"] + TILES)
+def test_conv_stats_small_spatial_multi_sample_tiles(tile):
+    from flocoder_amd._ops import conv_debug
+    B, ci, co, H = 6, 128, 256, 4
+    x, w, b = rnd(B, ci, H, H, seed=9), rnd(co, ci, 3, 3, seed=10, scale=0.03), rnd(co, seed=11)
+    pre = F.conv2d(x, w, b, padding=1)
+    out, (mean, var) = conv_debug(x.to(dev()), w.to(dev()), b.to(dev()), pad=1, groups_out=4, tile=tile)
+    assert rel_l2(out.cpu(), pre) < TOL
+    rm, rv = gn_ref(pre, 4)
+    assert rel_l2(mean.cpu(), rm) < 1e-4 and rel_l2(var.cpu(), rv) < 1e-5
+
+
+@pytest.mark.parametrize("tile", ["auto"] + TILES)
+def test_conv_stride2_is_space_to_depth(tile):
+    """Downsample (unet.py:49-54) == 2x2 stride-2 conv with weights regrouped from (c p1 p2)."""
+    from flocoder_amd._ops import conv_debug
+    B, c, co, H = 2, 32, 64, 16
+    x, w1, b = rnd(B, c, H, H, seed=12), rnd(co, 4 * c, 1, 1, seed=13, scale=0.1), rnd(co, seed=14)
+    xs = x.reshape(B, c, H // 2, 2, H // 2, 2).permute(0, 1, 3, 5, 2, 4).reshape(B, 4 * c, H // 2, H // 2)
+    ref = F.conv2d(xs, w1, b)
+    w2 = w1.reshape(co, c, 2, 2)            # [o][c][p1][p2]
+    out, _ = conv_debug(x.to(dev()), w2.to(dev()), b.to(dev()), pad=0, stride=2, tile=tile)
+    assert rel_l2(out.cpu(), ref) < TOL
+
+
+@pytest.mark.parametrize("tile", ["auto"] + TILES)
+def test_conv_nearest_upsample_folded(tile):
+    from flocoder_amd._ops import conv_debug
+    B, ci, co, H = 2, 64, 32, 8
+    x, w, b = rnd(B, ci, H, H, seed=15), rnd(co, ci, 3, 3, seed=16, scale=0.05), rnd(co, seed=17)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1)
+    out, _ = conv_debug(x.to(dev()), w.to(dev()), b.to(dev()), pad=1, upsample=True, tile=tile)
+    assert rel_l2(out.cpu(), ref) < TOL
+
+
+def test_conv_rejects_bad_shapes():
+    from flocoder_amd._ops import conv_debug
+    x, w = rnd(1, 8, 6, 6).to(dev()), rnd(8, 8, 3, 3).to(dev())
+    with pytest.raises(ValueError, match="powers of two"):
+        conv_debug(x, w, pad=1)
+    x, w = rnd(1, 6, 8, 8).to(dev()), rnd(8, 6, 3, 3).to(dev())
+    with pytest.raises(ValueError, match="multiples of 4"):
+        conv_debug(x, w, pad=1)
+
+
+def test_ot_pairing_matches_oracle():
+    from flocoder_amd._ops import ot_pairing
+    from oracle import flow_oracle as fo
+    from oracle.synth import synth_input
+    from conftest import load_golden
+    g = load_golden("g7_ot")
+    for B, D in ((8, 64), (64, 64), (256, 1024)):
+        s, t = synth_input(f"g7.s{B}", (B, D), 7), synth_input(f"g7.t{B}", (B, D), 7)
+        perm, dist = ot_pairing(s.to(dev()), t.to(dev()))
+        assert perm.dtype == torch.int64
+        assert rel_l2(dist.cpu(), torch.cdist(s.double(), t.double())) < 1e-6
+        # the sequential sweep is bit-exact given the distances; on these well-separated inputs the whole
+        # permutation equals the reference's golden one as well
+        assert torch.equal(perm.cpu(), fo.ot_pairing_from_distances(dist.cpu()))
+        assert torch.equal(perm.cpu(), torch.from_numpy(g[f"perm_{B}_{D}"]))
+    s, t = torch.from_numpy(g["tie_src"]), torch.from_numpy(g["tie_tgt"])
+    perm, _ = ot_pairing(s.to(dev()), t.to(dev()))
+    assert torch.equal(perm.cpu(), torch.from_numpy(g["tie_perm"]))      # duplicates resolve to the first unused index
+    # ragged / edge sizes
+    for B in (1, 2, 63, 65, 130):
+        s, t = rnd(B, 20, seed=B), rnd(B, 20, seed=B + 1)
+        perm, dist = ot_pairing(s.to(dev()), t.to(dev()))
+        assert torch.equal(perm.cpu(), fo.ot_pairing_from_distances(dist.cpu()))
+        assert sorted(perm.tolist()) == list(range(B))

@@ -1,0 +1,150 @@
+"""GPU parity of the U-Net forward and the integrators, through flocoder_amd.Unet -> C ABI -> HIP kernels.
+
+Checked against (1) the golden vectors produced by the reference itself and (2) the CPU oracle on fresh seeded
+inputs.  Tolerances (fp32 everywhere; differences are summation order + exp/erf ulps):
+    single forward      rel-L2 <= 2e-5      trajectories (<= 64 forwards)   rel-L2 <= 2e-4
+north_star's budget for decoded images is 1e-3."""
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2
+from oracle import flow_oracle as fo
+from oracle.synth import synth_input, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+FWD_TOL, TRAJ_TOL = 2e-5, 2e-4
+DEV = "cuda:0"
+
+
+def make_model(shapes, seed, **kw):
+    from flocoder_amd.unet import Unet
+    sd = synth_state_dict(shapes, seed)
+    m = Unet(dim_mults=(1, 2, 4, 8), **kw).eval()
+    missing, unexpected = m.load_state_dict(sd, strict=True), None
+    return m.to(DEV), sd
+
+
+def first_bad_tap(model, sd, x, t, cond, batch):
+    """Localise a mismatch: compare every tapped block output with the oracle's."""
+    from flocoder_amd._ops import fetch_tap
+    taps = {}
+    fo.unet_forward(sd, x, t, cond, taps=taps)
+    rows = []
+    for name, ref in taps.items():
+        try:
+            got = fetch_tap(model, name, batch).cpu()
+        except ValueError:
+            continue
+        rows.append((name, rel_l2(got, ref)))
+    return "\n".join(f"  {n:24s} {e:.3e}" for n, e in rows)
+
+
+CASES = [("d32c102", 32, 1, 2, dict(dim=32, channels=4, n_classes=102)),
+         ("d16c10", 16, 2, 3, dict(dim=16, channels=4, n_classes=10)),
+         ("d8mask", 8, 3, 2, dict(dim=8, channels=4, n_classes=0, mask_cond=True))]
+
+
+@pytest.mark.parametrize("tag,dim,seed,B,kw", CASES)
+def test_forward_matches_reference_goldens(tag, dim, seed, B, kw):
+    g = load_golden("g3_unet_" + tag)
+    model, sd = make_model(g["shapes"], seed, **kw)
+    x = synth_input("g3.x." + tag, (B, 4, dim, dim), seed)
+    t = torch.from_numpy(g["t"])
+    xd, td = x.to(DEV), t.to(DEV)
+
+    def run(cond):
+        c = None if cond is None else {k: (v.to(DEV) if v is not None else None) for k, v in cond.items()}
+        with torch.no_grad():
+            return model(xd, td, c).cpu()
+
+    checks = []
+    if "cls" in g:
+        cls = torch.from_numpy(g["cls"])
+        checks += [("v_class", {"class_cond": cls}), ("v_noclass", {"class_cond": None}), ("v_none", None)]
+    if "mask" in g:
+        mask = torch.from_numpy(g["mask"])
+        checks += [("v_mask", {"class_cond": None, "mask_cond": mask}), ("v_ones", {"mask_cond": torch.ones_like(mask)}), ("v_none", None)]
+    for key, cond in checks:
+        out = run(cond)
+        err = rel_l2(out, g[key])
+        assert err < FWD_TOL, f"{tag}/{key}: rel-L2 {err:.3e}\n" + first_bad_tap(model, sd, x, t, cond, B)
+    assert abs(model.flops_per_sample - {"d32c102": 1.0008e9, "d16c10": 0.0786e9, "d8mask": 0.0094e9}[tag]) / model.flops_per_sample < 0.03
+
+
+def test_forward_batch_sizes_and_determinism():
+    """Odd batch sizes cross tile boundaries; repeated launches are bit-identical (no atomics anywhere)."""
+    g = load_golden("g3_unet_d32c102")
+    model, sd = make_model(g["shapes"], 1, dim=32, channels=4, n_classes=102)
+    for B in (1, 5, 16):
+        x = synth_input(f"bs.x{B}", (B, 4, 32, 32), 1)
+        t = torch.linspace(1.0, 998.0, B)
+        cls = torch.arange(B) % 102
+        cls[0] = 101
+        ref = fo.unet_forward(sd, x, t, {"class_cond": cls})
+        with torch.no_grad():
+            a = model(x.to(DEV), t.to(DEV), {"class_cond": cls.to(DEV)})
+            b = model(x.to(DEV), t.to(DEV), {"class_cond": cls.to(DEV)})
+        assert torch.equal(a, b)
+        err = rel_l2(a.cpu(), ref)
+        assert err < FWD_TOL, f"B={B}: {err:.3e}\n" + first_bad_tap(model, sd, x, t, {"class_cond": cls}, B)
+
+
+def test_rk4_and_euler_trajectories_match_reference_goldens():
+    from flocoder_amd import sampling as S
+    g = load_golden("g5_trajectories")
+    model, sd = make_model(g["shapes"], 5, dim=16, channels=4, n_classes=10)
+    src = synth_input("g5.src", (2, 4, 16, 16), 5).to(DEV)
+    cls = torch.from_numpy(g["cls"]).to(DEV)
+    for cfg in (0, 3):
+        lat, nfe = S.generate_latents_rk4(model, (2, 4, 16, 16), n_steps=5, cond={"class_cond": cls}, cfg_strength=float(cfg), source=src.clone())
+        assert nfe == 20
+        assert rel_l2(lat.cpu(), g[f"rk4_n5_cfg{cfg}"]) < TRAJ_TOL, cfg
+    lat, _ = S.generate_latents_rk4(model, (2, 4, 16, 16), n_steps=4, cond={}, cfg_strength=3.0, source=src.clone())
+    assert rel_l2(lat.cpu(), g["rk4_n4_nocond"]) < TRAJ_TOL
+    init = synth_input("g5.init", (2, 4, 16, 16), 5).to(DEV)
+    lat, nfe = S.generate_latents_rk4(model, (2, 4, 16, 16), n_steps=8, cond={"class_cond": cls}, cfg_strength=3.0, source=src.clone(),
+                                      init_latents=init, init_strength=0.5)
+    assert nfe == 16 and rel_l2(lat.cpu(), g["rk4_n8_init05"]) < TRAJ_TOL
+    for n in (4, 16):
+        lat, nfe = S.euler_sampler(model, (2, 4, 16, 16), n, cond=cls, source=src)
+        assert nfe == n and rel_l2(lat.cpu(), g[f"euler_n{n}"]) < TRAJ_TOL, n
+    # generate_latents dispatch + graph replay of a cached variant gives the same bits
+    a, _ = S.generate_latents(model, (2, 4, 16, 16), "rk4", 5, {"class_cond": cls}, 3.0, source=src.clone())
+    b, _ = S.generate_latents(model, (2, 4, 16, 16), "rk4", 5, {"class_cond": cls}, 3.0, source=src.clone())
+    assert torch.equal(a, b) and rel_l2(a.cpu(), g["rk4_n5_cfg3"]) < TRAJ_TOL
+
+
+def test_euler64_flowers_shape_vs_oracle():
+    """BASELINE config 2 at reduced batch: 64-step Euler, 4x32x32, dim=32, n_classes=102, against the CPU oracle."""
+    from flocoder_amd import sampling as S
+    g = load_golden("g3_unet_d32c102")
+    model, sd = make_model(g["shapes"], 1, dim=32, channels=4, n_classes=102)
+    B = 3
+    src = synth_input("e64.src", (B, 4, 32, 32), 1)
+    cls = torch.tensor([5, 77, 101])
+    ref, _ = fo.euler_sampler(sd, src, 64, cls)
+    lat, nfe = S.euler_sampler(model, (B, 4, 32, 32), 64, cond=cls.to(DEV), source=src.to(DEV))
+    assert nfe == 64
+    err = rel_l2(lat.cpu(), ref)
+    assert err < TRAJ_TOL, f"{err:.3e}"
+    # linearity-free sanity property at a size the oracle would not finish quickly: batch independence
+    big = synth_input("e64.big", (32, 4, 32, 32), 1).to(DEV)
+    big[:B] = src.to(DEV)
+    ids = torch.cat([cls, torch.arange(29) % 102]).to(DEV)
+    lat2, _ = S.euler_sampler(model, (32, 4, 32, 32), 64, cond=ids, source=big)
+    assert rel_l2(lat2[:B].cpu(), lat.cpu()) < 1e-5      # a sample's trajectory does not depend on its batch mates
+
+
+def test_mask_cond_sampling_vs_oracle():
+    from flocoder_amd import sampling as S
+    g = load_golden("g3_unet_d8mask")
+    model, sd = make_model(g["shapes"], 3, dim=8, channels=4, n_classes=0, mask_cond=True)
+    src = synth_input("mk.src", (2, 4, 8, 8), 3)
+    mask = torch.from_numpy(g["mask"])
+    ref, _ = fo.generate_latents_rk4(sd, src.clone(), 6, {"class_cond": None, "mask_cond": mask}, 3.0)
+    lat, _ = S.generate_latents_rk4(model, (2, 4, 8, 8), 6, {"class_cond": None, "mask_cond": mask.to(DEV)}, 3.0, source=src.to(DEV))
+    assert rel_l2(lat.cpu(), ref) < TRAJ_TOL
+    ones = torch.ones_like(mask)
+    ref, _ = fo.generate_latents_rk4(sd, src.clone(), 4, {"mask_cond": ones}, 3.0)
+    lat, _ = S.generate_latents_rk4(model, (2, 4, 8, 8), 4, {"mask_cond": ones.to(DEV)}, 3.0, source=src.to(DEV))
+    assert rel_l2(lat.cpu(), ref) < TRAJ_TOL

@@ -87,6 +87,19 @@ def main():
     torch.set_num_threads(8)
     unet, sampling, ot, inpainting = import_reference()
 
+    # ---- G0: state_dict layout and default initialisation under a fixed seed -----------------
+    g0 = {}
+    for tag, kw in (("d16c10", dict(dim=16, channels=4, n_classes=10)),
+                    ("d8mask", dict(dim=8, channels=4, n_classes=0, mask_cond=True)),
+                    ("d32c102", dict(dim=32, channels=4, n_classes=102))):
+        torch.manual_seed(0)
+        m = unet.Unet(dim_mults=(1, 2, 4, 8), **kw)
+        sd = m.state_dict()
+        g0[tag] = {"keys": list(sd.keys()), "shapes": [list(v.shape) for v in sd.values()],
+                   "sum": [float(v.double().sum()) for v in sd.values()],
+                   "abssum": [float(v.double().abs().sum()) for v in sd.values()]}
+    npz("g0_state_dict", layout=g0)
+
     # ---- G1: sinusoidal embedding ---------------------------------------------------
     times = torch.tensor([0.999, 1.0, 37.5, 250.0, 499.5, 750.25, 998.0, 999.0])
     npz("g1_sinusoidal", times=times, emb32=unet.SinusoidalPositionEmbeddings(32)(times),
