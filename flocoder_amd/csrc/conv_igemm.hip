@@ -110,6 +110,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvDev p) {
                 gstat[2 * i] = mean;
                 gstat[2 * i + 1] = rstd;
             }
+            __syncthreads();   // step (a) of the first chunk reads gstat from other waves
         }
     }
 

@@ -66,11 +66,14 @@ def block(sd: SD, p: str, x: Tensor, groups: int, scale_shift=None) -> Tensor:
     return F.silu(x)
 
 
-def resnet_block(sd: SD, p: str, x: Tensor, temb: Tensor, groups: int) -> Tensor:
+def resnet_block(sd: SD, p: str, x: Tensor, temb: Tensor, groups: int, taps: Optional[dict] = None) -> Tensor:
     """unet.py:76-96 -- FiLM only on block1; 1x1 ``res_conv`` iff channel count changes."""
     ss = F.linear(F.silu(temb), sd[p + ".mlp.1.weight"], sd[p + ".mlp.1.bias"])[:, :, None, None]
     scale, shift = ss.chunk(2, dim=1)
     h = block(sd, p + ".block1", x, groups, (scale, shift))
+    if taps is not None:                      # raw conv outputs, as the GPU path stores them
+        taps[p + ".h1"] = _conv(sd, p + ".block1.proj", x, padding=1)
+        taps[p + ".h2"] = _conv(sd, p + ".block2.proj", h, padding=1)
     h = block(sd, p + ".block2", h, groups)
     res = _conv(sd, p + ".res_conv", x) if (p + ".res_conv.weight") in sd else x
     return h + res
@@ -160,17 +163,17 @@ def unet_forward(sd: SD, x: Tensor, time: Tensor, cond: Optional[dict] = None, t
     skips = []
     for i in range(L):
         p = f"downs.{i}"
-        x = tap(p + ".0", resnet_block(sd, p + ".0", x, t, g)); skips.append(x)
-        x = tap(p + ".1", resnet_block(sd, p + ".1", x, t, g))
+        x = tap(p + ".0", resnet_block(sd, p + ".0", x, t, g, taps)); skips.append(x)
+        x = tap(p + ".1", resnet_block(sd, p + ".1", x, t, g, taps))
         x = tap(p + ".2", _prenorm_residual(sd, p + ".2", x, linear_attention)); skips.append(x)
         if use_mask and i < 2:
             x = inject(x, "down_mask_fusions", i)
         x = _conv(sd, p + ".3", x, padding=1) if i == L - 1 else space_to_depth_conv(sd, p + ".3.1", x)
         tap(p + ".3", x)
 
-    x = tap("mid_block1", resnet_block(sd, "mid_block1", x, t, g))
+    x = tap("mid_block1", resnet_block(sd, "mid_block1", x, t, g, taps))
     x = tap("mid_attn", _prenorm_residual(sd, "mid_attn", x, full_attention))
-    x = tap("mid_block2", resnet_block(sd, "mid_block2", x, t, g))
+    x = tap("mid_block2", resnet_block(sd, "mid_block2", x, t, g, taps))
 
     for i in range(L):
         p = f"ups.{i}"

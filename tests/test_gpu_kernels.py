@@ -26,7 +26,7 @@ def gn_ref(y, groups):
     return yg.mean(-1), yg.var(-1, unbiased=False)
 
 
-@pytest.mark.parametrize("tile", TILES)
+@pytest.mark.parametrize("tile", ["auto"] + TILES)
 @pytest.mark.parametrize("shape", [
     # B, Cin, Cout, H, W, ks, pad
     (3, 32, 32, 32, 32, 3, 1),
@@ -43,7 +43,11 @@ def test_conv_tiles(tile, shape):
     B, ci, co, H, W, ks, pad = shape
     x, w, b = rnd(B, ci, H, W, seed=1), rnd(co, ci, ks, ks, seed=2, scale=(ci * ks * ks) ** -0.5), rnd(co, seed=3)
     ref = F.conv2d(x, w, b, padding=pad)
-    out, _ = conv_debug(x.to(dev()), w.to(dev()), b.to(dev()), pad=pad, tile=tile)
+    try:
+        out, _ = conv_debug(x.to(dev()), w.to(dev()), b.to(dev()), pad=pad, tile=tile)
+    except ValueError as e:            # a forced tile may not fit (1x1 images are all halo); "auto" below must
+        assert "does not fit in LDS" in str(e) and H * W < 16
+        pytest.skip(str(e))
     assert out.shape == ref.shape
     assert rel_l2(out.cpu(), ref) < TOL
 
