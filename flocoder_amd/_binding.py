@@ -42,6 +42,8 @@ SIGNATURES = {
     "fc_unet_integrate": (_i, [_vp, _i, _vp, _i, _i, _i, _pf, _i, _f, _f, _vp, _f, _vp, _i, _vp]),
     "fc_unet_plan_launches": (_i, [_vp]),
     "fc_unet_flops_per_sample": (C.c_double, [_vp]),
+    "fc_unet_op_info": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_double)]),
+    "fc_unet_profile_ops": (_i, [_vp, _i, _i, _pf, _i, _vp]),
     "fc_unet_set_time_freqs": (_i, [_vp, _pf, _i]),
     "fc_unet_debug_tensor": (_i, [_vp, C.c_char_p, C.POINTER(_vp), _pi, _pi, _pi]),
     "fc_debug_copy": (_i, [_vp, _vp, _i64, _vp]),

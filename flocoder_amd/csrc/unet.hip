@@ -71,6 +71,8 @@ struct fc_unet {
     // plan
     int maxB = 0, H = 0, W = 0;
     std::vector<Op> ops;
+    std::vector<std::string> op_kernel, op_what;  // parallel to ops: kernel family, reference module it serves
+    std::vector<double> op_flops;                  // algorithmic FLOPs per sample of that launch
     std::vector<void*> allocs;
     double flops = 0.0;
     float *t_emb = nullptr, *ss = nullptr;
@@ -224,10 +226,22 @@ static int run_pack(fc_unet* u, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------- plan builder
+static const char* kTileNames[] = {"conv_igemm<M128,N32>", "conv_igemm<M128,N64>", "conv_igemm<M64,N32,K2>", "conv_igemm<M32,N32,K4>",
+                                   "conv_igemm<M64,N64,K2>"};
+
 struct Builder {
     fc_unet* u;
     int B;  // max batch
     int err = FC_OK;
+    std::string scope;  // reference module the ops being emitted belong to
+
+    void push(Op op, const std::string& kernel, double flops = 0.0) {
+        u->ops.push_back(std::move(op));
+        u->op_kernel.push_back(kernel);
+        u->op_what.push_back(scope);
+        u->op_flops.push_back(flops);
+        u->flops += flops;
+    }
 
     float* dmalloc(size_t floats) {
         void* p = nullptr;
@@ -257,18 +271,19 @@ struct Builder {
         if ((err = conv_plan(a, TILE_AUTO, &g)) != FC_OK) return;
         if (fused) { *st = stat(want_G, g.T, g.n_t); a.stats_out = st->p; }
         const int tile = g.tile;
-        u->flops += 2.0 * out.H * out.W * a.KS * a.KS * (double)a.Cin * a.Cout;
-        if (a.res_out) u->flops += 2.0 * out.H * out.W * (double)a.Cin * a.Cout;
-        u->ops.push_back([a, tile](const FwdCtx& c, hipStream_t s) { ConvArgs b = a; b.B = c.B; return conv_launch(b, tile, s); });
+        double fl = 2.0 * out.H * out.W * a.KS * a.KS * (double)a.Cin * a.Cout;
+        if (a.res_out) fl += 2.0 * out.H * out.W * (double)a.Cin * a.Cout;
+        push([a, tile](const FwdCtx& c, hipStream_t s) { ConvArgs b = a; b.B = c.B; return conv_launch(b, tile, s); }, kTileNames[tile], fl);
         if (want_G > 0 && !fused) {
             *st = stat(want_G, 1, (float)(out.H * out.W * (out.C / want_G)));
             float* sp = st->p; const float* xp = out.p; const int HW = out.H * out.W, C = out.C, G = want_G;
-            u->ops.push_back([=](const FwdCtx& c, hipStream_t s) { return gn_stats_launch(xp, sp, c.B, HW, C, G, s); });
+            push([=](const FwdCtx& c, hipStream_t s) { return gn_stats_launch(xp, sp, c.B, HW, C, G, s); }, "gn_stats");
         }
     }
 
     // ResnetBlock (unet.py:76-96): conv1 [+res_conv] | conv2 with GN+FiLM+SiLU folded into its loader | finalize.
     Act resblock(const std::string& p, const Act& x, const Act* skip, int cout, bool want_gn1, Stat* gn1) {
+        scope = p;
         const int G = u->cfg.groups, cin = x.C + (skip ? skip->C : 0);
         Act h1 = act(cout, x.H, x.W), h2 = act(cout, x.H, x.W), out = act(cout, x.H, x.W), rb;
         Stat st1, st2;
@@ -296,7 +311,7 @@ struct Builder {
             *gn1 = stat(1, bps, (float)(f.HW * f.C / bps));
             f.stats_out = gn1->p;
         }
-        if (!err) u->ops.push_back([f](const FwdCtx& c, hipStream_t s) { FinalizeArgs g = f; g.B = c.B; return finalize_launch(g, s); });
+        if (!err) push([f](const FwdCtx& c, hipStream_t s) { FinalizeArgs g = f; g.B = c.B; return finalize_launch(g, s); }, "finalize");
         u->named[p] = out; u->named[p + ".h1"] = h1; u->named[p + ".h2"] = h2;
         return out;
     }
@@ -304,6 +319,7 @@ struct Builder {
     // Residual(PreNorm(LinearAttention)) (unet.py:125-161,250): qkv conv with GroupNorm(1) in its loader | context |
     // apply | to_out conv | GroupNorm(1) + residual.
     Act linattn(const std::string& p, const Act& x, const Stat& gn1) {
+        scope = p;
         const int hid = u->heads * 32, n = x.H * x.W, heads = u->heads;
         Act qkv = act(3 * hid, x.H, x.W), lao = act(hid, x.H, x.W), yb = act(x.C, x.H, x.W), out = act(x.C, x.H, x.W);
         float* ctx = dmalloc((size_t)B * heads * 32 * 32);
@@ -314,9 +330,8 @@ struct Builder {
         conv(a, qkv, 0, nullptr);
         const float* qp = qkv.p; float* lp = lao.p;
         if (!err) {
-            u->ops.push_back([=](const FwdCtx& c, hipStream_t s) { return linattn_ctx_launch(qp, ctx, c.B, n, heads, s); });
-            u->ops.push_back([=](const FwdCtx& c, hipStream_t s) { return linattn_apply_launch(qp, ctx, lp, c.B, n, heads, s); });
-            u->flops += 2.0 * 2.0 * n * 32 * 32 * heads;
+            push([=](const FwdCtx& c, hipStream_t s) { return linattn_ctx_launch(qp, ctx, c.B, n, heads, s); }, "linattn_ctx", 2.0 * n * 32 * 32 * heads);
+            push([=](const FwdCtx& c, hipStream_t s) { return linattn_apply_launch(qp, ctx, lp, c.B, n, heads, s); }, "linattn_apply", 2.0 * n * 32 * 32 * heads);
         }
         ConvArgs o;
         o.s0.p = lao.p; o.s0.C = hid; o.Hs = x.H; o.Ws = x.W; o.KS = 1; o.pad = 0;
@@ -326,13 +341,14 @@ struct Builder {
         FinalizeArgs f;
         f.h = yb.p; f.xf = xf_of(sty, 1, u->R(p + ".fn.fn.to_out.1.weight"), u->R(p + ".fn.fn.to_out.1.bias"));
         f.res = x.p; f.y = out.p; f.HW = n; f.C = x.C;
-        if (!err) u->ops.push_back([f](const FwdCtx& c, hipStream_t s) { FinalizeArgs g = f; g.B = c.B; return finalize_launch(g, s); });
+        if (!err) push([f](const FwdCtx& c, hipStream_t s) { FinalizeArgs g = f; g.B = c.B; return finalize_launch(g, s); }, "finalize");
         u->named[p] = out; u->named[p + ".qkv"] = qkv; u->named[p + ".lao"] = lao; u->named[p + ".y"] = yb;
         return out;
     }
 
     // Residual(PreNorm(Attention)) (unet.py:99-122,262)
     Act midattn(const Act& x, const Stat& gn1) {
+        scope = "mid_attn";
         const int hid = u->heads * 32, n = x.H * x.W, heads = u->heads;
         Act qkv = act(3 * hid, x.H, x.W), ao = act(hid, x.H, x.W), out = act(x.C, x.H, x.W);
         ConvArgs a;
@@ -342,8 +358,7 @@ struct Builder {
         conv(a, qkv, 0, nullptr);
         const float* qp = qkv.p; float* ap = ao.p;
         if (!err) {
-            u->ops.push_back([=](const FwdCtx& c, hipStream_t s) { return attn_small_launch(qp, ap, c.B, n, heads, s); });
-            u->flops += 2.0 * 2.0 * n * n * 32 * heads;
+            push([=](const FwdCtx& c, hipStream_t s) { return attn_small_launch(qp, ap, c.B, n, heads, s); }, "attn_small", 2.0 * 2.0 * n * n * 32 * heads);
         }
         ConvArgs o;
         o.s0.p = ao.p; o.s0.C = hid; o.Hs = x.H; o.Ws = x.W; o.KS = 1;
@@ -356,6 +371,7 @@ struct Builder {
 
     // x + SiLU(conv3x3(cat[x, bilinear(mask)]))  (unet.py:336-340,360-364); a plain copy when no mask is given
     Act mask_inject(const std::string& name, const Act& x, const Act& mask_nhwc) {
+        scope = name;
         Act mr = act(mask_nhwc.C, x.H, x.W), out = act(x.C, x.H, x.W);
         const float* mp = mask_nhwc.p; float* rp = mr.p;
         const int C = mask_nhwc.C, Hs = mask_nhwc.H, Ws = mask_nhwc.W, Hd = x.H, Wd = x.W;
@@ -369,12 +385,12 @@ struct Builder {
         const int tile = g.tile;
         const size_t bytes_per = (size_t)x.H * x.W * x.C * sizeof(float);
         const float* xp = x.p; float* op = out.p;
-        u->ops.push_back([=](const FwdCtx& c, hipStream_t s) -> int {
+        push([=](const FwdCtx& c, hipStream_t s) -> int {
             if (!c.mask) { FC_HIP(hipMemcpyAsync(op, xp, bytes_per * c.B, hipMemcpyDeviceToDevice, s)); return FC_OK; }
             FC_TRY(bilinear_nhwc_launch(mp, rp, c.B, C, Hs, Ws, Hd, Wd, s));
             ConvArgs b = a; b.B = c.B;
             return conv_launch(b, tile, s);
-        });
+        }, std::string("bilinear+") + kTileNames[tile], 2.0 * x.H * x.W * 9 * (double)a.Cin * a.Cout);
         return out;
     }
 };
@@ -385,6 +401,7 @@ static void free_plan(fc_unet* u) {
     for (void* p : u->allocs) (void)hipFree(p);
     u->allocs.clear();
     u->named.clear();
+    u->op_kernel.clear(); u->op_what.clear(); u->op_flops.clear();
     u->ops.clear();
     u->maxB = 0;
 }
@@ -416,14 +433,15 @@ static int build_plan(fc_unet* u, int maxB, int H, int W) {
             t.cw2t = u->P("class_cond_mlp.3.weight"); t.cb2 = u->R("class_cond_mlp.3.bias");
         }
         t.n_classes = ncls; t.t_out = u->t_emb; t.dim = dim; t.td = td;
-        u->ops.push_back([t](const FwdCtx& cx, hipStream_t s) {
+        b.scope = "time_mlp";
+        b.push([t](const FwdCtx& cx, hipStream_t s) {
             TembArgs a = t; a.B = cx.B; a.time = cx.time; a.class_ids = cx.ids; a.class_batch_mod = cx.ids_mod; a.null_from = cx.null_from;
             return temb_launch(a, s);
-        });
+        }, "temb", 2.0 * ((double)dim * td + (double)td * td * (ncls > 0 ? 3 : 1)));
         const float *te = u->t_emb, *wt = u->P("__ss_wt"), *sb = u->P("__ss_bias");
         float* ss = u->ss;
-        u->ops.push_back([=](const FwdCtx& cx, hipStream_t s) { return ss_launch(te, wt, sb, ss, cx.B, td, S, s); });
-        u->flops += 2.0 * ((double)dim * td + (double)td * td * (ncls > 0 ? 3 : 1) + (double)td * S);
+        b.scope = "resblock.mlp";
+        b.push([=](const FwdCtx& cx, hipStream_t s) { return ss_launch(te, wt, sb, ss, cx.B, td, S, s); }, "ss", 2.0 * (double)td * S);
     }
 
     // -- init_conv (unet.py:295) and mask fusion (unet.py:298-305) --
@@ -433,17 +451,17 @@ static int build_plan(fc_unet* u, int maxB, int H, int W) {
     {
         const float *w = u->P("init_conv.weight"), *bias = u->R("init_conv.bias");
         float* x0p = x0.p;
-        u->flops += 2.0 * HW * ch * dim;
+        b.scope = "init_conv";
         if (!c.mask_cond) {
-            u->ops.push_back([=](const FwdCtx& cx, hipStream_t s) { return init_conv_launch(cx.x, cx.x_mod, w, bias, x0p, cx.B, ch, HW, dim, s); });
+            b.push([=](const FwdCtx& cx, hipStream_t s) { return init_conv_launch(cx.x, cx.x_mod, w, bias, x0p, cx.B, ch, HW, dim, s); }, "init_conv", 2.0 * HW * ch * dim);
         } else {
             Act xi = b.act(dim, H, W), f1 = b.act(2 * dim, H, W), f2 = b.act(2 * dim, H, W);
             mask_nhwc = b.act(ch, H, W);
             float *xip = xi.p, *mp = mask_nhwc.p;
-            u->ops.push_back([=](const FwdCtx& cx, hipStream_t s) -> int {
+            b.push([=](const FwdCtx& cx, hipStream_t s) -> int {
                 if (cx.mask) FC_TRY(nchw_to_nhwc_launch(cx.mask, mp, cx.B, ch, HW, ch, cx.x_mod, s));
                 return init_conv_launch(cx.x, cx.x_mod, w, bias, cx.mask_fuse ? xip : x0p, cx.B, ch, HW, dim, s);
-            });
+            }, "init_conv", 2.0 * HW * ch * dim);
             ConvArgs a[3];
             const char* names[3] = {"mask_fusion_conv.0", "mask_fusion_conv.2", "mask_fusion_conv.4"};
             const Act* srcs[3] = {&xi, &f1, &f2};
@@ -462,12 +480,13 @@ static int build_plan(fc_unet* u, int maxB, int H, int W) {
             if (b.err) return b.err;
             const ConvArgs a0 = a[0], a1 = a[1], a2 = a[2];
             const int t0 = tiles[0], t1 = tiles[1], t2 = tiles[2];
-            u->ops.push_back([=](const FwdCtx& cx, hipStream_t s) -> int {
+            b.scope = "mask_fusion_conv";
+            b.push([=](const FwdCtx& cx, hipStream_t s) -> int {
                 if (!cx.mask_fuse) return FC_OK;
                 ConvArgs q = a0; q.B = cx.B; FC_TRY(conv_launch(q, t0, s));
                 q = a1; q.B = cx.B; FC_TRY(conv_launch(q, t1, s));
                 q = a2; q.B = cx.B; return conv_launch(q, t2, s);
-            });
+            }, "mask_fusion(3 x conv_igemm)", 2.0 * HW * (25.0 * (dim + ch) * 2 * dim + 9.0 * 2 * dim * 2 * dim + 9.0 * 2 * dim * dim));
         }
     }
 
@@ -483,6 +502,7 @@ static int build_plan(fc_unet* u, int maxB, int H, int W) {
         x = b.linattn(p + ".2", x, gn1);
         skips.push_back(x);
         if (c.mask_cond && i < 2) x = b.mask_inject("down_mask_fusions." + std::to_string(i) + ".0", x, mask_nhwc);
+        b.scope = p + ".3";
         ConvArgs a;
         a.s0.p = x.p; a.s0.C = x.C; a.Hs = x.H; a.Ws = x.W;
         if (i == L - 1) {
@@ -517,6 +537,7 @@ static int build_plan(fc_unet* u, int maxB, int H, int W) {
         x = b.resblock(p + ".1", x, &s2, dout, true, &gn1);
         x = b.linattn(p + ".2", x, gn1);
         if (c.mask_cond && i < 2) x = b.mask_inject("up_mask_fusions." + std::to_string(i) + ".0", x, mask_nhwc);
+        b.scope = p + ".3";
         ConvArgs a;
         a.s0.p = x.p; a.s0.C = x.C; a.Hs = x.H; a.Ws = x.W; a.KS = 3; a.pad = 1;
         if (i == L - 1) {
@@ -538,8 +559,8 @@ static int build_plan(fc_unet* u, int maxB, int H, int W) {
     if (b.err) return b.err;
     {
         const float *xp = x.p, *w = u->P("final_conv.weight"), *bias = u->R("final_conv.bias");
-        u->ops.push_back([=](const FwdCtx& cx, hipStream_t s) { return final_conv_launch(xp, w, bias, cx.out, cx.B, dim, HW, ch, s); });
-        u->flops += 2.0 * HW * dim * ch;
+        b.scope = "final_conv";
+        b.push([=](const FwdCtx& cx, hipStream_t s) { return final_conv_launch(xp, w, bias, cx.out, cx.B, dim, HW, ch, s); }, "final_conv", 2.0 * HW * dim * ch);
     }
     // -- integrator state --
     const size_t nstate = (size_t)maxB * ch * HW;
@@ -688,6 +709,45 @@ int fc_unet_forward(fc_unet* u, const float* x, const float* time, const int64_t
     c.mask_fuse = (c.mask && !mask_is_ones) ? 1 : 0;
     c.out = out; c.B = B;
     return run_forward(u, c, static_cast<hipStream_t>(stream));
+}
+
+// Time every launch of the current plan on its own: each op is enqueued `repeats` times back to back between two
+// events on `stream` (ops are idempotent: they only read their inputs), so host launch gaps do not pollute kernels
+// that run longer than a launch takes to issue.  ms_out[i] = average milliseconds of op i.
+int fc_unet_profile_ops(fc_unet* u, int batch, int repeats, float* ms_out, int n_out, void* stream) {
+    if (!u || !ms_out || repeats < 1) return fail(FC_E_ARG, "fc_unet_profile_ops: bad argument");
+    FC_TRY(check_ready(u, batch, u->H, u->W));
+    const int n = (int)u->ops.size();
+    if (n_out < n) return fail(FC_E_ARG, "fc_unet_profile_ops: output array too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    FwdCtx c;
+    c.x = u->y; c.x_mod = batch; c.time = u->tvec; c.ids = nullptr; c.ids_mod = batch; c.out = u->v2; c.B = batch;
+    FC_HIP(hipMemsetAsync(u->tvec, 0, batch * sizeof(float), s));
+    FC_TRY(run_forward(u, c, s));  // warm: every buffer holds finite data
+    std::vector<hipEvent_t> ev(2 * n);
+    for (auto& e : ev) FC_HIP(hipEventCreate(&e));
+    int rc = FC_OK;
+    for (int i = 0; i < n && rc == FC_OK; ++i) {
+        (void)hipEventRecord(ev[2 * i], s);
+        for (int r = 0; r < repeats && rc == FC_OK; ++r) rc = u->ops[i](c, s);
+        (void)hipEventRecord(ev[2 * i + 1], s);
+    }
+    (void)hipStreamSynchronize(s);
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
+        ms_out[i] = ms / repeats;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
+int fc_unet_op_info(const fc_unet* u, int i, const char** kernel, const char** module, double* flops_per_sample) {
+    if (!u || i < 0 || i >= (int)u->ops.size()) return fail(FC_E_ARG, "fc_unet_op_info: index out of range");
+    if (kernel) *kernel = u->op_kernel[i].c_str();
+    if (module) *module = u->op_what[i].c_str();
+    if (flops_per_sample) *flops_per_sample = u->op_flops[i];
+    return FC_OK;
 }
 
 int fc_unet_plan_launches(const fc_unet* u) { return u ? (int)u->ops.size() : 0; }

@@ -240,6 +240,21 @@ class Unet(nn.Module):
                                           float(cfg_strength or 0.0), B.ptr(mask), int(mask_is_ones), B.current_stream(dev)))
         return x
 
+    def profile_ops(self, batch: int, repeats: int = 20):
+        """Per-launch device time of the current plan (bench.py's live roofline measurement).  Run a forward or an
+        integration first so the internal state holds finite data.  Returns a list of dicts."""
+        lib, h = B.lib(), self._handle
+        n = lib.fc_unet_plan_launches(h)
+        ms = (C.c_float * n)()
+        dev = self._handle_device
+        B.check(lib.fc_unet_profile_ops(h, batch, repeats, ms, n, B.current_stream(dev)))
+        out = []
+        for i in range(n):
+            k, m, f = C.c_char_p(), C.c_char_p(), C.c_double()
+            B.check(lib.fc_unet_op_info(h, i, C.byref(k), C.byref(m), C.byref(f)))
+            out.append(dict(kernel=k.value.decode(), module=m.value.decode(), flops_per_sample=f.value, ms=float(ms[i])))
+        return out
+
     def debug_tensor(self, name: str) -> torch.Tensor:
         """NHWC copy of an internal activation of the last forward (tests only)."""
         p, c, h, w = C.c_void_p(), C.c_int(), C.c_int(), C.c_int()
