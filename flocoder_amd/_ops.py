@@ -14,9 +14,10 @@ def _nhwc(t: Optional[torch.Tensor]):
 
 
 def conv_debug(x0: torch.Tensor, w: torch.Tensor, bias=None, x1=None, add=None, *, pad=0, stride=1, upsample=False,
-               out_act=False, groups_out=0, tile="auto"):
+               out_act=False, groups_out=0, tile="auto", repeats=0):
     """One implicit-GEMM launch.  NCHW in / NCHW out (converted with torch, test plumbing only).
-    Returns (out, stats) with stats = (mean, var) per (b, group) reconstructed from the kernel's partials, or None."""
+    Returns (out, stats) with stats = (mean, var) per (b, group) reconstructed from the kernel's partials, or None;
+    with repeats > 0 returns the average milliseconds of that many back-to-back launches instead."""
     dev = x0.device
     bsz, c0, hs, ws = x0.shape
     cout, cin, ks, _ = w.shape
@@ -27,13 +28,15 @@ def conv_debug(x0: torch.Tensor, w: torch.Tensor, bias=None, x1=None, add=None, 
     x0n, x1n, addn = _nhwc(x0.float()), _nhwc(None if x1 is None else x1.float()), _nhwc(None if add is None else add.float())
     out = torch.empty(bsz, ho, wo, cout, device=dev, dtype=torch.float32)
     stats = torch.full((bsz * max(groups_out, 1) * 4096 * 2,), float("nan"), device=dev) if groups_out else None
-    T, nt = C.c_int(0), C.c_float(0)
+    T, nt, ms = C.c_int(0), C.c_float(0), C.c_float(0)
     tile_id = B.TILE_AUTO if tile == "auto" else B.TILES[tile]
     wc = w.float().contiguous()
     bc = None if bias is None else bias.float().contiguous()
     B.check(B.lib().fc_debug_conv(B.ptr(x0n), c0, B.ptr(x1n), c1, B.ptr(wc), B.ptr(bc), B.ptr(addn), B.ptr(out), B.ptr(stats),
                                   groups_out, C.byref(T), C.byref(nt), bsz, hs, ws, cout, ks, pad, stride, int(upsample),
-                                  int(out_act), tile_id, B.current_stream(dev)))
+                                  int(out_act), tile_id, int(repeats), C.byref(ms), B.current_stream(dev)))
+    if repeats:
+        return ms.value
     res = out.permute(0, 3, 1, 2).contiguous()
     if not groups_out:
         return res, None

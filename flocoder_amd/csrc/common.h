@@ -85,11 +85,13 @@ enum ConvTile { TILE_AUTO = -1, TILE_M128N32 = 0, TILE_M128N64 = 1, TILE_M64N32K
                 TILE_COUNT = 5 };
 
 struct ConvGeom {  // filled by conv_plan(): what a consumer must know about `stats_out`
-    int tile = 0, grid = 0, T = 0;
+    int tile = 0, grid = 0, T = 0, pipe = 0;
     float n_t = 0.f;
     size_t lds = 0;
 };
 int conv_init();
+unsigned long long* conv_stamp_buffer();
+void conv_set_stamp_buffer(unsigned long long* p);  // diagnostics: phase stamps of the pipelined kernel
 int conv_plan(const ConvArgs& a, int tile, ConvGeom* g);
 int conv_launch(const ConvArgs& a, int tile, hipStream_t s);
 

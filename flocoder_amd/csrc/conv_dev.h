@@ -1,0 +1,186 @@
+// Shared between the two implicit-GEMM kernels (conv_igemm.hip: synchronous chunk loop, the fallback;
+// conv_pipe.hip: software-pipelined chunk loop, the fast path).
+#pragma once
+#include "common.h"
+
+namespace fc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvDev {
+    ConvArgs a;
+    int TWl, THl, TB, PH, PW, P;
+    int tiles_x, tiles_y, ntiles, nblocks;
+    int cpg, cpgt, NPG, rps;     // output-stats geometry
+    int act0, act1, any_xf;
+    int o_pixoff, o_pixtb, o_gstat, o_aff, o_patch, o_wl, o_wres, o_red, o_part;
+    // pipelined kernel only
+    const float* zeros16;        // 16 zero bytes in global memory: source of out-of-range LDS-DMA lanes
+    int patch_stride, wl_stride; // floats between the two pipeline stages of each buffer
+    int nchunks;
+    unsigned long long* stamps;  // diagnostic builds only: [block][8 waves][16] s_memtime samples, or null
+};
+
+// Phase stamp (diagnostics; null pointer = one scalar branch).  Lane 0 of every wave records the shader clock.
+__device__ __forceinline__ void conv_stamp(const ConvDev& p, int slot) {
+    if (p.stamps) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if ((threadIdx.x & 63) == 0) p.stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + slot] = t;
+    }
+}
+
+struct TileInfo { int BM, BN, CC, WK, MTNT, WMWN; };
+
+__device__ __forceinline__ float silu_f(float z) { return z / (1.0f + __expf(-z)); }
+
+// bijective XCD remap (cdna_hip_programming.md 5 "XCD swizzle must be bijective"): blocks that share an
+// XCD (bid % 8) get a contiguous run of tile ids, so n-tiles of one m-tile and neighbouring m-tiles hit
+// the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+
+// Shared epilogue: K-split reduction through LDS, + bias, GroupNorm partials, optional SiLU / residual, stores.
+template <int WM, int WN, int WK, int MT, int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT][NT], f32x16 (&accr)[MT][NT], float* smem, int tid, int lane,
+                                              int wave, int b0, int y0, int x0, int n0, int tx, int ty, bool active = true,
+                                              int nthr = 256) {
+    // `active` = this wave holds accumulators (false for the loader waves of the producer/consumer kernel, which only
+    // take part in the barriers and the statistics reduction); `nthr` = threads in the workgroup.
+    constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+    const ConvArgs& a = p.a;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
+    const int TW = 1 << p.TWl, TH = 1 << p.THl, Cout = a.Cout;
+    const bool has_res = a.res_out != nullptr;
+    if (WK > 1) {  // meet the K-split partials in LDS (patch/wl are dead now)
+        __syncthreads();
+        float* red = smem + p.o_red;
+        constexpr int TILE = 16 * 64;
+        const int slot = ((wm * WN + wn) * (WK - 1) + (wk - 1)) * MT * NT * (has_res ? 2 : 1);
+        if (active && wk > 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float* d = red + (size_t)(slot + mt * NT + nt) * TILE + lane;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) d[r * 64] = acc[mt][nt][r];
+                    if (has_res) {
+                        float* dr = red + (size_t)(slot + MT * NT + mt * NT + nt) * TILE + lane;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dr[r * 64] = accr[mt][nt][r];
+                    }
+                }
+        }
+        __syncthreads();
+        if (active && wk == 0) {
+            for (int k2 = 1; k2 < WK; ++k2) {
+                const int sl = ((wm * WN + wn) * (WK - 1) + (k2 - 1)) * MT * NT * (has_res ? 2 : 1);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float* d = red + (size_t)(sl + mt * NT + nt) * TILE + lane;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[mt][nt][r] += d[r * 64];
+                        if (has_res) {
+                            const float* dr = red + (size_t)(sl + MT * NT + mt * NT + nt) * TILE + lane;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) accr[mt][nt][r] += dr[r * 64];
+                        }
+                    }
+            }
+        }
+    }
+
+    conv_stamp(p, 6);
+    const bool owner = active && (wk == 0);
+    float* partS = smem + p.o_part;               // [BM/16][BN]
+    float* partQ = partS + (BM / 16) * BN;        // [BM/16][BN]
+    float* colS = partQ + (BM / 16) * BN;         // [TB][BN]
+    float* colQ = colS + p.TB * BN;
+    if (a.stats_out) __syncthreads();             // patch/wl (aliased by part*) are dead for every wave
+
+    if (owner) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int ncol = (wn * NT + nt) * 32 + l31, n = n0 + ncol;
+                const bool nok = n < Cout;
+                const float bias = (a.bias && nok) ? a.bias[n] : 0.f;
+                const float rbias = (has_res && a.res_b && nok) ? a.res_b[n] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] += bias;
+                if (a.stats_out) {
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        float s = 0.f, q = 0.f;
+#pragma unroll
+                        for (int r = 8 * hh; r < 8 * hh + 8; ++r) { const float v = acc[mt][nt][r]; s += v; q += v * v; }
+                        s += __shfl_xor(s, 32);
+                        q += __shfl_xor(q, 32);
+                        if (half == 0) {
+                            const int hb = (wm * MT + mt) * 2 + hh;
+                            partS[hb * BN + ncol] = s;
+                            partQ[hb * BN + ncol] = q;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int tw = m & (TW - 1), th = (m >> p.TWl) & (TH - 1), tb = m >> (p.TWl + p.THl);
+                    const int b = b0 + tb;
+                    if (nok && b < a.B) {
+                        const size_t o = ((size_t)(b * a.H + y0 + th) * a.W + x0 + tw) * Cout + n;
+                        float v = acc[mt][nt][r];
+                        if (a.out_act) v = silu_f(v);
+                        if (a.add) v += a.add[o];
+                        a.out[o] = v;
+                        if (has_res) a.res_out[o] = accr[mt][nt][r] + rbias;
+                    }
+                }
+            }
+    }
+
+    conv_stamp(p, 7);
+    if (a.stats_out) {
+        __syncthreads();
+        const int hb_per = p.rps >> 4;  // 16-row half-blocks per sample in this tile
+        for (int i = tid; i < p.TB * BN; i += nthr) {
+            const int tb = i / BN, col = i - tb * BN;
+            float s = 0.f, q = 0.f;
+            for (int h = 0; h < hb_per; ++h) { s += partS[(tb * hb_per + h) * BN + col]; q += partQ[(tb * hb_per + h) * BN + col]; }
+            colS[i] = s;
+            colQ[i] = q;
+        }
+        __syncthreads();
+        const int ncols = min(BN, Cout - n0), GT = ncols / p.cpgt;
+        for (int i = tid; i < p.TB * GT; i += nthr) {
+            const int tb = i / GT, gl = i - tb * GT, b = b0 + tb;
+            if (b >= a.B) continue;
+            float s = 0.f, q = 0.f;
+            for (int c = 0; c < p.cpgt; ++c) { s += colS[tb * BN + gl * p.cpgt + c]; q += colQ[tb * BN + gl * p.cpgt + c]; }
+            const float n = (float)(p.rps * p.cpgt), mean = s / n;
+            const int g = n0 / p.cpg + (p.cpg >= BN ? 0 : gl);
+            const int nsub = (p.cpg >= BN) ? (n0 % p.cpg) / BN : 0;
+            const int msub = (p.TB > 1) ? 0 : ty * p.tiles_x + tx;
+            const int T = (p.TB > 1 ? 1 : p.tiles_x * p.tiles_y) * p.NPG;
+            float* d = a.stats_out + ((size_t)(b * a.Gout + g) * T + msub * p.NPG + nsub) * 2;
+            d[0] = mean;
+            d[1] = q - s * mean;
+        }
+    }
+    conv_stamp(p, 8);
+}
+
+int conv_pipe_launch(const ConvDev& d, int tile, int grid, size_t lds, hipStream_t s);
+int conv_pipe_init();
+bool conv_pipe_supports_ks(int ks);
+const float* conv_zeros16();
+
+}  // namespace fc

@@ -22,30 +22,12 @@
 // Epilogue: + bias, per-tile GroupNorm partials (mean, M2) of the result written without atomics, optional
 // SiLU, optional residual add, optional second accumulator = 1x1 projection of the centre tap
 // (ResnetBlock.res_conv shares conv1's staged input).
-#include "common.h"
+#include <cstdlib>
+#include <string>
+
+#include "conv_dev.h"
 
 namespace fc {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct ConvDev {
-    ConvArgs a;
-    int TWl, THl, TB, PH, PW, P;
-    int tiles_x, tiles_y, ntiles, nblocks;
-    int cpg, cpgt, NPG, rps;     // output-stats geometry
-    int act0, act1, any_xf;
-    int o_pixoff, o_pixtb, o_gstat, o_aff, o_patch, o_wl, o_wres, o_red, o_part;
-};
-
-__device__ __forceinline__ float silu_f(float z) { return z / (1.0f + __expf(-z)); }
-
-// bijective XCD remap (cdna_hip_programming.md 5 "XCD swizzle must be bijective"): blocks that share an
-// XCD (bid % 8) get a contiguous run of tile ids, so n-tiles of one m-tile and neighbouring m-tiles hit
-// the same L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-}
 
 template <int WM, int WN, int WK, int MT, int NT, int CC>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvDev p) {
@@ -243,134 +225,10 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvDev p) {
         }
     }
 
-    // ---- epilogue ----
-    if (WK > 1) {  // meet the K-split partials in LDS (patch/wl are dead now)
-        __syncthreads();
-        float* red = smem + p.o_red;
-        constexpr int TILE = 16 * 64;
-        const int slot = ((wm * WN + wn) * (WK - 1) + (wk - 1)) * MT * NT * (has_res ? 2 : 1);
-        if (wk > 0) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    float* d = red + (size_t)(slot + mt * NT + nt) * TILE + lane;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) d[r * 64] = acc[mt][nt][r];
-                    if (has_res) {
-                        float* dr = red + (size_t)(slot + MT * NT + mt * NT + nt) * TILE + lane;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) dr[r * 64] = accr[mt][nt][r];
-                    }
-                }
-        }
-        __syncthreads();
-        if (wk == 0) {
-            for (int k2 = 1; k2 < WK; ++k2) {
-                const int sl = ((wm * WN + wn) * (WK - 1) + (k2 - 1)) * MT * NT * (has_res ? 2 : 1);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const float* d = red + (size_t)(sl + mt * NT + nt) * TILE + lane;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[mt][nt][r] += d[r * 64];
-                        if (has_res) {
-                            const float* dr = red + (size_t)(sl + MT * NT + mt * NT + nt) * TILE + lane;
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) accr[mt][nt][r] += dr[r * 64];
-                        }
-                    }
-            }
-        }
-    }
-
-    const bool owner = (wk == 0);
-    float* partS = smem + p.o_part;               // [BM/16][BN]
-    float* partQ = partS + (BM / 16) * BN;        // [BM/16][BN]
-    float* colS = partQ + (BM / 16) * BN;         // [TB][BN]
-    float* colQ = colS + p.TB * BN;
-    if (a.stats_out) __syncthreads();             // patch/wl (aliased by part*) are dead for every wave
-
-    if (owner) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int ncol = (wn * NT + nt) * 32 + l31, n = n0 + ncol;
-                const bool nok = n < Cout;
-                const float bias = (a.bias && nok) ? a.bias[n] : 0.f;
-                const float rbias = (has_res && a.res_b && nok) ? a.res_b[n] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][nt][r] += bias;
-                if (a.stats_out) {
-#pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        float s = 0.f, q = 0.f;
-#pragma unroll
-                        for (int r = 8 * hh; r < 8 * hh + 8; ++r) { const float v = acc[mt][nt][r]; s += v; q += v * v; }
-                        s += __shfl_xor(s, 32);
-                        q += __shfl_xor(q, 32);
-                        if (half == 0) {
-                            const int hb = (wm * MT + mt) * 2 + hh;
-                            partS[hb * BN + ncol] = s;
-                            partQ[hb * BN + ncol] = q;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const int tw = m & (TW - 1), th = (m >> p.TWl) & (TH - 1), tb = m >> (p.TWl + p.THl);
-                    const int b = b0 + tb;
-                    if (nok && b < a.B) {
-                        const size_t o = ((size_t)(b * a.H + y0 + th) * a.W + x0 + tw) * Cout + n;
-                        float v = acc[mt][nt][r];
-                        if (a.out_act) v = silu_f(v);
-                        if (a.add) v += a.add[o];
-                        a.out[o] = v;
-                        if (has_res) a.res_out[o] = accr[mt][nt][r] + rbias;
-                    }
-                }
-            }
-    }
-
-    if (a.stats_out) {
-        __syncthreads();
-        const int hb_per = p.rps >> 4;  // 16-row half-blocks per sample in this tile
-        for (int i = tid; i < p.TB * BN; i += 256) {
-            const int tb = i / BN, col = i - tb * BN;
-            float s = 0.f, q = 0.f;
-            for (int h = 0; h < hb_per; ++h) { s += partS[(tb * hb_per + h) * BN + col]; q += partQ[(tb * hb_per + h) * BN + col]; }
-            colS[i] = s;
-            colQ[i] = q;
-        }
-        __syncthreads();
-        const int ncols = min(BN, Cout - n0), GT = ncols / p.cpgt;
-        for (int i = tid; i < p.TB * GT; i += 256) {
-            const int tb = i / GT, gl = i - tb * GT, b = b0 + tb;
-            if (b >= a.B) continue;
-            float s = 0.f, q = 0.f;
-            for (int c = 0; c < p.cpgt; ++c) { s += colS[tb * BN + gl * p.cpgt + c]; q += colQ[tb * BN + gl * p.cpgt + c]; }
-            const float n = (float)(p.rps * p.cpgt), mean = s / n;
-            const int g = n0 / p.cpg + (p.cpg >= BN ? 0 : gl);
-            const int nsub = (p.cpg >= BN) ? (n0 % p.cpg) / BN : 0;
-            const int msub = (p.TB > 1) ? 0 : ty * p.tiles_x + tx;
-            const int T = (p.TB > 1 ? 1 : p.tiles_x * p.tiles_y) * p.NPG;
-            float* d = a.stats_out + ((size_t)(b * a.Gout + g) * T + msub * p.NPG + nsub) * 2;
-            d[0] = mean;
-            d[1] = q - s * mean;
-        }
-    }
+    conv_epilogue<WM, WN, WK, MT, NT>(p, acc, accr, smem, tid, lane, wave, b0, y0, x0, n0, tx, ty);
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <int WM, int WN, int WK, int MT, int NT, int CC>
-struct TileTraits {
-    static constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN, cc = CC, wk = WK, mtnt = MT * NT, wmwn = WM * WN;
-};
-
-struct TileInfo { int BM, BN, CC, WK, MTNT, WMWN; };
 static const TileInfo kTiles[TILE_COUNT] = {
     {128, 32, 32, 1, 1, 4},  // TILE_M128N32
     {128, 64, 16, 1, 2, 4},  // TILE_M128N64
@@ -379,11 +237,26 @@ static const TileInfo kTiles[TILE_COUNT] = {
     {64, 64, 16, 2, 2, 2},   // TILE_M64N64K2
 };
 
+// the pipelined kernel's instantiations (conv_pipe.hip): same wave layouts, chunk depth chosen so that two stages fit
+static const TileInfo kTilesPipe[TILE_COUNT] = {
+    {128, 32, 16, 1, 1, 4},  // TILE_M128N32
+    {128, 64, 16, 1, 2, 4},  // TILE_M128N64
+    {64, 32, 32, 2, 1, 2},   // TILE_M64N32K2
+    {32, 32, 32, 4, 1, 1},   // TILE_M32N32K4
+    {64, 64, 16, 2, 2, 2},   // TILE_M64N64K2
+};
+constexpr int kPipeNPL = 8;   // patch float4 elements a thread may own per stage
+
 static int align4(int v) { return (v + 3) & ~3; }
 
-static int conv_geometry(const ConvArgs& a, int tile, ConvDev* d, ConvGeom* g) {
+static bool pipe_disabled() {
+    static const bool off = [] { const char* e = std::getenv("FLOCODER_AMD_CONV"); return e && std::string(e) == "simple"; }();
+    return off;
+}
+
+static int conv_geometry(const ConvArgs& a, int tile, bool pipe, ConvDev* d, ConvGeom* g) {
     if (tile < 0 || tile >= TILE_COUNT) return fail(FC_E_ARG, "conv: bad tile id");
-    const TileInfo& t = kTiles[tile];
+    const TileInfo& t = pipe ? kTilesPipe[tile] : kTiles[tile];
     if (!is_pow2(a.H) || !is_pow2(a.W)) return fail(FC_E_SHAPE, "conv: H and W must be powers of two");
     if ((a.s0.C & 3) || (a.s1.C & 3) || (a.Cout & 3)) return fail(FC_E_SHAPE, "conv: channel counts must be multiples of 4");
     if (a.s0.C + a.s1.C != a.Cin) return fail(FC_E_ARG, "conv: Cin != C0 + C1");
@@ -398,6 +271,7 @@ static int conv_geometry(const ConvArgs& a, int tile, ConvDev* d, ConvGeom* g) {
     if (a.w_batch_stride && TB != 1) return fail(FC_E_SHAPE, "conv: per-sample weights need >= BM pixels per sample");
     ConvDev& p = *d;
     p.a = a;
+    p.stamps = nullptr;
     p.TWl = ilog2(TW); p.THl = ilog2(TH); p.TB = TB;
     p.PH = TH * a.stride + a.KS - a.stride;
     p.PW = TW * a.stride + a.KS - a.stride;
@@ -419,6 +293,34 @@ static int conv_geometry(const ConvArgs& a, int tile, ConvDev* d, ConvGeom* g) {
         p.NPG = p.cpg >= t.BN ? p.cpg / t.BN : 1;
         g->T = (TB > 1 ? 1 : p.tiles_x * p.tiles_y) * p.NPG;
         g->n_t = (float)(p.rps * p.cpgt);
+    }
+    g->pipe = pipe ? 1 : 0;
+    if (pipe) {
+        if (!conv_pipe_supports_ks(a.KS)) return fail(FC_E_SHAPE, "conv: kernel size not instantiated in the pipelined kernel");
+        if (p.P * (t.CC / 4) > 256 * kPipeNPL) return fail(FC_E_SHAPE, "conv: patch too large for the pipelined kernel");
+        const int G0 = a.s0.xf.mode ? a.s0.xf.G : 0, G1 = a.s1.xf.mode ? a.s1.xf.G : 0;
+        int o = 0;
+        p.o_pixoff = p.o_pixtb = 0;
+        p.o_gstat = o; o += align4(2 * TB * (G0 + G1));
+        p.o_aff = o; o += p.any_xf ? align4(2 * TB * a.Cin) : 0;
+        p.o_patch = o;
+        p.patch_stride = align4(p.P * (t.CC + 1));
+        p.o_wl = o + 2 * p.patch_stride;
+        p.wl_stride = a.KS * a.KS * t.CC * t.BN + (a.res_out ? t.CC * t.BN : 0);
+        p.o_wres = 0;
+        const int main_sz = 2 * p.patch_stride + 2 * p.wl_stride;
+        int epi = 0;
+        p.o_red = o;
+        if (t.WK > 1) epi = t.WMWN * (t.WK - 1) * t.MTNT * (a.res_out ? 2 : 1) * 1024;
+        p.o_part = o + epi;
+        if (a.stats_out) epi += 2 * (t.BM / 16) * t.BN + 2 * TB * t.BN;
+        o += main_sz > epi ? main_sz : epi;
+        p.nchunks = cdiv(a.Cin, t.CC);
+        p.zeros16 = conv_zeros16();
+        p.stamps = conv_stamp_buffer();
+        g->tile = tile; g->grid = p.nblocks; g->lds = (size_t)o * sizeof(float);
+        if (g->lds > 160 * 1024) return fail(FC_E_SHAPE, "conv: tile does not fit in LDS");
+        return FC_OK;
     }
     // LDS carve (in floats)
     int o = 0;
@@ -455,10 +357,20 @@ static int auto_tile(const ConvArgs& a) {
     return TILE_M32N32K4;
 }
 
+static unsigned long long* g_stamps = nullptr;
+unsigned long long* conv_stamp_buffer() { return g_stamps; }
+void conv_set_stamp_buffer(unsigned long long* p) { g_stamps = p; }
+
+// pipelined kernel when its constraints hold, else the synchronous one
+static int geometry_best(const ConvArgs& a, int tile, ConvDev* d, ConvGeom* g) {
+    if (!pipe_disabled() && conv_geometry(a, tile, true, d, g) == FC_OK) return FC_OK;
+    return conv_geometry(a, tile, false, d, g);
+}
+
 int conv_plan(const ConvArgs& a, int tile, ConvGeom* g) {
     ConvDev d;
     if (tile == TILE_AUTO) tile = auto_tile(a);
-    return conv_geometry(a, tile, &d, g);
+    return geometry_best(a, tile, &d, g);
 }
 
 template <int WM, int WN, int WK, int MT, int NT, int CC>
@@ -484,6 +396,7 @@ int conv_init() {
     FC_TRY((allow_big_lds<2, 1, 2, 1, 1, 32>()));
     FC_TRY((allow_big_lds<1, 1, 4, 1, 1, 32>()));
     FC_TRY((allow_big_lds<2, 1, 2, 1, 2, 16>()));
+    FC_TRY(conv_pipe_init());
     done = true;
     return FC_OK;
 }
@@ -492,7 +405,8 @@ int conv_launch(const ConvArgs& a, int tile, hipStream_t s) {
     ConvDev d;
     ConvGeom g;
     if (tile == TILE_AUTO) tile = auto_tile(a);
-    FC_TRY(conv_geometry(a, tile, &d, &g));
+    FC_TRY(geometry_best(a, tile, &d, &g));
+    if (g.pipe) return conv_pipe_launch(d, tile, g.grid, g.lds, s);
     switch (tile) {
         case TILE_M128N32: return launch_t<4, 1, 1, 1, 1, 32>(d, g, s);
         case TILE_M128N64: return launch_t<4, 1, 1, 1, 2, 16>(d, g, s);

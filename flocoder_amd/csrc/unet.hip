@@ -848,6 +848,11 @@ int fc_unet_debug_tensor(const fc_unet* u, const char* name, const float** ptr, 
     return FC_OK;
 }
 
+int fc_debug_set_conv_stamps(void* buf_dev) {
+    conv_set_stamp_buffer(static_cast<unsigned long long*>(buf_dev));
+    return FC_OK;
+}
+
 int fc_debug_copy(void* dst_dev, const void* src_dev, int64_t bytes, void* stream) {
     FC_HIP(hipMemcpyAsync(dst_dev, src_dev, (size_t)bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
     return FC_OK;
@@ -855,7 +860,7 @@ int fc_debug_copy(void* dst_dev, const void* src_dev, int64_t bytes, void* strea
 
 int fc_debug_conv(const float* src0, int c0, const float* src1, int c1, const float* w_oihw, const float* bias, const float* add,
                   float* out, float* stats_out, int groups_out, int* stats_T, float* stats_nt, int batch, int hs, int ws, int cout,
-                  int ksize, int pad, int stride, int upsample, int out_act, int tile_cfg, void* stream) {
+                  int ksize, int pad, int stride, int upsample, int out_act, int tile_cfg, int repeats, float* ms_out, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     FC_TRY(conv_init());
     ConvArgs a;
@@ -873,6 +878,18 @@ int fc_debug_conv(const float* src0, int c0, const float* src1, int c1, const fl
     ConvGeom g;
     if (r == FC_OK) r = conv_plan(a, tile_cfg, &g);
     if (r == FC_OK) { if (stats_T) *stats_T = g.T; if (stats_nt) *stats_nt = g.n_t; r = conv_launch(a, g.tile, s); }
+    if (r == FC_OK && repeats > 0 && ms_out) {   // back-to-back timing of the same launch (warm caches)
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, s);
+        for (int i = 0; i < repeats && r == FC_OK; ++i) r = conv_launch(a, g.tile, s);
+        (void)hipEventRecord(e1, s);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        *ms_out = ms / repeats;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
     (void)hipStreamSynchronize(s);
     (void)hipFree(wp);
     return r;

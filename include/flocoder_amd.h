@@ -120,12 +120,17 @@ int fc_unet_set_time_freqs(fc_unet* u, const float* freqs_host, int n);
  * ("downs.0.0", "downs.0.2", "mid_attn", "ups.3.3", ...). */
 int fc_unet_debug_tensor(const fc_unet* u, const char* name, const float** ptr, int* channels, int* height, int* width);
 int fc_debug_copy(void* dst_dev, const void* src_dev, int64_t bytes, void* stream);
+/* Diagnostics: subsequent pipelined-conv launches write shader-clock phase stamps to buf_dev
+ * ([block][wave][16] uint64); NULL switches them off again. */
+int fc_debug_set_conv_stamps(void* buf_dev);
 /* One implicit-GEMM launch on caller tensors (NHWC activations, OIHW weights as torch stores them).
  * Synchronises; allocates a scratch weight buffer. stats_out [B][G][T][2] gets (mean, M2) partials, T and the
- * per-slot count come back through stats_T / stats_nt. tile_cfg = -1 picks automatically. */
+ * per-slot count come back through stats_T / stats_nt. tile_cfg = -1 picks automatically.  repeats > 0 additionally
+ * times that many back-to-back launches with HIP events (average milliseconds in *ms_out). */
 int fc_debug_conv(const float* src0_nhwc, int c0, const float* src1_nhwc, int c1, const float* w_oihw_dev, const float* bias_dev,
                   const float* add_nhwc, float* out_nhwc, float* stats_out, int groups_out, int* stats_T, float* stats_nt, int batch,
-                  int hs, int ws, int cout, int ksize, int pad, int stride, int upsample, int out_act, int tile_cfg, void* stream);
+                  int hs, int ws, int cout, int ksize, int pad, int stride, int upsample, int out_act, int tile_cfg, int repeats,
+                  float* ms_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Greedy OT pairing  (replaces flocoder/ot.py:63-84 compute_ot_pairing)

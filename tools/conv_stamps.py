@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Phase timeline of the pipelined conv kernel from in-kernel s_memtime stamps (diagnostic; GPU box only)."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from flocoder_amd import _binding as B
+from flocoder_amd._ops import conv_debug
+from tools.conv_microbench import LAYERS
+
+NAMES = ["start", "descr", "issue", "stored0", "barrier0", "mfma_done", "kreduce", "stores", "end"]
+dev = torch.device("cuda:0")
+only = sys.argv[1] if len(sys.argv) > 1 else ""
+tile = sys.argv[2] if len(sys.argv) > 2 else "auto"
+for name, c0, c1, co, H, ks, pad, stride, ups, G in LAYERS:
+    if only and only not in name:
+        continue
+    Bn = 64
+    x0 = torch.randn(Bn, c0, H, H, device=dev); x1 = torch.randn(Bn, c1, H, H, device=dev) if c1 else None
+    w = torch.randn(co, c0 + c1, ks, ks, device=dev) * 0.05; b = torch.randn(co, device=dev)
+    conv_debug(x0, w, b, x1=x1, pad=pad, stride=stride, upsample=bool(ups), groups_out=G, tile=tile)   # warm
+    buf = torch.zeros(8192 * 8 * 16, dtype=torch.int64, device=dev)
+    B.check(B.lib().fc_debug_set_conv_stamps(buf.data_ptr()))
+    conv_debug(x0, w, b, x1=x1, pad=pad, stride=stride, upsample=bool(ups), groups_out=G, tile=tile)
+    B.check(B.lib().fc_debug_set_conv_stamps(None))
+    torch.cuda.synchronize()
+    st = buf.view(8192, 8, 16).cpu()
+    nb = int((st[:, 0, 0] != 0).sum())
+    st = st[:nb].double()
+    print(f"{name}: {nb} blocks")
+    rel = (st[:, :, :9] - st[:, :, 0:1])      # per wave, relative to its own start (shader cycles)
+    for role, sl in (("consumer", slice(0, 4)), ("loader", slice(4, 8))):
+        med = rel[:, sl].median(dim=0).values.median(dim=0).values
+        print(f"   {role:8s} median timeline (cycles since wave start): " + ", ".join(f"{n}={int(v)}" for n, v in zip(NAMES, med.tolist())))
+    span = (st[:, :, 8].max(dim=1).values - st[:, :, 0].min(dim=1).values)
+    print(f"   workgroup lifetime: median {int(span.median())} cycles, max {int(span.max())}")
