@@ -54,9 +54,10 @@ def roofline(model, batch):
     by = {}
     for r in rows:
         k = by.setdefault(r["kernel"], dict(ms=0.0, flops=0.0, launches=0))
-        k["ms"] += r["ms"]; k["flops"] += r["flops_per_sample"] * batch; k["launches"] += 1
+        k["ms"] += r["ms"]; k["flops"] += r["flops_per_sample"] * r["rows"]; k["launches"] += 1
     name, dom = max(by.items(), key=lambda kv: kv[1]["ms"])
     total_ms = sum(v["ms"] for v in by.values())
+    rows_timed = rows[0]["rows"]
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
     return {
         "bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -64,7 +65,8 @@ def roofline(model, batch):
         "launches_per_forward": dom["launches"], "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
         "flops_per_launch_avg": dom["flops"] / dom["launches"], "share_of_forward_time": round(dom["ms"] / total_ms, 3),
         "forward_sum_of_kernels_ms": round(total_ms, 4),
-        "forward_tflops_all_kernels": round(model.flops_per_sample * batch / (total_ms * 1e-3) / 1e12, 3),
+        "rows_per_launch": rows_timed, "chains": model.chains[0],
+        "forward_tflops_all_kernels": round(model.flops_per_sample * rows_timed / (total_ms * 1e-3) / 1e12, 3),
         "per_kernel": {k: dict(ms=round(v["ms"], 4), launches=v["launches"], tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 3))
                        for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])},
     }

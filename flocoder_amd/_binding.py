@@ -40,6 +40,7 @@ SIGNATURES = {
     "fc_unet_reserve": (_i, [_vp, _i, _i, _i]),
     "fc_unet_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     "fc_unet_integrate": (_i, [_vp, _i, _vp, _i, _i, _i, _pf, _i, _f, _f, _vp, _f, _vp, _i, _vp]),
+    "fc_unet_chains": (_i, [_vp, _pi]),
     "fc_unet_plan_launches": (_i, [_vp]),
     "fc_unet_flops_per_sample": (C.c_double, [_vp]),
     "fc_unet_op_info": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_double)]),

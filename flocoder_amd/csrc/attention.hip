@@ -8,22 +8,28 @@ constexpr int DH = 32;
 
 // ---------------------------------------------------------------------------------------------------
 // LinearAttention part 1 (unet.py:143,146): ctx[d][e] = sum_n softmax_n(k)[d][n] * v[e][n].   grid (B*heads)
-// Pass 1 finds max_n k[d][n]; pass 2 walks n in tiles of 64 staged in LDS, accumulating the 32x32 context
-// (4 entries per thread) and the softmax denominators in registers.
+// Pass 1 finds max_n k[d][n]; pass 2 walks n in tiles of 64 rows staged in LDS (double-buffered, next tile in flight in
+// registers), accumulating the 32x32 context (4 entries per thread) and the softmax denominators in registers.
 __global__ void __launch_bounds__(256) linattn_ctx_kernel(const float* qkv, float* ctx, int n, int heads) {
     __shared__ float red[8][DH];
-    __shared__ float kmax[DH];
-    __shared__ __attribute__((aligned(16))) float ek[64][DH];
-    __shared__ __attribute__((aligned(16))) float vv[64][DH];
+    __shared__ __attribute__((aligned(16))) float kmax[DH];
+    __shared__ __attribute__((aligned(16))) float ek[2][64][DH];
+    __shared__ __attribute__((aligned(16))) float vv[2][64][DH];
     const int b = blockIdx.x / heads, h = blockIdx.x % heads, tid = threadIdx.x;
     const int C3 = 3 * heads * DH;
     const float* kb = qkv + (size_t)b * n * C3 + heads * DH + h * DH;
     const float* vb = kb + heads * DH;
-    {   // pass 1
+    {   // pass 1: max over n, 8 independent loads in flight per thread
         const int d = tid & 31, grp = tid >> 5;
-        float m = -INFINITY;
-        for (int i = grp; i < n; i += 8) m = fmaxf(m, kb[(size_t)i * C3 + d]);
-        red[grp][d] = m;
+        float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
+        int i = grp;
+        for (; i + 24 < n; i += 32) {
+            const float a0 = kb[(size_t)i * C3 + d], a1 = kb[(size_t)(i + 8) * C3 + d];
+            const float a2 = kb[(size_t)(i + 16) * C3 + d], a3 = kb[(size_t)(i + 24) * C3 + d];
+            m0 = fmaxf(m0, a0); m1 = fmaxf(m1, a1); m2 = fmaxf(m2, a2); m3 = fmaxf(m3, a3);
+        }
+        for (; i < n; i += 8) m0 = fmaxf(m0, kb[(size_t)i * C3 + d]);
+        red[grp][d] = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
         __syncthreads();
         if (tid < DH) {
             float mm = red[0][tid];
@@ -33,30 +39,49 @@ __global__ void __launch_bounds__(256) linattn_ctx_kernel(const float* qkv, floa
         }
         __syncthreads();
     }
+    // pass 2: tiles of 64 rows, double-buffered: tile t+1 travels HBM -> registers while tile t is consumed from LDS
     const int d = tid >> 3, e0 = (tid & 7) * 4;
+    const int r0 = tid >> 3, c4 = (tid & 7) * 4;     // staging role: rows r0 and r0 + 32, float4 column c4
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 km = *reinterpret_cast<const float4*>(&kmax[c4]);
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f, ksum = 0.f;
-    for (int i0 = 0; i0 < n; i0 += 64) {
-        const int cnt = min(64, n - i0);
-        for (int j = tid; j < 64 * 8; j += 256) {   // 64 rows x 8 float4
-            const int r = j >> 3, c4 = (j & 7) * 4;
-            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), v4 = kv;
-            if (r < cnt) {
-                kv = *reinterpret_cast<const float4*>(kb + (size_t)(i0 + r) * C3 + c4);
-                v4 = *reinterpret_cast<const float4*>(vb + (size_t)(i0 + r) * C3 + c4);
-                kv.x = __expf(kv.x - kmax[c4]); kv.y = __expf(kv.y - kmax[c4 + 1]);
-                kv.z = __expf(kv.z - kmax[c4 + 2]); kv.w = __expf(kv.w - kmax[c4 + 3]);
+    float4 kr[2], vr[2];
+    auto fetch = [&](int i0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r = i0 + r0 + 32 * u;
+            kr[u] = zero4; vr[u] = zero4;
+            if (r < n) {
+                kr[u] = *reinterpret_cast<const float4*>(kb + (size_t)r * C3 + c4);
+                vr[u] = *reinterpret_cast<const float4*>(vb + (size_t)r * C3 + c4);
             }
-            *reinterpret_cast<float4*>(&ek[r][c4]) = kv;
-            *reinterpret_cast<float4*>(&vv[r][c4]) = v4;
         }
-        __syncthreads();
+    };
+    auto stage = [&](int buf, int i0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r = r0 + 32 * u;
+            float4 e = zero4;
+            if (i0 + r < n) e = make_float4(__expf(kr[u].x - km.x), __expf(kr[u].y - km.y), __expf(kr[u].z - km.z), __expf(kr[u].w - km.w));
+            *reinterpret_cast<float4*>(&ek[buf][r][c4]) = e;
+            *reinterpret_cast<float4*>(&vv[buf][r][c4]) = vr[u];
+        }
+    };
+    fetch(0);
+    stage(0, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int i0 = 0; i0 < n; i0 += 64, buf ^= 1) {
+        const bool more = i0 + 64 < n;
+        if (more) fetch(i0 + 64);
 #pragma unroll 8
         for (int r = 0; r < 64; ++r) {
-            const float kd = ek[r][d];
-            const float4 v4 = *reinterpret_cast<const float4*>(&vv[r][e0]);
+            const float kd = ek[buf][r][d];
+            const float4 v4 = *reinterpret_cast<const float4*>(&vv[buf][r][e0]);
             acc0 += kd * v4.x; acc1 += kd * v4.y; acc2 += kd * v4.z; acc3 += kd * v4.w;
             ksum += kd;
         }
+        if (more) stage(buf ^ 1, i0 + 64);
         __syncthreads();
     }
     const float inv = 1.0f / ksum;

@@ -17,7 +17,8 @@ struct ConvDev {
     // pipelined kernel only
     const float* zeros16;        // 16 zero bytes in global memory: source of out-of-range LDS-DMA lanes
     int patch_stride, wl_stride; // floats between the two pipeline stages of each buffer
-    int nchunks;
+    int nchunks, nwb;            // Cin chunks; weight stages resident in LDS (2 or 3)
+    unsigned magic_phw, magic_pw;  // ceil(2^32 / PH*PW), ceil(2^32 / PW): x / d == umulhi(x, magic) for the small x used here
     unsigned long long* stamps;  // diagnostic builds only: [block][8 waves][16] s_memtime samples, or null
 };
 
@@ -30,6 +31,9 @@ __device__ __forceinline__ void conv_stamp(const ConvDev& p, int slot) {
 }
 
 struct TileInfo { int BM, BN, CC, WK, MTNT, WMWN; };
+
+// x / d for 0 <= x < 2^16 and 1 < d < 2^16 with magic = floor(2^32 / d) + 1 (exact in that range); magic == 0 encodes d == 1
+__device__ __forceinline__ int fastdiv(int x, unsigned magic) { return magic ? (int)__umulhi((unsigned)x, magic) : x; }
 
 __device__ __forceinline__ float silu_f(float z) { return z / (1.0f + __expf(-z)); }
 
@@ -100,8 +104,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
     const bool owner = active && (wk == 0);
     float* partS = smem + p.o_part;               // [BM/16][BN]
     float* partQ = partS + (BM / 16) * BN;        // [BM/16][BN]
-    float* colS = partQ + (BM / 16) * BN;         // [TB][BN]
-    float* colQ = colS + p.TB * BN;
     if (a.stats_out) __syncthreads();             // patch/wl (aliased by part*) are dead for every wave
 
     if (owner) {
@@ -150,29 +152,30 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
     conv_stamp(p, 7);
     if (a.stats_out) {
         __syncthreads();
-        const int hb_per = p.rps >> 4;  // 16-row half-blocks per sample in this tile
-        for (int i = tid; i < p.TB * BN; i += nthr) {
-            const int tb = i / BN, col = i - tb * BN;
+        // thread i <-> (sample tb, column col) sums its column over the sample's 16-row half-blocks, then the cpgt columns of a
+        // group -- consecutive lanes of one wave, cpgt a power of two <= 64 -- meet by xor-shuffles; the group's first lane writes.
+        const int hb_per = p.rps >> 4;
+        const int ncols = min(BN, Cout - n0);
+        for (int i0 = 0; i0 < p.TB * BN; i0 += nthr) {
+            const int i = i0 + tid;
+            const bool live = i < p.TB * BN;
+            const int tb = live ? i / BN : 0, col = live ? i - tb * BN : 0;
             float s = 0.f, q = 0.f;
-            for (int h = 0; h < hb_per; ++h) { s += partS[(tb * hb_per + h) * BN + col]; q += partQ[(tb * hb_per + h) * BN + col]; }
-            colS[i] = s;
-            colQ[i] = q;
-        }
-        __syncthreads();
-        const int ncols = min(BN, Cout - n0), GT = ncols / p.cpgt;
-        for (int i = tid; i < p.TB * GT; i += nthr) {
-            const int tb = i / GT, gl = i - tb * GT, b = b0 + tb;
-            if (b >= a.B) continue;
-            float s = 0.f, q = 0.f;
-            for (int c = 0; c < p.cpgt; ++c) { s += colS[tb * BN + gl * p.cpgt + c]; q += colQ[tb * BN + gl * p.cpgt + c]; }
-            const float n = (float)(p.rps * p.cpgt), mean = s / n;
-            const int g = n0 / p.cpg + (p.cpg >= BN ? 0 : gl);
-            const int nsub = (p.cpg >= BN) ? (n0 % p.cpg) / BN : 0;
-            const int msub = (p.TB > 1) ? 0 : ty * p.tiles_x + tx;
-            const int T = (p.TB > 1 ? 1 : p.tiles_x * p.tiles_y) * p.NPG;
-            float* d = a.stats_out + ((size_t)(b * a.Gout + g) * T + msub * p.NPG + nsub) * 2;
-            d[0] = mean;
-            d[1] = q - s * mean;
+            if (live)
+                for (int h = 0; h < hb_per; ++h) { s += partS[(tb * hb_per + h) * BN + col]; q += partQ[(tb * hb_per + h) * BN + col]; }
+            for (int o = p.cpgt >> 1; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+            const int b = b0 + tb;
+            if (live && (col & (p.cpgt - 1)) == 0 && col < ncols && b < a.B) {
+                const int gl = col / p.cpgt;
+                const float n = (float)(p.rps * p.cpgt), mean = s / n;
+                const int g = n0 / p.cpg + (p.cpg >= BN ? 0 : gl);
+                const int nsub = (p.cpg >= BN) ? (n0 % p.cpg) / BN : 0;
+                const int msub = (p.TB > 1) ? 0 : ty * p.tiles_x + tx;
+                const int T = (p.TB > 1 ? 1 : p.tiles_x * p.tiles_y) * p.NPG;
+                float* d = a.stats_out + ((size_t)(b * a.Gout + g) * T + msub * p.NPG + nsub) * 2;
+                d[0] = mean;
+                d[1] = q - s * mean;
+            }
         }
     }
     conv_stamp(p, 8);

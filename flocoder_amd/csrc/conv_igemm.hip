@@ -276,6 +276,8 @@ static int conv_geometry(const ConvArgs& a, int tile, bool pipe, ConvDev* d, Con
     p.PH = TH * a.stride + a.KS - a.stride;
     p.PW = TW * a.stride + a.KS - a.stride;
     p.P = TB * p.PH * p.PW;
+    p.magic_phw = p.PH * p.PW > 1 ? (unsigned)((1ull << 32) / (unsigned)(p.PH * p.PW)) + 1u : 0u;
+    p.magic_pw = p.PW > 1 ? (unsigned)((1ull << 32) / (unsigned)p.PW) + 1u : 0u;
     p.tiles_x = a.W / TW; p.tiles_y = a.H / TH;
     p.ntiles = cdiv(a.Cout, t.BN);
     p.nblocks = cdiv(a.B, TB) * p.tiles_x * p.tiles_y * p.ntiles;
@@ -308,14 +310,16 @@ static int conv_geometry(const ConvArgs& a, int tile, bool pipe, ConvDev* d, Con
         p.o_wl = o + 2 * p.patch_stride;
         p.wl_stride = a.KS * a.KS * t.CC * t.BN + (a.res_out ? t.CC * t.BN : 0);
         p.o_wres = 0;
-        const int main_sz = 2 * p.patch_stride + 2 * p.wl_stride;
+        p.nchunks = cdiv(a.Cin, t.CC);
+        // a third weight stage lets slabs run two chunks ahead of the MFMAs; only worth its LDS when there are chunks to run ahead of
+        p.nwb = (p.nchunks >= 3 && (size_t)(o + 2 * p.patch_stride + 3 * p.wl_stride) * sizeof(float) <= 160 * 1024) ? 3 : 2;
+        const int main_sz = 2 * p.patch_stride + p.nwb * p.wl_stride;
         int epi = 0;
         p.o_red = o;
         if (t.WK > 1) epi = t.WMWN * (t.WK - 1) * t.MTNT * (a.res_out ? 2 : 1) * 1024;
         p.o_part = o + epi;
         if (a.stats_out) epi += 2 * (t.BM / 16) * t.BN + 2 * TB * t.BN;
         o += main_sz > epi ? main_sz : epi;
-        p.nchunks = cdiv(a.Cin, t.CC);
         p.zeros16 = conv_zeros16();
         p.stamps = conv_stamp_buffer();
         g->tile = tile; g->grid = p.nblocks; g->lds = (size_t)o * sizeof(float);

@@ -20,8 +20,56 @@
 
 namespace fc {
 
-typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+
+// One LDS-DMA wave instruction: 64 lanes x 16 B from per-lane global addresses to lds_dst + lane*16 (wave-uniform base in
+// M0).  Inline asm on purpose (cdna_hip_programming.md 5.7): hipcc then keeps these out of its vmcnt bookkeeping, so the
+// waits it inserts for the loaders' ordinary register loads do not drain a slab that was issued for a LATER stage; we
+// count them by hand (explicit vmcnt(0) before a stage is handed over).  M0 is saved/restored inside the statement.
+__device__ __forceinline__ void lds_dma16(const float* gsrc, float* lds_dst) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)lds_dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Register load the compiler does not count either (same reason): 16 B per lane; the caller waits with wait_vmcnt().
+__device__ __forceinline__ void hidden_load16(f32x4& dst, const float* gsrc) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(gsrc) : "memory");
+}
+// s_waitcnt vmcnt(n) for a run-time n (the instruction takes an immediate).  vmcnt counts loads and LDS-DMA together in
+// issue order, so "all but my n youngest" = everything issued before the slab that is allowed to stay in flight.
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    // s_waitcnt ignores EXEC, so the selection must be a SCALAR branch: readfirstlane makes n provably wave-uniform
+    switch (__builtin_amdgcn_readfirstlane(n)) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // more pieces than cases: drain (correct, just no lookahead)
+    }
+    __builtin_amdgcn_sched_barrier(0);   // nothing that reads the hidden loads' registers may move above the wait
+}
+__device__ __forceinline__ void loader_handover() {   // LDS stores of this wave visible, then the workgroup barrier; no vmcnt drain
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 template <int WM, int WN, int WK, int MT, int NT, int CC, int NPL, int KS>
 __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvDev p) {
@@ -114,7 +162,7 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvDev p) {
                 const int pix = ltid / Q + k * PIXSTEP;
                 e_po[k] = -1; e_lds[k] = -1; e_tb[k] = 0;
                 if (pix < p.P) {
-                    const int tb = pix / PHW, r = pix - tb * PHW, py = r / PW, px = r - py * PW;
+                    const int tb = fastdiv(pix, p.magic_phw), r = pix - tb * PHW, py = fastdiv(r, p.magic_pw), px = r - py * PW;
                     const int iy = y0 * a.stride - a.pad + py, ix = x0 * a.stride - a.pad + px, b = b0 + tb;
                     if (b < a.B && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) e_po[k] = (b * a.Hs + (iy >> a.ups)) * a.Ws + (ix >> a.ups);
                     e_lds[k] = pix * CS + q4;
@@ -123,41 +171,57 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvDev p) {
             }
         }
         conv_stamp(p, 1);
-        for (int i = 0; i < nchunks; ++i) {      // fill stage i while the consumers work on stage i-1
+        const int nwb = p.nwb;                    // weight stages in LDS: 3 = slabs run two chunks ahead, 2 = one ahead
+        // LDS-DMA plan of this wave: piece j = wave + 4m covers 256 floats of the slab = (256/BN) rows x BN columns.  A lane's
+        // source pointer at chunk 0 is fixed for the whole kernel and advances by CC*Cout floats per chunk, so issuing a slab
+        // costs one 64-bit add + one scalar add per piece (the address arithmetic used to outweigh the transfer: the loaders,
+        // not the MFMA waves, set the pace of the small-M layers -- profiles/r01_c_stamps.txt).
+        constexpr int MAXP = ((KK + 1) * CC * BN / 256 + 3) / 4;
+        const int rows_main = KK * CC, npieces = (rows_main + (has_res ? CC : 0)) * BN / 256;
+        const int my_pieces = __builtin_amdgcn_readfirstlane(npieces > wave ? (npieces - wave + 3) / 4 : 0);
+        const float* d_ptr[MAXP];   // nullptr: column beyond Cout -> zero block
+        int d_row[MAXP];            // channel row inside the chunk (for the Cin tail test)
+#pragma unroll
+        for (int m = 0; m < MAXP; ++m) {
+            const int j = wave + 4 * m, f = j * 256 + lane * 4, row = f / BN, n = n0 + (f % BN);
+            const bool res = row >= rows_main;
+            d_row[m] = res ? row - rows_main : row % CC;
+            d_ptr[m] = n >= Cout ? nullptr : (res ? a.res_w + (size_t)d_row[m] * Cout + n : wbase + ((size_t)(row / CC) * Cin + d_row[m]) * Cout + n);
+        }
+        auto dma_weights = [&](int i) {
             const int c0 = i * CC;
-            float* pb = patch0 + (i & 1) * p.patch_stride;
-            float* wb = wl0 + (i & 1) * p.wl_stride;
-            {   // weight slab: rows [0, KK*CC) conv taps, rows [KK*CC, KK*CC + CC) res_conv; BN floats per row; 1 KiB pieces
-                const int rows_main = KK * CC, rows = rows_main + (has_res ? CC : 0), npieces = rows * BN / 256;
-                for (int j = wave; j < npieces; j += 4) {
-                    const int f = j * 256 + lane * 4, row = f / BN, n = n0 + (f % BN);
-                    const float* src = p.zeros16;
-                    if (n < Cout) {
-                        if (row < rows_main) {
-                            const int gc = c0 + (row % CC);
-                            if (gc < Cin) src = wbase + ((size_t)(row / CC) * Cin + gc) * Cout + n;
-                        } else {
-                            const int gc = c0 + (row - rows_main);
-                            if (gc < Cin) src = a.res_w + (size_t)gc * Cout + n;
-                        }
-                    }
-                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(wb + j * 256), 16, 0, 0);
-                }
+            const size_t adv = (size_t)c0 * Cout;
+            float* wb = wl0 + (i % nwb) * p.wl_stride + wave * 256;
+            const bool tail = c0 + CC > Cin;            // only the last chunk can run past Cin
+#pragma unroll
+            for (int m = 0; m < MAXP; ++m) {
+                if (m >= my_pieces) break;
+                const bool ok = d_ptr[m] != nullptr && (!tail || c0 + d_row[m] < Cin);
+                lds_dma16(ok ? d_ptr[m] + adv : p.zeros16, wb + m * 1024);
             }
-            const int c = c0 + q4;
-            const bool live = c < Cin, first = c < C0, act = first ? p.act0 : p.act1;
+        };
+        f32x4 pv[NPL];
+        const int nk = __builtin_amdgcn_readfirstlane((p.P * Q + 255) / 256);   // element slots in use (scalar: cheap loop exits)
+        auto issue_patch = [&](int i) {           // input window of chunk i -> registers, every load issued back to back
+            const int c = i * CC + q4;
+            const bool live = c < Cin, first = c < C0;
             const float* base = first ? a.s0.p + c : a.s1.p + (c - C0);
             const int Cs = first ? C0 : C1;
-            float4 v[NPL];
 #pragma unroll
-            for (int k = 0; k < NPL; ++k) {
-                v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (live && e_po[k] >= 0) v[k] = *reinterpret_cast<const float4*>(base + (size_t)e_po[k] * Cs);
+            for (int k = 0; k < NPL; ++k) {       // padding / out-of-range elements read the zero block: no branches, zeros arrive
+                if (k >= nk) break;
+                hidden_load16(pv[k], (live && e_po[k] >= 0) ? base + (size_t)e_po[k] * Cs : p.zeros16);
             }
+        };
+        auto store_patch = [&](int i) {           // ... and on into LDS with GroupNorm / FiLM / SiLU applied
+            const int c = i * CC + q4;
+            float* pb = patch0 + (i & 1) * p.patch_stride;
+            const bool live = c < Cin, act = (c < C0) ? p.act0 : p.act1;
 #pragma unroll
             for (int k = 0; k < NPL; ++k) {
+                if (k >= nk) break;
                 if (e_lds[k] < 0) continue;
-                float4 x = v[k];
+                f32x4 x = pv[k];
                 if (p.any_xf && live && e_po[k] >= 0) {
                     const float2* ab = aff + e_tb[k] * Cin + c;
                     x.x = ab[0].x * x.x + ab[0].y; x.y = ab[1].x * x.y + ab[1].y;
@@ -167,10 +231,36 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvDev p) {
                 float* d = pb + e_lds[k];
                 d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
             }
-            if (i == 0) conv_stamp(p, 3);
-            __syncthreads();    // stage i handed over (LDS-DMA drained: the barrier waits vmcnt(0)); stage i-1 is free again
+        };
+        unsigned long long dbg_mem = 0, dbg_store = 0, dbg_bar = 0, dbg_issue = 0, dbg_dma = 0;   // diagnostics: cycles per loader phase
+        dma_weights(0);
+        if (nwb == 3 && nchunks > 1) dma_weights(1);
+        issue_patch(0);
+        wait_vmcnt(0);
+        store_patch(0);
+        conv_stamp(p, 3);
+        loader_handover();                        // stage 0 ready
+        for (int g = 0; g < nchunks; ++g) {       // consumers are on chunk g
+            const bool next = g + 1 < nchunks;
+            int ahead = 0;
+            unsigned long long ta = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+            if (next && nwb == 2) dma_weights(g + 1);
+            if (next) issue_patch(g + 1);
+            unsigned long long tb_ = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+            if (nwb == 3 && g + 2 < nchunks) { dma_weights(g + 2); ahead = my_pieces; }
+            unsigned long long t0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+            if (p.stamps) { dbg_issue += tb_ - ta; dbg_dma += t0 - tb_; }
+            wait_vmcnt(ahead);                    // window g+1 in registers, slab g+1 landed; slab g+2 stays in flight across the barrier
+            unsigned long long t1 = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+            if (next) store_patch(g + 1);
+            unsigned long long t2 = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+            loader_handover();
+            if (p.stamps) { dbg_mem += t1 - t0; dbg_store += t2 - t1; dbg_bar += __builtin_amdgcn_s_memtime() - t2; }
         }
-        __syncthreads();        // matches the consumers' barrier after the last chunk
+        if (p.stamps && lane == 0) {
+            unsigned long long* d = p.stamps + ((size_t)blockIdx.x * 8 + wave8) * 16;
+            d[9] = dbg_mem; d[10] = dbg_store; d[11] = dbg_bar; d[12] = dbg_issue; d[13] = dbg_dma;
+        }
     } else {
         // =========================================== CONSUMERS ===========================================
         int abase[MT];
@@ -182,12 +272,13 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvDev p) {
         }
         const int bbase = half * BN + wn * NT * 32 + l31;
         const int kk0 = wk * KPW;
+        unsigned long long dbg_cbar = 0;
         conv_stamp(p, 1);
         __syncthreads();        // stage 0 ready
         conv_stamp(p, 4);
         for (int i = 0; i < nchunks; ++i) {
             const float* patch = patch0 + (i & 1) * p.patch_stride;
-            const float* wl = wl0 + (i & 1) * p.wl_stride + bbase;
+            const float* wl = wl0 + (i % p.nwb) * p.wl_stride + bbase;
 #pragma unroll
             for (int tap = 0; tap < KK; ++tap) {
                 const int tapoff = ((tap / KS) * PW + (tap % KS)) * CS;
@@ -223,8 +314,11 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvDev p) {
                             accr[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], accr[mt][nt], 0, 0, 0);
                 }
             }
+            unsigned long long t0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
             __syncthreads();    // stage i consumed; stage i+1 (if any) ready
+            if (p.stamps) dbg_cbar += __builtin_amdgcn_s_memtime() - t0;
         }
+        if (p.stamps && lane == 0) p.stamps[((size_t)blockIdx.x * 8 + wave8) * 16 + 11] = dbg_cbar;
         conv_stamp(p, 5);
     }
     conv_epilogue<WM, WN, WK, MT, NT>(p, acc, accr, smem, tid, lane, wave, b0, y0, x0, n0, tx, ty, consumer, 512);

@@ -8,6 +8,24 @@ namespace fc {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
+// y[j] = bias[j] + sum_i x[i] * wt[i][j] for one output column j; 4 accumulators x 4-deep unroll keep 16 independent
+// (coalesced across threads) weight loads in flight -- this kernel is pure latency, its weights arrive cold from HBM.
+__device__ __forceinline__ float matvec_col(const float* __restrict__ x, const float* __restrict__ wt, int n_in, int ld, int j, float bias) {
+    float s0 = bias, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = 0;
+    for (; i + 16 <= n_in; i += 16) {
+        float w[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) w[u] = wt[(size_t)(i + u) * ld + j];
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) {
+            s0 += x[i + u] * w[u]; s1 += x[i + u + 1] * w[u + 1]; s2 += x[i + u + 2] * w[u + 2]; s3 += x[i + u + 3] * w[u + 3];
+        }
+    }
+    for (; i < n_in; ++i) s0 += x[i] * wt[(size_t)i * ld + j];
+    return (s0 + s1) + (s2 + s3);
+}
+
 // grid (B), 256 threads
 __global__ void __launch_bounds__(256) temb_kernel(const TembArgs a) {
     extern __shared__ float sm[];   // e[dim] | h[td] | c0[td] | c1[td]
@@ -28,28 +46,17 @@ __global__ void __launch_bounds__(256) temb_kernel(const TembArgs a) {
     if (cid >= a.n_classes) cid = -1;
     __syncthreads();
     for (int j = tid; j < a.td; j += 256) {
-        float s = a.b1[j];
-        for (int i = 0; i < a.dim; ++i) s += e[i] * a.w1t[(size_t)i * a.td + j];
-        h[j] = gelu_erf(s);
+        h[j] = gelu_erf(matvec_col(e, a.w1t, a.dim, a.td, j, a.b1[j]));
         if (cid >= 0) c0[j] = a.emb[(size_t)cid * a.td + j];
     }
     __syncthreads();
     if (cid >= 0) {
-        for (int j = tid; j < a.td; j += 256) {
-            float s = a.cb1[j];
-            for (int i = 0; i < a.td; ++i) s += c0[i] * a.cw1t[(size_t)i * a.td + j];
-            c1[j] = gelu_erf(s);
-        }
+        for (int j = tid; j < a.td; j += 256) c1[j] = gelu_erf(matvec_col(c0, a.cw1t, a.td, a.td, j, a.cb1[j]));
     }
     __syncthreads();
     for (int j = tid; j < a.td; j += 256) {
-        float s = a.b2[j];
-        for (int i = 0; i < a.td; ++i) s += h[i] * a.w2t[(size_t)i * a.td + j];
-        if (cid >= 0) {
-            float c = a.cb2[j];
-            for (int i = 0; i < a.td; ++i) c += c1[i] * a.cw2t[(size_t)i * a.td + j];
-            s += c;
-        }
+        float s = matvec_col(h, a.w2t, a.td, a.td, j, a.b2[j]);
+        if (cid >= 0) s += matvec_col(c1, a.cw2t, a.td, a.td, j, a.cb2[j]);
         a.t_out[(size_t)b * a.td + j] = s;
     }
 }
@@ -71,9 +78,7 @@ __global__ void __launch_bounds__(256) ss_kernel(const float* t, const float* wt
     }
     __syncthreads();
     if (j >= S) return;
-    float s = bias[j];
-    for (int i = 0; i < td; ++i) s += st[i] * wt[(size_t)i * S + j];
-    ss[(size_t)b * S + j] = s;
+    ss[(size_t)b * S + j] = matvec_col(st, wt, td, S, j, bias[j]);
 }
 
 int ss_launch(const float* t, const float* wt, const float* bias, float* ss, int B, int td, int S, hipStream_t s) {

@@ -46,6 +46,17 @@ struct FwdCtx {             // per-call inputs of one U-Net forward
 };
 using Op = std::function<int(const FwdCtx&, hipStream_t)>;
 
+struct Plan {                 // one launch plan + activation arena for up to maxB rows of HxW latents
+    int maxB = 0, H = 0, W = 0;
+    std::vector<Op> ops;
+    std::vector<std::string> op_kernel, op_what;  // parallel to ops: kernel family, reference module it serves
+    std::vector<double> op_flops;                  // algorithmic FLOPs per sample of that launch
+    std::vector<void*> allocs;
+    double flops = 0.0;
+    float *t_emb = nullptr, *ss = nullptr;
+    std::map<std::string, Act> named;              // debug taps: block outputs by reference module name
+};
+
 struct PackOp { int kind; int64_t src, dst; int a, b, c, d; };  // kind 0 conv OIHW, 1 s2d, 2 transpose(R=a,Cc=b,ld=c,col0=d), 3 copy(a)
 
 }  // namespace fc
@@ -68,15 +79,13 @@ struct fc_unet {
     float* freqs = nullptr;
     bool loaded = false;
 
-    // plan
-    int maxB = 0, H = 0, W = 0;
-    std::vector<Op> ops;
-    std::vector<std::string> op_kernel, op_what;  // parallel to ops: kernel family, reference module it serves
-    std::vector<double> op_flops;                  // algorithmic FLOPs per sample of that launch
-    std::vector<void*> allocs;
-    double flops = 0.0;
-    float *t_emb = nullptr, *ss = nullptr;
-    std::map<std::string, fc::Act> named;   // debug taps: block outputs by reference module name
+    // plans: the batch can run as `nchains` independent row ranges on concurrent streams (no cross-sample op exists in the
+    // network; FLOCODER_AMD_CHAINS=2).  Off by default: half-batch launches lose more than the overlap wins on one GPU.
+    int maxB = 0, H = 0, W = 0, nchains = 1;
+    fc::Plan plan[2];
+    std::vector<void*> int_allocs;           // integrator state
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
     // integrator state (library-owned so captured graphs never see caller pointers)
     hipStream_t stream = nullptr;
@@ -231,22 +240,23 @@ static const char* kTileNames[] = {"conv_igemm<M128,N32>", "conv_igemm<M128,N64>
 
 struct Builder {
     fc_unet* u;
+    Plan* pl;
     int B;  // max batch
     int err = FC_OK;
     std::string scope;  // reference module the ops being emitted belong to
 
     void push(Op op, const std::string& kernel, double flops = 0.0) {
-        u->ops.push_back(std::move(op));
-        u->op_kernel.push_back(kernel);
-        u->op_what.push_back(scope);
-        u->op_flops.push_back(flops);
-        u->flops += flops;
+        pl->ops.push_back(std::move(op));
+        pl->op_kernel.push_back(kernel);
+        pl->op_what.push_back(scope);
+        pl->op_flops.push_back(flops);
+        pl->flops += flops;
     }
 
     float* dmalloc(size_t floats) {
         void* p = nullptr;
         if (hipMalloc(&p, (floats ? floats : 1) * sizeof(float)) != hipSuccess) { err = fail(FC_E_HIP, "hipMalloc failed while reserving the arena"); return nullptr; }
-        u->allocs.push_back(p);
+        pl->allocs.push_back(p);
         return static_cast<float*>(p);
     }
     Act act(int C, int H, int W) { Act a; a.C = C; a.H = H; a.W = W; a.p = dmalloc((size_t)B * H * W * C); return a; }
@@ -299,7 +309,7 @@ struct Builder {
         conv(a, h1, G, &st1);
         ConvArgs b;
         b.s0.p = h1.p; b.s0.C = cout;
-        b.s0.xf = xf_of(st1, 2, u->R(p + ".block1.norm.weight"), u->R(p + ".block1.norm.bias"), u->ss + u->ss_off.at(p), u->S);
+        b.s0.xf = xf_of(st1, 2, u->R(p + ".block1.norm.weight"), u->R(p + ".block1.norm.bias"), pl->ss + u->ss_off.at(p), u->S);
         b.Hs = x.H; b.Ws = x.W; b.KS = 3; b.pad = 1;
         b.w = u->P(p + ".block2.proj.weight"); b.bias = u->R(p + ".block2.proj.bias");
         conv(b, h2, G, &st2);
@@ -312,7 +322,7 @@ struct Builder {
             f.stats_out = gn1->p;
         }
         if (!err) push([f](const FwdCtx& c, hipStream_t s) { FinalizeArgs g = f; g.B = c.B; return finalize_launch(g, s); }, "finalize");
-        u->named[p] = out; u->named[p + ".h1"] = h1; u->named[p + ".h2"] = h2;
+        pl->named[p] = out; pl->named[p + ".h1"] = h1; pl->named[p + ".h2"] = h2;
         return out;
     }
 
@@ -342,7 +352,7 @@ struct Builder {
         f.h = yb.p; f.xf = xf_of(sty, 1, u->R(p + ".fn.fn.to_out.1.weight"), u->R(p + ".fn.fn.to_out.1.bias"));
         f.res = x.p; f.y = out.p; f.HW = n; f.C = x.C;
         if (!err) push([f](const FwdCtx& c, hipStream_t s) { FinalizeArgs g = f; g.B = c.B; return finalize_launch(g, s); }, "finalize");
-        u->named[p] = out; u->named[p + ".qkv"] = qkv; u->named[p + ".lao"] = lao; u->named[p + ".y"] = yb;
+        pl->named[p] = out; pl->named[p + ".qkv"] = qkv; pl->named[p + ".lao"] = lao; pl->named[p + ".y"] = yb;
         return out;
     }
 
@@ -365,7 +375,7 @@ struct Builder {
         o.w = u->P("mid_attn.fn.fn.to_out.weight"); o.bias = u->R("mid_attn.fn.fn.to_out.bias");
         o.add = x.p;
         conv(o, out, 0, nullptr);
-        u->named["mid_attn"] = out;
+        pl->named["mid_attn"] = out;
         return out;
     }
 
@@ -398,25 +408,25 @@ struct Builder {
 static void free_plan(fc_unet* u) {
     for (auto& kv : u->graphs) (void)hipGraphExecDestroy(kv.second);
     u->graphs.clear();
-    for (void* p : u->allocs) (void)hipFree(p);
-    u->allocs.clear();
-    u->named.clear();
-    u->op_kernel.clear(); u->op_what.clear(); u->op_flops.clear();
-    u->ops.clear();
+    for (Plan& pln : u->plan) {
+        for (void* p : pln.allocs) (void)hipFree(p);
+        pln = Plan();
+    }
+    for (void* p : u->int_allocs) (void)hipFree(p);
+    u->int_allocs.clear();
     u->maxB = 0;
 }
 
-static int build_plan(fc_unet* u, int maxB, int H, int W) {
-    free_plan(u);
+static int build_plan(fc_unet* u, Plan* pl, int maxB, int H, int W) {
     const fc_unet_config& c = u->cfg;
     const int L = c.n_levels, dim = c.dim, ch = c.channels, HW = H * W;
     if (!is_pow2(H) || !is_pow2(W) || (H >> (L - 1)) < 1 || (W >> (L - 1)) < 1)
         return fail(FC_E_SHAPE, "unet: latent height/width must be powers of two >= 2^(levels-1)");
     if ((ch & 3) || (dim & 3)) return fail(FC_E_SHAPE, "unet: channels and dim must be multiples of 4");
-    Builder b{u, maxB};
-    u->flops = 0.0;
-    u->t_emb = b.dmalloc((size_t)maxB * u->td);
-    u->ss = b.dmalloc((size_t)maxB * u->S);
+    Builder b{u, pl, maxB};
+    pl->flops = 0.0;
+    pl->t_emb = b.dmalloc((size_t)maxB * u->td);
+    pl->ss = b.dmalloc((size_t)maxB * u->S);
     const std::vector<int>& cs = u->chans;
     const int td = u->td, S = u->S, ncls = c.n_classes;
 
@@ -432,21 +442,21 @@ static int build_plan(fc_unet* u, int maxB, int H, int W) {
             t.cw1t = u->P("class_cond_mlp.1.weight"); t.cb1 = u->R("class_cond_mlp.1.bias");
             t.cw2t = u->P("class_cond_mlp.3.weight"); t.cb2 = u->R("class_cond_mlp.3.bias");
         }
-        t.n_classes = ncls; t.t_out = u->t_emb; t.dim = dim; t.td = td;
+        t.n_classes = ncls; t.t_out = pl->t_emb; t.dim = dim; t.td = td;
         b.scope = "time_mlp";
         b.push([t](const FwdCtx& cx, hipStream_t s) {
             TembArgs a = t; a.B = cx.B; a.time = cx.time; a.class_ids = cx.ids; a.class_batch_mod = cx.ids_mod; a.null_from = cx.null_from;
             return temb_launch(a, s);
         }, "temb", 2.0 * ((double)dim * td + (double)td * td * (ncls > 0 ? 3 : 1)));
-        const float *te = u->t_emb, *wt = u->P("__ss_wt"), *sb = u->P("__ss_bias");
-        float* ss = u->ss;
+        const float *te = pl->t_emb, *wt = u->P("__ss_wt"), *sb = u->P("__ss_bias");
+        float* ss = pl->ss;
         b.scope = "resblock.mlp";
         b.push([=](const FwdCtx& cx, hipStream_t s) { return ss_launch(te, wt, sb, ss, cx.B, td, S, s); }, "ss", 2.0 * (double)td * S);
     }
 
     // -- init_conv (unet.py:295) and mask fusion (unet.py:298-305) --
     Act x0 = b.act(dim, H, W);
-    u->named["init"] = x0;
+    pl->named["init"] = x0;
     Act mask_nhwc;
     {
         const float *w = u->P("init_conv.weight"), *bias = u->R("init_conv.bias");
@@ -510,13 +520,13 @@ static int build_plan(fc_unet* u, int maxB, int H, int W) {
             Act o = b.act(cs[i + 1], x.H, x.W);
             b.conv(a, o, 0, nullptr);
             x = o;
-            u->named[p + ".3"] = o;
+            pl->named[p + ".3"] = o;
         } else {
             a.KS = 2; a.pad = 0; a.stride = 2; a.w = u->P(p + ".3.1.weight"); a.bias = u->R(p + ".3.1.bias");
             Act o = b.act(cs[i + 1], x.H / 2, x.W / 2);
             b.conv(a, o, 0, nullptr);
             x = o;
-            u->named[p + ".3"] = o;
+            pl->named[p + ".3"] = o;
         }
     }
     // -- bottleneck (unet.py:345-347) --
@@ -551,7 +561,7 @@ static int build_plan(fc_unet* u, int maxB, int H, int W) {
             b.conv(a, o, 0, nullptr);
             x = o;
         }
-        u->named[p + ".3"] = x;
+        pl->named[p + ".3"] = x;
     }
     if (b.err) return b.err;
     // -- head (unet.py:369-372) --
@@ -562,22 +572,72 @@ static int build_plan(fc_unet* u, int maxB, int H, int W) {
         b.scope = "final_conv";
         b.push([=](const FwdCtx& cx, hipStream_t s) { return final_conv_launch(xp, w, bias, cx.out, cx.B, dim, HW, ch, s); }, "final_conv", 2.0 * HW * dim * ch);
     }
-    // -- integrator state --
-    const size_t nstate = (size_t)maxB * ch * HW;
-    u->y = b.dmalloc(nstate); u->xs = b.dmalloc(nstate);
-    u->k1 = b.dmalloc(nstate); u->k2 = b.dmalloc(nstate); u->k3 = b.dmalloc(nstate);
-    u->v2 = b.dmalloc(nstate); u->mask_own = b.dmalloc(nstate);
-    u->tvec = b.dmalloc(maxB);
-    u->sc = b.dmalloc(4);
-    u->step = reinterpret_cast<int*>(b.dmalloc(4));
-    u->ids_own = reinterpret_cast<int64_t*>(b.dmalloc(2 * (size_t)maxB));
     if (b.err) return b.err;
-    u->maxB = maxB; u->H = H; u->W = W;
+    pl->maxB = maxB; pl->H = H; pl->W = W;
     return FC_OK;
 }
 
+// integrator state for `rows` U-Net rows (library-owned so captured graphs never see caller pointers)
+static int alloc_integrator(fc_unet* u, int rows, int H, int W) {
+    const size_t nstate = (size_t)rows * u->cfg.channels * H * W;
+    auto get = [&](size_t floats, float** out) -> int {
+        void* p = nullptr;
+        FC_HIP(hipMalloc(&p, (floats ? floats : 1) * sizeof(float)));
+        u->int_allocs.push_back(p);
+        *out = static_cast<float*>(p);
+        return FC_OK;
+    };
+    float* tmp = nullptr;
+    FC_TRY(get(nstate, &u->y)); FC_TRY(get(nstate, &u->xs));
+    FC_TRY(get(nstate, &u->k1)); FC_TRY(get(nstate, &u->k2)); FC_TRY(get(nstate, &u->k3));
+    FC_TRY(get(nstate, &u->v2)); FC_TRY(get(nstate, &u->mask_own));
+    FC_TRY(get(rows, &u->tvec));
+    FC_TRY(get(4, &u->sc));
+    FC_TRY(get(4, &tmp)); u->step = reinterpret_cast<int*>(tmp);
+    FC_TRY(get(2 * (size_t)rows, &tmp)); u->ids_own = reinterpret_cast<int64_t*>(tmp);
+    return FC_OK;
+}
+
+static int run_plan(const Plan& pl, const FwdCtx& c, hipStream_t s) {
+    for (const Op& op : pl.ops) FC_TRY(op(c, s));
+    return FC_OK;
+}
+
+// Rows [r0, r0 + n) of the caller's batch as a context of their own (row r reads sample r % x_mod, class id r % ids_mod,
+// no class at all from row null_from on -- the CFG layout of fc_unet_integrate).
+static FwdCtx slice_ctx(const FwdCtx& c, int r0, int n, size_t sample_floats) {
+    FwdCtx k = c;
+    k.B = n;
+    k.time = c.time + r0;
+    k.out = c.out + (size_t)r0 * sample_floats;
+    const int xs = r0 % c.x_mod;                 // first sample this slice reads
+    k.x = c.x + (size_t)xs * sample_floats;
+    if (c.mask) k.mask = c.mask + (size_t)xs * sample_floats;
+    k.x_mod = c.x_mod - xs;
+    if (c.ids) {
+        if (c.null_from > 0 && r0 >= c.null_from) { k.ids = nullptr; k.null_from = 0; }
+        else {
+            const int is = r0 % c.ids_mod;
+            k.ids = c.ids + is;
+            k.ids_mod = c.ids_mod - is;
+            k.null_from = c.null_from > 0 ? c.null_from - r0 : 0;
+        }
+    }
+    return k;
+}
+
 static int run_forward(fc_unet* u, const FwdCtx& c, hipStream_t s) {
-    for (const Op& op : u->ops) FC_TRY(op(c, s));
+    if (u->nchains < 2 || c.B < 2) return run_plan(u->plan[0], c, s);
+    // two chains: with CFG the conditional and the unconditional rows, otherwise the two halves of the batch
+    const int r0 = (c.null_from > 0 && c.null_from < c.B) ? c.null_from : (c.B + 1) / 2;
+    if (r0 > u->plan[0].maxB || c.B - r0 > u->plan[1].maxB) return fail(FC_E_STATE, "unet: chain plans too small for this batch");
+    const size_t sf = (size_t)u->cfg.channels * u->H * u->W;
+    FC_HIP(hipEventRecord(u->ev_fork, s));
+    FC_HIP(hipStreamWaitEvent(u->stream2, u->ev_fork, 0));
+    FC_TRY(run_plan(u->plan[1], slice_ctx(c, r0, c.B - r0, sf), u->stream2));
+    FC_HIP(hipEventRecord(u->ev_join, u->stream2));
+    FC_TRY(run_plan(u->plan[0], slice_ctx(c, 0, r0, sf), s));
+    FC_HIP(hipStreamWaitEvent(s, u->ev_join, 0));
     return FC_OK;
 }
 
@@ -627,6 +687,9 @@ int fc_unet_create(const fc_unet_config* cfg, int device, fc_unet** out) {
     FC_HIP(hipStreamCreateWithFlags(&u->stream, hipStreamNonBlocking));
     FC_HIP(hipEventCreateWithFlags(&u->ev_in, hipEventDisableTiming));
     FC_HIP(hipEventCreateWithFlags(&u->ev_out, hipEventDisableTiming));
+    FC_HIP(hipStreamCreateWithFlags(&u->stream2, hipStreamNonBlocking));
+    FC_HIP(hipEventCreateWithFlags(&u->ev_fork, hipEventDisableTiming));
+    FC_HIP(hipEventCreateWithFlags(&u->ev_join, hipEventDisableTiming));
     *out = u.release();
     return FC_OK;
 }
@@ -644,6 +707,9 @@ void fc_unet_destroy(fc_unet* u) {
     if (u->stream) (void)hipStreamDestroy(u->stream);
     if (u->ev_in) (void)hipEventDestroy(u->ev_in);
     if (u->ev_out) (void)hipEventDestroy(u->ev_out);
+    if (u->stream2) (void)hipStreamDestroy(u->stream2);
+    if (u->ev_fork) (void)hipEventDestroy(u->ev_fork);
+    if (u->ev_join) (void)hipEventDestroy(u->ev_join);
     delete u;
 }
 
@@ -685,9 +751,16 @@ int fc_unet_reserve(fc_unet* u, int max_batch, int height, int width) {
     if (u->maxB >= max_batch && u->H == height && u->W == width) return FC_OK;
     FC_HIP(hipSetDevice(u->device));
     FC_HIP(hipDeviceSynchronize());
-    const int r = build_plan(u, max_batch, height, width);
-    if (r != FC_OK) free_plan(u);
-    return r;
+    free_plan(u);
+    static const int want_chains = [] { const char* e = std::getenv("FLOCODER_AMD_CHAINS"); return e ? std::atoi(e) : 1; }();   // measured: 2 half-batch chains 404 vs 1 chain 446 samples/s (profiles/r01_c_*)
+    u->nchains = (want_chains >= 2 && max_batch >= 2) ? 2 : 1;
+    const int rows0 = u->nchains == 2 ? (max_batch + 1) / 2 : max_batch;
+    int r = build_plan(u, &u->plan[0], rows0, height, width);
+    if (r == FC_OK && u->nchains == 2) r = build_plan(u, &u->plan[1], rows0, height, width);
+    if (r == FC_OK) r = alloc_integrator(u, max_batch, height, width);
+    if (r != FC_OK) { free_plan(u); return r; }
+    u->maxB = max_batch; u->H = height; u->W = width;
+    return FC_OK;
 }
 
 static int check_ready(const fc_unet* u, int rows, int H, int W) {
@@ -717,19 +790,21 @@ int fc_unet_forward(fc_unet* u, const float* x, const float* time, const int64_t
 int fc_unet_profile_ops(fc_unet* u, int batch, int repeats, float* ms_out, int n_out, void* stream) {
     if (!u || !ms_out || repeats < 1) return fail(FC_E_ARG, "fc_unet_profile_ops: bad argument");
     FC_TRY(check_ready(u, batch, u->H, u->W));
-    const int n = (int)u->ops.size();
+    const Plan& pl0 = u->plan[0];
+    if (batch > pl0.maxB) batch = pl0.maxB;   // ops are timed on chain 0's plan, at the rows one chain carries
+    const int n = (int)pl0.ops.size();
     if (n_out < n) return fail(FC_E_ARG, "fc_unet_profile_ops: output array too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     FwdCtx c;
     c.x = u->y; c.x_mod = batch; c.time = u->tvec; c.ids = nullptr; c.ids_mod = batch; c.out = u->v2; c.B = batch;
     FC_HIP(hipMemsetAsync(u->tvec, 0, batch * sizeof(float), s));
-    FC_TRY(run_forward(u, c, s));  // warm: every buffer holds finite data
+    FC_TRY(run_plan(pl0, c, s));  // warm: every buffer holds finite data
     std::vector<hipEvent_t> ev(2 * n);
     for (auto& e : ev) FC_HIP(hipEventCreate(&e));
     int rc = FC_OK;
     for (int i = 0; i < n && rc == FC_OK; ++i) {
         (void)hipEventRecord(ev[2 * i], s);
-        for (int r = 0; r < repeats && rc == FC_OK; ++r) rc = u->ops[i](c, s);
+        for (int r = 0; r < repeats && rc == FC_OK; ++r) rc = pl0.ops[i](c, s);
         (void)hipEventRecord(ev[2 * i + 1], s);
     }
     (void)hipStreamSynchronize(s);
@@ -743,15 +818,21 @@ int fc_unet_profile_ops(fc_unet* u, int batch, int repeats, float* ms_out, int n
 }
 
 int fc_unet_op_info(const fc_unet* u, int i, const char** kernel, const char** module, double* flops_per_sample) {
-    if (!u || i < 0 || i >= (int)u->ops.size()) return fail(FC_E_ARG, "fc_unet_op_info: index out of range");
-    if (kernel) *kernel = u->op_kernel[i].c_str();
-    if (module) *module = u->op_what[i].c_str();
-    if (flops_per_sample) *flops_per_sample = u->op_flops[i];
+    if (!u || i < 0 || i >= (int)u->plan[0].ops.size()) return fail(FC_E_ARG, "fc_unet_op_info: index out of range");
+    if (kernel) *kernel = u->plan[0].op_kernel[i].c_str();
+    if (module) *module = u->plan[0].op_what[i].c_str();
+    if (flops_per_sample) *flops_per_sample = u->plan[0].op_flops[i];
     return FC_OK;
 }
 
-int fc_unet_plan_launches(const fc_unet* u) { return u ? (int)u->ops.size() : 0; }
-double fc_unet_flops_per_sample(const fc_unet* u) { return u ? u->flops : 0.0; }
+int fc_unet_chains(const fc_unet* u, int* rows_per_chain) {
+    if (!u) return 0;
+    if (rows_per_chain) *rows_per_chain = u->plan[0].maxB;
+    return u->nchains;
+}
+
+int fc_unet_plan_launches(const fc_unet* u) { return u ? (int)u->plan[0].ops.size() : 0; }
+double fc_unet_flops_per_sample(const fc_unet* u) { return u ? u->plan[0].flops : 0.0; }
 
 // -------------------------------------------------------------------------------- integrator
 static uint32_t fbits(float f) { uint32_t v; std::memcpy(&v, &f, 4); return v; }
@@ -842,8 +923,8 @@ int fc_unet_integrate(fc_unet* u, int method, float* x_dev, int B, int H, int W,
 // ---- debug / test hooks --------------------------------------------------------------------------
 int fc_unet_debug_tensor(const fc_unet* u, const char* name, const float** ptr, int* C, int* H, int* W) {
     if (!u || !name) return fail(FC_E_ARG, "fc_unet_debug_tensor: null argument");
-    auto it = u->named.find(name);
-    if (it == u->named.end()) return fail(FC_E_ARG, std::string("fc_unet_debug_tensor: no tap named ") + name);
+    auto it = u->plan[0].named.find(name);   // chain 0 = the first rows of the batch
+    if (it == u->plan[0].named.end()) return fail(FC_E_ARG, std::string("fc_unet_debug_tensor: no tap named ") + name);
     *ptr = it->second.p; *C = it->second.C; *H = it->second.H; *W = it->second.W;
     return FC_OK;
 }

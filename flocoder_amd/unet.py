@@ -164,6 +164,13 @@ class Unet(nn.Module):
         return float(B.lib().fc_unet_flops_per_sample(self._handle)) if self._handle else 0.0
 
     @property
+    def chains(self):
+        """(number of concurrent row-range chains, rows per chain) of the current plan."""
+        rows = C.c_int(0)
+        n = B.lib().fc_unet_chains(self._handle, C.byref(rows)) if self._handle else 0
+        return n, rows.value
+
+    @property
     def launches_per_forward(self) -> int:
         return int(B.lib().fc_unet_plan_launches(self._handle)) if self._handle else 0
 
@@ -244,6 +251,9 @@ class Unet(nn.Module):
         """Per-launch device time of the current plan (bench.py's live roofline measurement).  Run a forward or an
         integration first so the internal state holds finite data.  Returns a list of dicts."""
         lib, h = B.lib(), self._handle
+        rows = C.c_int(0)
+        lib.fc_unet_chains(h, C.byref(rows))
+        batch = min(batch, rows.value)                 # launches are timed at the rows one chain carries
         n = lib.fc_unet_plan_launches(h)
         ms = (C.c_float * n)()
         dev = self._handle_device
@@ -252,7 +262,7 @@ class Unet(nn.Module):
         for i in range(n):
             k, m, f = C.c_char_p(), C.c_char_p(), C.c_double()
             B.check(lib.fc_unet_op_info(h, i, C.byref(k), C.byref(m), C.byref(f)))
-            out.append(dict(kernel=k.value.decode(), module=m.value.decode(), flops_per_sample=f.value, ms=float(ms[i])))
+            out.append(dict(kernel=k.value.decode(), module=m.value.decode(), flops_per_sample=f.value, ms=float(ms[i]), rows=batch))
         return out
 
     def debug_tensor(self, name: str) -> torch.Tensor:

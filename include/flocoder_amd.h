@@ -103,12 +103,16 @@ int fc_unet_integrate(fc_unet* u, int method, float* x_dev, int batch, int heigh
 
 /* Number of kernel launches in one U-Net forward of the current plan, and its algorithmic FLOPs per
  * sample (2 x MACs over every conv / linear / attention contraction). */
+/* The reserved batch runs as this many independent row ranges ("chains") on concurrent streams; *rows_per_chain = the rows
+ * each chain's plan holds (= the batch every kernel launch of that chain sees). */
+int fc_unet_chains(const fc_unet* u, int* rows_per_chain);
 int fc_unet_plan_launches(const fc_unet* u);
 double fc_unet_flops_per_sample(const fc_unet* u);
 /* Launch i of the plan: kernel family, the reference module it implements, its algorithmic FLOPs per sample. */
 int fc_unet_op_info(const fc_unet* u, int i, const char** kernel, const char** module, double* flops_per_sample);
 /* Measurement hook for bench.py: average device milliseconds of every launch of the plan at `batch` rows, each
- * timed alone with HIP events on `stream` over `repeats` back-to-back launches.  Synchronises. */
+ * timed alone with HIP events on `stream` over `repeats` back-to-back launches (`batch` is clamped to the rows of one
+ * chain, see fc_unet_chains).  Synchronises. */
 int fc_unet_profile_ops(fc_unet* u, int batch, int repeats, float* ms_out, int n_out, void* stream);
 
 /* The sinusoidal frequency table exp(-k ln(1e4)/(dim/2-1)) (unet.py:26-27).  The library builds it in double

@@ -37,6 +37,8 @@ def gn_ref(y, groups):
     (3, 12, 16, 8, 8, 5, 2),
     (2, 8, 8, 2, 2, 3, 1),
     (9, 16, 32, 1, 1, 3, 1),
+    (5, 32, 96, 1, 1, 1, 0),
+    (3, 64, 32, 2, 2, 1, 0),
 ])
 def test_conv_tiles(tile, shape):
     from flocoder_amd._ops import conv_debug

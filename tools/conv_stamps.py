@@ -31,5 +31,7 @@ for name, c0, c1, co, H, ks, pad, stride, ups, G in LAYERS:
     for role, sl in (("consumer", slice(0, 4)), ("loader", slice(4, 8))):
         med = rel[:, sl].median(dim=0).values.median(dim=0).values
         print(f"   {role:8s} median timeline (cycles since wave start): " + ", ".join(f"{n}={int(v)}" for n, v in zip(NAMES, med.tolist())))
+    print(f"   consumer cycles at chunk barriers (sum): {int(st[:, 0:4, 11].median())};  loader: vmcnt-wait {int(st[:, 4:8, 9].median())}, "
+          f"LDS stores {int(st[:, 4:8, 10].median())}, barrier {int(st[:, 4:8, 11].median())}, patch issue {int(st[:, 4:8, 12].median())}, dma issue {int(st[:, 4:8, 13].median())}")
     span = (st[:, :, 8].max(dim=1).values - st[:, :, 0].min(dim=1).values)
     print(f"   workgroup lifetime: median {int(span.median())} cycles, max {int(span.max())}")
