@@ -50,6 +50,18 @@ SIGNATURES = {
     "fc_debug_copy": (_i, [_vp, _vp, _i64, _vp]),
     "fc_debug_set_conv_stamps": (_i, [_vp]),
     "fc_debug_conv": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _pi, _pf, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _pf, _vp]),
+    "fc_vae_create": (_i, [_i, C.POINTER(_vp)]),
+    "fc_vae_destroy": (None, [_vp]),
+    "fc_vae_param_count": (_i, [_vp]),
+    "fc_vae_param_numel": (_i64, [_vp]),
+    "fc_vae_param_info": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_i64 * 4), C.POINTER(_i64)]),
+    "fc_vae_load_params": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "fc_vae_reserve_encode": (_i, [_vp, _i, _i, _i]),
+    "fc_vae_reserve_decode": (_i, [_vp, _i, _i, _i]),
+    "fc_vae_encode": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "fc_vae_decode": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "fc_vae_flops_per_sample": (C.c_double, [_vp, _i]),
+    "fc_vae_plan_launches": (_i, [_vp, _i]),
     "fc_ot_pairing": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _vp]),
 }
 

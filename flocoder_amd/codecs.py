@@ -1,0 +1,274 @@
+"""Codec plugin API: host-side mirror of ``flocoder/codecs.py``'s factory and codec wrappers (codecs.py:578-741).
+
+``setup_codec(config, device, no_natten=False, load_checkpoint=True, eval=True)`` returns an object with the protocol the
+flow path consumes: ``encode(x) -> z``, ``decode(z, orig_size=None, noise_strength=0.0) -> x``,
+``forward(x, noise_strength, minval, get_stats)``, ``in_channels``, ``parameters()``.  The SD codec runs on the gfx950
+library (``fc_vae_*``); there is no CPU path for it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _binding as B
+from .general import ldcfg
+
+
+class SimpleResizeAE(nn.Module):
+    """codecs.py:578-619 -- interpolation 'codec' (encode: resize to latent_shape, extra channels = channel mean)."""
+
+    def __init__(self, in_channels=3, latent_shape=(4, 16, 16), mode='bicubic'):
+        super().__init__()
+        self.in_channels, self.latent_shape, self.orig_shape, self.mode = in_channels, latent_shape, None, mode
+
+    def encode(self, x):
+        self.orig_shape = x.shape[1:]
+        if self.latent_shape is None or self.orig_shape == self.latent_shape:
+            return x
+        c, h, w = self.latent_shape
+        small = F.interpolate(x, size=(h, w), mode=self.mode, align_corners=False)
+        if c == x.shape[-3]:
+            return small
+        return torch.cat([small, small.mean(dim=1, keepdim=True).repeat(1, c - x.shape[-3], 1, 1)], dim=1)
+
+    def decode(self, z, orig_shape=None, noise_strength=0.0):
+        target = orig_shape if orig_shape is not None else self.orig_shape
+        if self.latent_shape is None or target is None or target == self.latent_shape:
+            return z
+        return F.interpolate(z[:, :3], size=(target[-2], target[-1]), mode=self.mode, align_corners=False)
+
+    def forward(self, x, noise_strength=0.0, minval=0, get_stats=False):
+        recon = self.decode(self.encode(x))
+        return (recon, 0.0, {'codebook_mean_dist': 0.0, 'codebook_max_dist': 0.0}) if get_stats else (recon, 0.0)
+
+
+class NoOpAE(SimpleResizeAE):
+    """codecs.py:621-627.  As upstream, the parent constructor resets latent_shape to (4,16,16), so 'noop' resizes
+     -- kept, because checkpoints trained against that behaviour expect it."""
+
+    def __init__(self):
+        self.latent_shape = None
+        super().__init__()
+
+
+# legacy (pre-0.14 diffusers) attention parameter names still present in the published sd-vae-ft-mse checkpoint
+_LEGACY = {".query.": ".to_q.", ".key.": ".to_k.", ".value.": ".to_v.", ".proj_attn.": ".to_out.0."}
+
+
+def vae_param_table():
+    """(name, shape, offset) of the native AutoencoderKL parameter table (no GPU needed)."""
+    lib = B.lib()
+    h = C.c_void_p()
+    B.check(lib.fc_vae_create(-1, C.byref(h)))
+    try:
+        out = []
+        for i in range(lib.fc_vae_param_count(h)):
+            name, shape, off = C.c_char_p(), (C.c_int64 * 4)(), C.c_int64()
+            B.check(lib.fc_vae_param_info(h, i, C.byref(name), C.byref(shape), C.byref(off)))
+            out.append((name.value.decode(), tuple(int(s) for s in shape if s), int(off.value)))
+        return out, int(lib.fc_vae_param_numel(h))
+    finally:
+        lib.fc_vae_destroy(h)
+
+
+class _Node(nn.Module):
+    pass
+
+
+class SD_VAE_Wrapper(nn.Module):
+    """codecs.py:631-663 over the native AutoencoderKL.  Parameters live under ``self.vae.*`` with the upstream key names, so a
+    ``state_dict`` saved from the reference's wrapper loads here unchanged.
+
+    The reference calls ``AutoencoderKL.from_pretrained("stabilityai/sd-vae-ft-mse")`` (a network fetch).  Here weights come from a
+    LOCAL copy: ``weights`` = a state_dict, a ``.safetensors`` / ``.pt`` file, or a directory holding
+    ``diffusion_pytorch_model.safetensors`` (also taken from ``$FLOCODER_SD_VAE_PATH``); ``weights="random"`` draws seeded random
+    weights (benchmarks / tests).  Without any of these it raises FileNotFoundError -- it never downloads."""
+
+    def __init__(self, pretrained_model_name="stabilityai/sd-vae-ft-mse", weights=None, seed: int = 0):
+        super().__init__()
+        self.in_channels = 3
+        self.pretrained_model_name = pretrained_model_name
+        self._table, self._flat_numel = vae_param_table()
+        self.vae = _Node()
+        for name, shape, _ in self._table:
+            node = self.vae
+            *path, leaf = name.split(".")
+            for part in path:
+                if not hasattr(node, part):
+                    node.add_module(part, _Node())
+                node = getattr(node, part)
+            node.register_parameter(leaf, nn.Parameter(torch.empty(shape, dtype=torch.float32), requires_grad=False))
+        self._handle, self._handle_device, self._synced = None, None, None
+        if weights is None:
+            weights = os.environ.get("FLOCODER_SD_VAE_PATH")
+        if weights is None:
+            raise FileNotFoundError(
+                f"SD_VAE_Wrapper: no local weights for '{pretrained_model_name}'. Pass weights=<dir|file|state_dict> or set "
+                "FLOCODER_SD_VAE_PATH (the reference downloads them; this build never touches the network).")
+        if isinstance(weights, str) and weights == "random":
+            self._init_random(seed)
+        else:
+            self.load_vae_state_dict(weights if isinstance(weights, dict) else _read_weights(weights))
+
+    # ---- weights
+    def _init_random(self, seed):
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for name, p in self.vae.named_parameters():
+                leaf = name.rsplit(".", 1)[1]
+                if p.dim() == 1:
+                    p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g) if leaf == "weight" else 0.05 * torch.randn(p.shape, generator=g))
+                else:
+                    p.copy_(torch.randn(p.shape, generator=g) * (1.0 / math.prod(p.shape[1:])) ** 0.5)
+
+    def load_vae_state_dict(self, sd: Dict[str, torch.Tensor]):
+        sd = dict(sd)
+        for k in list(sd):
+            nk = k[4:] if k.startswith("vae.") else k
+            for old, new in _LEGACY.items():
+                nk = nk.replace(old, new)
+            if nk != k:
+                sd[nk] = sd.pop(k)
+        own = dict(self.vae.named_parameters())
+        missing = [k for k in own if k not in sd]
+        if missing:
+            raise KeyError(f"SD-VAE weights are missing {len(missing)} tensors, e.g. {missing[:3]}")
+        with torch.no_grad():
+            for k, p in own.items():
+                p.copy_(sd[k].reshape(p.shape).to(p.dtype))      # legacy attention weights are [C,C,1,1]
+        self._synced = None
+
+    # ---- native object
+    def _native(self, device):
+        lib = B.lib()
+        if self._handle is None or self._handle_device != device:
+            self._release()
+            h = C.c_void_p()
+            B.check(lib.fc_vae_create(device.index or 0, C.byref(h)))
+            self._handle, self._handle_device, self._synced = h, device, None
+        ver = tuple((p.data_ptr(), p._version) for p in self.vae.parameters())
+        if ver != self._synced:
+            flat = torch.zeros(self._flat_numel, dtype=torch.float32, device=device)
+            sd = dict(self.vae.named_parameters())
+            for name, shape, off in self._table:
+                flat[off:off + math.prod(shape)] = sd[name].detach().reshape(-1).to(device)
+            B.check(lib.fc_vae_load_params(self._handle, flat.data_ptr(), flat.numel(), 1, B.current_stream(device)))
+            torch.cuda.current_stream(device).synchronize()
+            self._synced = ver
+        return self._handle
+
+    def _release(self):
+        if getattr(self, "_handle", None) is not None:
+            B.lib().fc_vae_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _need_gpu(t):
+        if not t.is_cuda:
+            raise RuntimeError("flocoder_amd.SD_VAE_Wrapper runs on MI355X (gfx950) only; there is no CPU path")
+
+    # ---- codec protocol
+    @torch.no_grad()
+    def encode(self, x):
+        """vae.encode(x).latent_dist.mean.detach() (codecs.py:639-642): deterministic, no 0.18215 scaling."""
+        self._need_gpu(x)
+        bsz, ch, h, w = x.shape
+        if ch != 3:
+            raise ValueError("SD-VAE expects 3-channel images")
+        x = x.contiguous().float()
+        hnd = self._native(x.device)
+        B.check(B.lib().fc_vae_reserve_encode(hnd, bsz, h, w))
+        out = torch.empty(bsz, 4, h // 8, w // 8, device=x.device, dtype=torch.float32)
+        B.check(B.lib().fc_vae_encode(hnd, B.ptr(x), B.ptr(out), bsz, h, w, B.current_stream(x.device)))
+        return out
+
+    @torch.no_grad()
+    def decode(self, z, orig_size=None, noise_strength=0.0):
+        """vae.decode(z).sample (codecs.py:649-652)."""
+        self._need_gpu(z)
+        bsz, ch, h, w = z.shape
+        if ch != 4:
+            raise ValueError("SD-VAE latents have 4 channels")
+        z = z.contiguous().float()
+        hnd = self._native(z.device)
+        B.check(B.lib().fc_vae_reserve_decode(hnd, bsz, h, w))
+        out = torch.empty(bsz, 3, 8 * h, 8 * w, device=z.device, dtype=torch.float32)
+        B.check(B.lib().fc_vae_decode(hnd, B.ptr(z), B.ptr(out), bsz, h, w, B.current_stream(z.device)))
+        return out
+
+    def forward(self, x, noise_strength=0.0, minval=0, get_stats=False):
+        """codecs.py:657-663."""
+        self.last_min, self.last_max = x.min(), x.max()
+        recon = self.decode(self.encode(x))
+        return (recon, 0.0, {'codebook_mean_dist': 0.0, 'codebook_max_dist': 0.0}) if get_stats else (recon, 0.0)
+
+    def flops_per_sample(self, decode=True) -> float:
+        return float(B.lib().fc_vae_flops_per_sample(self._handle, int(decode))) if self._handle else 0.0
+
+
+def _read_weights(path: str) -> Dict[str, torch.Tensor]:
+    path = os.path.expanduser(path)
+    if os.path.isdir(path):
+        for cand in ("diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.bin", "vae.safetensors", "vae.pt"):
+            if os.path.exists(os.path.join(path, cand)):
+                path = os.path.join(path, cand)
+                break
+        else:
+            raise FileNotFoundError(f"no SD-VAE weight file under {path}")
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"SD-VAE weights not found: {path}")
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        return load_file(path)
+    sd = torch.load(path, map_location="cpu", weights_only=False)
+    return sd.get("state_dict", sd.get("model_state_dict", sd))
+
+
+def setup_codec(config, device, no_natten=False, load_checkpoint=True, eval=True):
+    """codecs.py:668-741 -- codec factory keyed on ``config.codec.choice``."""
+    choice = config.codec.choice if 'choice' in config.codec else None
+    if choice is None or choice == "noop":
+        print("Using NoOpAE")
+        codec = NoOpAE().eval().to(device)
+    elif choice == "resize":
+        print("Using SimpleResizeAE")
+        codec = SimpleResizeAE(latent_shape=tuple(config.codec.get('latent_shape', (4, 16, 16)))).eval().to(device)
+    elif choice == "sd":
+        print("Loading SD VAE via SD_VAE_Wrapper")
+        weights = config.codec.get('sd_vae_path') or os.environ.get("FLOCODER_SD_VAE_PATH")
+        codec = SD_VAE_Wrapper(pretrained_model_name="stabilityai/sd-vae-ft-mse", weights=weights).eval().to(device)
+        if 'image_size' in config and config.image_size % 8 != 0:
+            print(f"Warning: SD VAE works best with image sizes divisible by 8. Current size: {config.image_size}")
+    elif choice == "vqgan_plus":
+        raise NotImplementedError("codec 'vqgan_plus' is codec-training territory and outside the flow hot path (SURVEY.md 2)")
+    else:
+        # the reference builds its VQVAE here (codecs.py:707-737); that codec is SURVEY 8 row C2, not built yet
+        for key in ('in_channels', 'hidden_channels', 'num_downsamples', 'internal_dim', 'vq_embedding_dim', 'codebook_levels',
+                    'vq_num_embeddings', 'commitment_weight'):
+            ldcfg(config, key, verbose=False)
+        if load_checkpoint:
+            if 'vqgan_checkpoint' in config:
+                path = config.vqgan_checkpoint
+            elif 'codec' in config and 'checkpoint' in config.codec:
+                path = config.codec.checkpoint
+            else:
+                raise ValueError("Could not find codec checkpoint path in config")
+            if path.lower() != "sd" and not os.path.exists(path):
+                raise FileNotFoundError(f"Codec checkpoint file {path} not found.")
+        raise NotImplementedError("the VQVAE codec (codecs.py:395-574) is not built yet in this implementation")
+    if eval:
+        codec = codec.eval()
+    print("Codec model ready")
+    return codec

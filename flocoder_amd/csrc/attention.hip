@@ -186,6 +186,53 @@ __global__ void __launch_bounds__(256) attn_small_kernel(const float* qkv, float
     }
 }
 
+// Row softmax for the SD-VAE mid-block attention scores (n x n per sample, n <= 4096): one wave per row, the row held in
+// registers between the max, the exp-sum and the write-back, so scores make one round trip.   grid (ceil(rows/4)), 256 threads
+__global__ void __launch_bounds__(256) softmax_rows_kernel(float* x, long rows, int cols, float scale) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float* xr = x + row * cols;
+    constexpr int MAXV = 16;                       // 16 float4 per lane = 4096 columns
+    float4 v[MAXV];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < cols) {
+            v[i] = *reinterpret_cast<const float4*>(xr + c);
+            v[i].x *= scale; v[i].y *= scale; v[i].z *= scale; v[i].w *= scale;
+            m = fmaxf(m, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < cols) {
+            v[i].x = __expf(v[i].x - m); v[i].y = __expf(v[i].y - m); v[i].z = __expf(v[i].z - m); v[i].w = __expf(v[i].w - m);
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < cols) *reinterpret_cast<float4*>(xr + c) = make_float4(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);
+    }
+}
+
+int softmax_rows_launch(float* x, long rows, int cols, float scale, hipStream_t s) {
+    if (cols > 4096 || (cols & 3)) return fail(FC_E_SHAPE, "softmax_rows: columns must be a multiple of 4 and <= 4096");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, rows, cols, scale);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
 int attn_small_launch(const float* qkv, float* out, int B, int n, int heads, hipStream_t s) {
     if (n > 64) return fail(FC_E_SHAPE, "attn_small: more than 64 tokens");
     hipLaunchKernelGGL(attn_small_kernel, dim3(B * heads), dim3(256), 0, s, qkv, out, n, heads);

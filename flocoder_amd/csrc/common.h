@@ -67,8 +67,9 @@ struct ConvArgs {
     float* out = nullptr;      // NHWC [B][H][W][Cout]
     int out_act = 0;           // 1: SiLU on (acc + bias) before `add`
     const float* add = nullptr;  // NHWC [B][H][W][Cout] added last (residuals)
-    float* stats_out = nullptr;  // partial GroupNorm stats of `out` (after bias, before act/add)
+    float* stats_out = nullptr;  // partial GroupNorm stats of `out`: after bias, before act/add -- or of the final value when stats_post
     int Gout = 0;
+    int stats_post = 0;
     // fused 1x1 projection of the (untransformed) centre tap: ResnetBlock.res_conv, unet.py:86,96
     const float* res_w = nullptr;  // [Cin][Cout]
     const float* res_b = nullptr;
@@ -156,6 +157,12 @@ int ode_rk4_final_launch(const float* sc, float* y, const float* k1, const float
 
 // ---- weight packing (pack.hip) ----------------------------------------------------------------
 int pack_conv_launch(const float* oihw, float* dst /*[KK][I][O]*/, int O, int I, int KH, int KW, hipStream_t s);
+// same with zero padding of either channel count: dst [KK][Ipad][Opad]
+int pack_conv_pad_launch(const float* oihw, float* dst, int O, int I, int KK, int Opad, int Ipad, hipStream_t s);
+// [B][rows][cols] -> [B][cols][rows]
+int transpose_batched_launch(const float* src, float* dst, int B, int rows, int cols, hipStream_t s);
+// in place: x[r][:] = softmax(scale * x[r][:]) for `rows` rows of `cols` floats
+int softmax_rows_launch(float* x, long rows, int cols, float scale, hipStream_t s);
 int pack_s2d_conv_launch(const float* oi, float* dst /*[4][C][O]*/, int O, int C, hipStream_t s);  // Downsample: (c p1 p2) -> 2x2 s2
 int pack_transpose_launch(const float* src /*[R][Cc]*/, float* dst /*[Cc][R]*/, int R, int Cc, int dst_ld, int dst_col0,
                           hipStream_t s);

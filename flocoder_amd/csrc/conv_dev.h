@@ -117,6 +117,25 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                 const float rbias = (has_res && a.res_b && nok) ? a.res_b[n] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mt][nt][r] += bias;
+                size_t off[16];
+                bool ok[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int tw = m & (TW - 1), th = (m >> p.TWl) & (TH - 1), tb = m >> (p.TWl + p.THl);
+                    const int b = b0 + tb;
+                    ok[r] = nok && b < a.B;
+                    off[r] = ((size_t)(b * a.H + y0 + th) * a.W + x0 + tw) * Cout + n;
+                }
+                if (a.stats_post) {   // statistics of the FINAL value (activation and residual included): pre-norm resnets (SD-VAE)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[mt][nt][r];
+                        if (a.out_act) v = silu_f(v);
+                        if (a.add && ok[r]) v += a.add[off[r]];
+                        acc[mt][nt][r] = v;
+                    }
+                }
                 if (a.stats_out) {
 #pragma unroll
                     for (int hh = 0; hh < 2; ++hh) {
@@ -134,16 +153,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const int tw = m & (TW - 1), th = (m >> p.TWl) & (TH - 1), tb = m >> (p.TWl + p.THl);
-                    const int b = b0 + tb;
-                    if (nok && b < a.B) {
-                        const size_t o = ((size_t)(b * a.H + y0 + th) * a.W + x0 + tw) * Cout + n;
+                    if (ok[r]) {
                         float v = acc[mt][nt][r];
-                        if (a.out_act) v = silu_f(v);
-                        if (a.add) v += a.add[o];
-                        a.out[o] = v;
-                        if (has_res) a.res_out[o] = accr[mt][nt][r] + rbias;
+                        if (!a.stats_post) {
+                            if (a.out_act) v = silu_f(v);
+                            if (a.add) v += a.add[off[r]];
+                        }
+                        a.out[off[r]] = v;
+                        if (has_res) a.res_out[off[r]] = accr[mt][nt][r] + rbias;
                     }
                 }
             }

@@ -37,10 +37,42 @@ __global__ void __launch_bounds__(256) pack_transpose_kernel(const float* src, f
     }
 }
 
+__global__ void __launch_bounds__(256) pack_conv_pad_kernel(const float* src, float* dst, int O, int I, int KK, int Opad, int Ipad) {
+    const size_t total = (size_t)Opad * Ipad * KK;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int o = (int)(i % Opad);
+        const size_t r = i / Opad;
+        const int ci = (int)(r % Ipad), tap = (int)(r / Ipad);
+        dst[i] = (o < O && ci < I) ? src[((size_t)o * I + ci) * KK + tap] : 0.f;
+    }
+}
+
+// [B][R][Cc] -> [B][Cc][R] through a padded 32x32 LDS tile (coalesced on both sides).   grid (Cc/32, R/32, B), block (32, 8)
+__global__ void __launch_bounds__(256) transpose_batched_kernel(const float* src, float* dst, int R, int Cc) {
+    __shared__ float tile[32][33];
+    const size_t base = (size_t)blockIdx.z * R * Cc;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += 8)
+        if (r0 + j < R && c0 + threadIdx.x < Cc) tile[j][threadIdx.x] = src[base + (size_t)(r0 + j) * Cc + c0 + threadIdx.x];
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8)
+        if (c0 + j < Cc && r0 + threadIdx.x < R) dst[base + (size_t)(c0 + j) * R + r0 + threadIdx.x] = tile[threadIdx.x][j];
+}
+
 static int pgrid(size_t total) { size_t g = (total + 255) / 256; return (int)(g < 4096 ? (g ? g : 1) : 4096); }
 
 int pack_conv_launch(const float* oihw, float* dst, int O, int I, int KH, int KW, hipStream_t s) {
     hipLaunchKernelGGL(pack_conv_kernel, dim3(pgrid((size_t)O * I * KH * KW)), dim3(256), 0, s, oihw, dst, O, I, KH * KW);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+int pack_conv_pad_launch(const float* oihw, float* dst, int O, int I, int KK, int Opad, int Ipad, hipStream_t s) {
+    hipLaunchKernelGGL(pack_conv_pad_kernel, dim3(pgrid((size_t)Opad * Ipad * KK)), dim3(256), 0, s, oihw, dst, O, I, KK, Opad, Ipad);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+int transpose_batched_launch(const float* src, float* dst, int B, int rows, int cols, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_batched_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32), B), dim3(32, 8), 0, s, src, dst, rows, cols);
     FC_HIP(hipGetLastError());
     return FC_OK;
 }

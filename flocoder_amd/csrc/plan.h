@@ -1,0 +1,217 @@
+// Generic pieces of the native runtimes (unet.hip, vae.hip): parameter store with the reference's state_dict names, weight
+// packing, launch plan over a fixed activation arena, and the builder that emits implicit-GEMM launches.
+#pragma once
+#include <functional>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+
+namespace fc {
+
+struct Param {
+    std::string name;
+    int64_t shape[4] = {0, 0, 0, 0};
+    int64_t numel = 0, offset = 0;
+};
+
+struct Act { float* p = nullptr; int C = 0, H = 0, W = 0; };
+struct Stat { float* p = nullptr; int G = 0, T = 0; float n_t = 0.f; };
+
+struct FwdCtx {             // per-call inputs of one forward
+    const float* x = nullptr;          // NCHW [x_mod][C][H][W]
+    int x_mod = 0;                     // row b reads sample b % x_mod (CFG: both halves share x)
+    const float* time = nullptr;       // [B]
+    const int64_t* ids = nullptr;      // [ids_mod] or null
+    int ids_mod = 0, null_from = 0;
+    const float* mask = nullptr;       // NCHW [x_mod][C][H][W] or null
+    int mask_fuse = 0;                 // run mask_fusion_conv (mask present and not all ones)
+    float* out = nullptr;              // NCHW [B][C][H][W]
+    int B = 0;
+};
+using Op = std::function<int(const FwdCtx&, hipStream_t)>;
+
+struct Plan {                 // one launch plan + activation arena for up to maxB rows
+    int maxB = 0, H = 0, W = 0;
+    std::vector<Op> ops;
+    std::vector<std::string> op_kernel, op_what;  // parallel to ops: kernel family, reference module it serves
+    std::vector<double> op_flops;                  // algorithmic FLOPs per sample of that launch
+    std::vector<void*> allocs;
+    double flops = 0.0;
+    float *t_emb = nullptr, *ss = nullptr;
+    std::map<std::string, Act> named;              // debug taps: block outputs by reference module name
+    void release() {
+        for (void* p : allocs) (void)hipFree(p);
+        *this = Plan();
+    }
+};
+
+struct PackOp { int kind; int64_t src, dst; int a, b, c, d, e = 0; };
+// kind 0 conv OIHW(O=a,I=b,KH=c,KW=d), 1 s2d, 2 transpose(R=a,Cc=b,ld=c,col0=d), 3 copy(a floats), 4 conv with channel padding(O=a,I=b,KK=c,Opad=d,Ipad=e)
+
+static const char* const kTileNames[] = {"conv_igemm<M128,N32>", "conv_igemm<M128,N64>", "conv_igemm<M64,N32,K2>", "conv_igemm<M32,N32,K4>",
+                                         "conv_igemm<M64,N64,K2>"};
+
+// Parameters as the reference stores them (`raw`, flat, table order, every tensor 16-byte aligned) plus the operand
+// layouts the kernels read (`packed`), and the list of re-layout launches that turns one into the other.
+struct ParamStore {
+    std::vector<Param> params;
+    std::unordered_map<std::string, int> pidx;
+    int64_t raw_numel = 0, packed_numel = 0;
+    float *raw = nullptr, *packed = nullptr;
+    std::unordered_map<std::string, int64_t> pk;  // name -> offset into packed
+    std::vector<PackOp> packops;
+    bool loaded = false;
+
+    const float* R(const std::string& n) const { return raw + params[pidx.at(n)].offset; }
+    const float* P(const std::string& n) const { return packed + pk.at(n); }
+    bool has(const std::string& n) const { return pidx.count(n) != 0; }
+
+    void declare(const std::string& name, std::initializer_list<int64_t> shape) {
+        Param p;
+        p.name = name;
+        p.numel = 1;
+        int i = 0;
+        for (int64_t s : shape) { p.shape[i++] = s; p.numel *= s; }
+        p.offset = raw_numel;
+        raw_numel += (p.numel + 3) & ~3ll;  // keep every tensor 16-byte aligned inside `raw`
+        pidx[name] = (int)params.size();
+        params.push_back(p);
+    }
+    int64_t pk_alloc(const std::string& name, int64_t numel) {
+        const int64_t off = packed_numel;
+        pk[name] = off;
+        packed_numel += (numel + 3) & ~3ll;
+        return off;
+    }
+    void decl_conv(const std::string& n, int O, int I, int K, bool bias = true) {
+        declare(n + ".weight", {O, I, K, K});
+        if (bias) declare(n + ".bias", {O});
+        const int64_t dst = pk_alloc(n + ".weight", (int64_t)O * I * K * K);
+        packops.push_back({0, params[pidx[n + ".weight"]].offset, dst, O, I, K, K});
+    }
+    void decl_linear_t(const std::string& n, int O, int I) {  // stored transposed [I][O]
+        declare(n + ".weight", {O, I});
+        declare(n + ".bias", {O});
+        const int64_t dst = pk_alloc(n + ".weight", (int64_t)O * I);
+        packops.push_back({2, params[pidx[n + ".weight"]].offset, dst, O, I, O, 0});
+    }
+    void decl_norm(const std::string& n, int C) {
+        declare(n + ".weight", {C});
+        declare(n + ".bias", {C});
+    }
+    int alloc_device() {
+        FC_HIP(hipMalloc(reinterpret_cast<void**>(&raw), (size_t)(raw_numel ? raw_numel : 4) * sizeof(float)));
+        FC_HIP(hipMalloc(reinterpret_cast<void**>(&packed), (size_t)(packed_numel ? packed_numel : 4) * sizeof(float)));
+        FC_HIP(hipMemset(raw, 0, (size_t)(raw_numel ? raw_numel : 4) * sizeof(float)));
+        return FC_OK;
+    }
+    void free_device() {
+        if (raw) (void)hipFree(raw);
+        if (packed) (void)hipFree(packed);
+        raw = packed = nullptr;
+    }
+    int run_pack(hipStream_t s) const {
+        for (const PackOp& o : packops) {
+            const float* src = raw + o.src;
+            float* dst = packed + o.dst;
+            switch (o.kind) {
+                case 0: FC_TRY(pack_conv_launch(src, dst, o.a, o.b, o.c, o.d, s)); break;
+                case 1: FC_TRY(pack_s2d_conv_launch(src, dst, o.a, o.b, s)); break;
+                case 2: FC_TRY(pack_transpose_launch(src, dst, o.a, o.b, o.c, o.d, s)); break;
+                case 3: FC_HIP(hipMemcpyAsync(dst, src, (size_t)o.a * sizeof(float), hipMemcpyDeviceToDevice, s)); break;
+                case 4: FC_TRY(pack_conv_pad_launch(src, dst, o.a, o.b, o.c, o.d, o.e, s)); break;
+            }
+        }
+        return FC_OK;
+    }
+    // flat fp32 vector in table order (padded layout) -> raw -> packed
+    int load(const float* flat, int64_t numel, int on_device, hipStream_t s) {
+        if (numel != raw_numel) return fail(FC_E_ARG, "load_params: expected " + std::to_string(raw_numel) + " floats (padded table layout)");
+        FC_HIP(hipMemcpyAsync(raw, flat, (size_t)numel * sizeof(float), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+        FC_TRY(run_pack(s));
+        if (!on_device) FC_HIP(hipStreamSynchronize(s));  // the host buffer may be freed by the caller on return
+        loaded = true;
+        return FC_OK;
+    }
+    int info(int i, const char** name, int64_t shape[4], int64_t* offset) const {
+        if (i < 0 || i >= (int)params.size()) return fail(FC_E_ARG, "param_info: index out of range");
+        const Param& p = params[i];
+        if (name) *name = p.name.c_str();
+        if (shape) for (int k = 0; k < 4; ++k) shape[k] = p.shape[k];
+        if (offset) *offset = p.offset;
+        return FC_OK;
+    }
+};
+
+struct PlanBuilder {
+    Plan* pl = nullptr;
+    int B = 0;  // max batch
+    int err = FC_OK;
+    std::string scope;  // reference module the ops being emitted belong to
+
+    void push(Op op, const std::string& kernel, double flops = 0.0) {
+        pl->ops.push_back(std::move(op));
+        pl->op_kernel.push_back(kernel);
+        pl->op_what.push_back(scope);
+        pl->op_flops.push_back(flops);
+        pl->flops += flops;
+    }
+    float* dmalloc(size_t floats) {
+        void* p = nullptr;
+        if (hipMalloc(&p, (floats ? floats : 1) * sizeof(float)) != hipSuccess) { err = fail(FC_E_HIP, "hipMalloc failed while reserving the arena"); return nullptr; }
+        pl->allocs.push_back(p);
+        return static_cast<float*>(p);
+    }
+    std::multimap<size_t, float*> pool;   // buffers handed back by release(): later tensors of the same size reuse them
+    Act act(int C, int H, int W) {
+        Act a; a.C = C; a.H = H; a.W = W;
+        const size_t n = (size_t)B * H * W * C;
+        auto it = pool.find(n);
+        if (it != pool.end()) { a.p = it->second; pool.erase(it); }
+        else a.p = dmalloc(n);
+        return a;
+    }
+    // The plan is a fixed sequence on one stream, so a buffer whose last reader has been emitted can serve a later tensor.
+    void release(const Act& a) { if (a.p) pool.emplace((size_t)B * a.H * a.W * a.C, a.p); }
+    Stat stat(int G, int T, float n_t) { Stat s; s.G = G; s.T = T; s.n_t = n_t; s.p = dmalloc((size_t)B * G * T * 2); return s; }
+
+    static SrcXform xf_of(const Stat& st, int mode, const float* gamma, const float* beta, const float* ss = nullptr, int ss_stride = 0,
+                          float eps = 1e-5f) {
+        SrcXform x;
+        x.mode = mode; x.stats = st.p; x.G = st.G; x.T = st.T; x.n_t = st.n_t;
+        x.gamma = gamma; x.beta = beta; x.ss = ss; x.ss_stride = ss_stride; x.eps = eps;
+        return x;
+    }
+
+    // Emits one implicit-GEMM launch (plus a standalone statistics pass when the output has < 16 pixels per sample).
+    // `want_G` > 0 asks for GroupNorm partials of the output; returns them in *st.
+    void conv(ConvArgs a, const Act& out, int want_G, Stat* st) {
+        if (err) return;
+        a.B = B; a.H = out.H; a.W = out.W; a.Cout = out.C; a.out = out.p;
+        a.Cin = a.s0.C + a.s1.C;
+        const bool fused = want_G > 0 && (out.H * out.W) % 16 == 0;
+        ConvGeom g;
+        if (fused) { a.Gout = want_G; a.stats_out = reinterpret_cast<float*>(1); }  // placeholder: geometry only
+        if ((err = conv_plan(a, TILE_AUTO, &g)) != FC_OK) return;
+        if (fused) { *st = stat(want_G, g.T, g.n_t); a.stats_out = st->p; }
+        const int tile = g.tile;
+        double fl = 2.0 * out.H * out.W * a.KS * a.KS * (double)a.Cin * a.Cout;
+        if (a.res_out) fl += 2.0 * out.H * out.W * (double)a.Cin * a.Cout;
+        push([a, tile](const FwdCtx& c, hipStream_t s) { ConvArgs b = a; b.B = c.B; return conv_launch(b, tile, s); }, kTileNames[tile], fl);
+        if (want_G > 0 && !fused) {
+            *st = stat(want_G, 1, (float)(out.H * out.W * (out.C / want_G)));
+            float* sp = st->p; const float* xp = out.p; const int HW = out.H * out.W, C = out.C, G = want_G;
+            push([=](const FwdCtx& c, hipStream_t s) { return gn_stats_launch(xp, sp, c.B, HW, C, G, s); }, "gn_stats");
+        }
+    }
+};
+
+inline int run_plan(const Plan& pl, const FwdCtx& c, hipStream_t s) {
+    for (const Op& op : pl.ops) FC_TRY(op(c, s));
+    return FC_OK;
+}
+
+}  // namespace fc

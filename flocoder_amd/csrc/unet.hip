@@ -15,7 +15,7 @@
 #include <unordered_map>
 #include <vector>
 
-#include "common.h"
+#include "plan.h"
 
 namespace fc {
 
@@ -24,60 +24,18 @@ void set_error(const std::string& m) { g_err = m; }
 int fail(int code, const std::string& m) { g_err = m; return code; }
 const char* last_error() { return g_err.c_str(); }
 
-struct Param {
-    std::string name;
-    int64_t shape[4] = {0, 0, 0, 0};
-    int64_t numel = 0, offset = 0;
-};
-
-struct Act { float* p = nullptr; int C = 0, H = 0, W = 0; };
-struct Stat { float* p = nullptr; int G = 0, T = 0; float n_t = 0.f; };
-
-struct FwdCtx {             // per-call inputs of one U-Net forward
-    const float* x = nullptr;          // NCHW [x_mod][C][H][W]
-    int x_mod = 0;                     // row b reads sample b % x_mod (CFG: both halves share x)
-    const float* time = nullptr;       // [B]
-    const int64_t* ids = nullptr;      // [ids_mod] or null
-    int ids_mod = 0, null_from = 0;
-    const float* mask = nullptr;       // NCHW [x_mod][C][H][W] or null
-    int mask_fuse = 0;                 // run mask_fusion_conv (mask present and not all ones)
-    float* out = nullptr;              // NCHW [B][C][H][W]
-    int B = 0;
-};
-using Op = std::function<int(const FwdCtx&, hipStream_t)>;
-
-struct Plan {                 // one launch plan + activation arena for up to maxB rows of HxW latents
-    int maxB = 0, H = 0, W = 0;
-    std::vector<Op> ops;
-    std::vector<std::string> op_kernel, op_what;  // parallel to ops: kernel family, reference module it serves
-    std::vector<double> op_flops;                  // algorithmic FLOPs per sample of that launch
-    std::vector<void*> allocs;
-    double flops = 0.0;
-    float *t_emb = nullptr, *ss = nullptr;
-    std::map<std::string, Act> named;              // debug taps: block outputs by reference module name
-};
-
-struct PackOp { int kind; int64_t src, dst; int a, b, c, d; };  // kind 0 conv OIHW, 1 s2d, 2 transpose(R=a,Cc=b,ld=c,col0=d), 3 copy(a)
-
 }  // namespace fc
 
 using namespace fc;
 
-struct fc_unet {
+struct fc_unet : fc::ParamStore {
     fc_unet_config cfg{};
     int device = 0;
     int td = 0, heads = 4;
     std::vector<int> chans;  // [dim, dim*m0, dim*m1, ...]
-    std::vector<Param> params;
-    std::unordered_map<std::string, int> pidx;
-    int64_t raw_numel = 0, packed_numel = 0;
-    float *raw = nullptr, *packed = nullptr;
-    std::unordered_map<std::string, int64_t> pk;  // name -> offset into packed
-    std::vector<PackOp> packops;
     int S = 0;                                    // total scale/shift width
     std::unordered_map<std::string, int> ss_off;  // resblock prefix -> column offset
     float* freqs = nullptr;
-    bool loaded = false;
 
     // plans: the batch can run as `nchains` independent row ranges on concurrent streams (no cross-sample op exists in the
     // network; FLOCODER_AMD_CHAINS=2).  Off by default: half-batch launches lose more than the overlap wins on one GPU.
@@ -97,47 +55,16 @@ struct fc_unet {
     int64_t* ids_own = nullptr;
     std::map<std::tuple<int, int, int, int, uint32_t, uint32_t, uint32_t, int>, hipGraphExec_t> graphs;
 
-    const float* R(const std::string& n) const { return raw + params[pidx.at(n)].offset; }
-    const float* P(const std::string& n) const { return packed + pk.at(n); }
-    bool has(const std::string& n) const { return pidx.count(n) != 0; }
 };
 
 namespace fc {
 
 // ------------------------------------------------------------------------------------------- parameters
-static void declare(fc_unet* u, const std::string& name, std::initializer_list<int64_t> shape) {
-    Param p;
-    p.name = name;
-    p.numel = 1;
-    int i = 0;
-    for (int64_t s : shape) { p.shape[i++] = s; p.numel *= s; }
-    p.offset = u->raw_numel;
-    u->raw_numel += (p.numel + 3) & ~3ll;  // keep every tensor 16-byte aligned inside `raw`
-    u->pidx[name] = (int)u->params.size();
-    u->params.push_back(p);
-}
-static int64_t pk_alloc(fc_unet* u, const std::string& name, int64_t numel) {
-    const int64_t off = u->packed_numel;
-    u->pk[name] = off;
-    u->packed_numel += (numel + 3) & ~3ll;
-    return off;
-}
-static void decl_conv(fc_unet* u, const std::string& n, int O, int I, int K, bool bias = true) {
-    declare(u, n + ".weight", {O, I, K, K});
-    if (bias) declare(u, n + ".bias", {O});
-    const int64_t dst = pk_alloc(u, n + ".weight", (int64_t)O * I * K * K);
-    u->packops.push_back({0, u->params[u->pidx[n + ".weight"]].offset, dst, O, I, K, K});
-}
-static void decl_linear_t(fc_unet* u, const std::string& n, int O, int I) {  // stored transposed [I][O]
-    declare(u, n + ".weight", {O, I});
-    declare(u, n + ".bias", {O});
-    const int64_t dst = pk_alloc(u, n + ".weight", (int64_t)O * I);
-    u->packops.push_back({2, u->params[u->pidx[n + ".weight"]].offset, dst, O, I, O, 0});
-}
-static void decl_norm(fc_unet* u, const std::string& n, int C) {
-    declare(u, n + ".weight", {C});
-    declare(u, n + ".bias", {C});
-}
+static void declare(fc_unet* u, const std::string& name, std::initializer_list<int64_t> shape) { u->declare(name, shape); }
+static int64_t pk_alloc(fc_unet* u, const std::string& name, int64_t numel) { return u->pk_alloc(name, numel); }
+static void decl_conv(fc_unet* u, const std::string& n, int O, int I, int K, bool bias = true) { u->decl_conv(n, O, I, K, bias); }
+static void decl_linear_t(fc_unet* u, const std::string& n, int O, int I) { u->decl_linear_t(n, O, I); }
+static void decl_norm(fc_unet* u, const std::string& n, int C) { u->decl_norm(n, C); }
 static void decl_resblock(fc_unet* u, const std::string& p, int cin, int cout) {
     declare(u, p + ".mlp.1.weight", {2 * cout, u->td});
     declare(u, p + ".mlp.1.bias", {2 * cout});
@@ -220,76 +147,10 @@ static int declare_all(fc_unet* u) {
     return FC_OK;
 }
 
-static int run_pack(fc_unet* u, hipStream_t s) {
-    for (const PackOp& o : u->packops) {
-        const float* src = u->raw + o.src;
-        float* dst = u->packed + o.dst;
-        switch (o.kind) {
-            case 0: FC_TRY(pack_conv_launch(src, dst, o.a, o.b, o.c, o.d, s)); break;
-            case 1: FC_TRY(pack_s2d_conv_launch(src, dst, o.a, o.b, s)); break;
-            case 2: FC_TRY(pack_transpose_launch(src, dst, o.a, o.b, o.c, o.d, s)); break;
-            case 3: FC_HIP(hipMemcpyAsync(dst, src, (size_t)o.a * sizeof(float), hipMemcpyDeviceToDevice, s)); break;
-        }
-    }
-    return FC_OK;
-}
-
 // ------------------------------------------------------------------------------------------- plan builder
-static const char* kTileNames[] = {"conv_igemm<M128,N32>", "conv_igemm<M128,N64>", "conv_igemm<M64,N32,K2>", "conv_igemm<M32,N32,K4>",
-                                   "conv_igemm<M64,N64,K2>"};
-
-struct Builder {
-    fc_unet* u;
-    Plan* pl;
-    int B;  // max batch
-    int err = FC_OK;
-    std::string scope;  // reference module the ops being emitted belong to
-
-    void push(Op op, const std::string& kernel, double flops = 0.0) {
-        pl->ops.push_back(std::move(op));
-        pl->op_kernel.push_back(kernel);
-        pl->op_what.push_back(scope);
-        pl->op_flops.push_back(flops);
-        pl->flops += flops;
-    }
-
-    float* dmalloc(size_t floats) {
-        void* p = nullptr;
-        if (hipMalloc(&p, (floats ? floats : 1) * sizeof(float)) != hipSuccess) { err = fail(FC_E_HIP, "hipMalloc failed while reserving the arena"); return nullptr; }
-        pl->allocs.push_back(p);
-        return static_cast<float*>(p);
-    }
-    Act act(int C, int H, int W) { Act a; a.C = C; a.H = H; a.W = W; a.p = dmalloc((size_t)B * H * W * C); return a; }
-    Stat stat(int G, int T, float n_t) { Stat s; s.G = G; s.T = T; s.n_t = n_t; s.p = dmalloc((size_t)B * G * T * 2); return s; }
-
-    static SrcXform xf_of(const Stat& st, int mode, const float* gamma, const float* beta, const float* ss = nullptr, int ss_stride = 0) {
-        SrcXform x;
-        x.mode = mode; x.stats = st.p; x.G = st.G; x.T = st.T; x.n_t = st.n_t;
-        x.gamma = gamma; x.beta = beta; x.ss = ss; x.ss_stride = ss_stride;
-        return x;
-    }
-
-    // Emits one implicit-GEMM launch (plus a standalone statistics pass when the output has < 16 pixels per sample).
-    // `want_G` > 0 asks for GroupNorm partials of the output; returns them in *st.
-    void conv(ConvArgs a, const Act& out, int want_G, Stat* st) {
-        if (err) return;
-        a.B = B; a.H = out.H; a.W = out.W; a.Cout = out.C; a.out = out.p;
-        a.Cin = a.s0.C + a.s1.C;
-        const bool fused = want_G > 0 && (out.H * out.W) % 16 == 0;
-        ConvGeom g;
-        if (fused) { a.Gout = want_G; a.stats_out = reinterpret_cast<float*>(1); }  // placeholder: geometry only
-        if ((err = conv_plan(a, TILE_AUTO, &g)) != FC_OK) return;
-        if (fused) { *st = stat(want_G, g.T, g.n_t); a.stats_out = st->p; }
-        const int tile = g.tile;
-        double fl = 2.0 * out.H * out.W * a.KS * a.KS * (double)a.Cin * a.Cout;
-        if (a.res_out) fl += 2.0 * out.H * out.W * (double)a.Cin * a.Cout;
-        push([a, tile](const FwdCtx& c, hipStream_t s) { ConvArgs b = a; b.B = c.B; return conv_launch(b, tile, s); }, kTileNames[tile], fl);
-        if (want_G > 0 && !fused) {
-            *st = stat(want_G, 1, (float)(out.H * out.W * (out.C / want_G)));
-            float* sp = st->p; const float* xp = out.p; const int HW = out.H * out.W, C = out.C, G = want_G;
-            push([=](const FwdCtx& c, hipStream_t s) { return gn_stats_launch(xp, sp, c.B, HW, C, G, s); }, "gn_stats");
-        }
-    }
+struct Builder : PlanBuilder {
+    fc_unet* u = nullptr;
+    Builder(fc_unet* u_, Plan* pl_, int B_) : u(u_) { pl = pl_; B = B_; }
 
     // ResnetBlock (unet.py:76-96): conv1 [+res_conv] | conv2 with GN+FiLM+SiLU folded into its loader | finalize.
     Act resblock(const std::string& p, const Act& x, const Act* skip, int cout, bool want_gn1, Stat* gn1) {
@@ -408,10 +269,7 @@ struct Builder {
 static void free_plan(fc_unet* u) {
     for (auto& kv : u->graphs) (void)hipGraphExecDestroy(kv.second);
     u->graphs.clear();
-    for (Plan& pln : u->plan) {
-        for (void* p : pln.allocs) (void)hipFree(p);
-        pln = Plan();
-    }
+    for (Plan& pln : u->plan) pln.release();
     for (void* p : u->int_allocs) (void)hipFree(p);
     u->int_allocs.clear();
     u->maxB = 0;
@@ -423,7 +281,7 @@ static int build_plan(fc_unet* u, Plan* pl, int maxB, int H, int W) {
     if (!is_pow2(H) || !is_pow2(W) || (H >> (L - 1)) < 1 || (W >> (L - 1)) < 1)
         return fail(FC_E_SHAPE, "unet: latent height/width must be powers of two >= 2^(levels-1)");
     if ((ch & 3) || (dim & 3)) return fail(FC_E_SHAPE, "unet: channels and dim must be multiples of 4");
-    Builder b{u, pl, maxB};
+    Builder b(u, pl, maxB);
     pl->flops = 0.0;
     pl->t_emb = b.dmalloc((size_t)maxB * u->td);
     pl->ss = b.dmalloc((size_t)maxB * u->S);
@@ -598,11 +456,6 @@ static int alloc_integrator(fc_unet* u, int rows, int H, int W) {
     return FC_OK;
 }
 
-static int run_plan(const Plan& pl, const FwdCtx& c, hipStream_t s) {
-    for (const Op& op : pl.ops) FC_TRY(op(c, s));
-    return FC_OK;
-}
-
 // Rows [r0, r0 + n) of the caller's batch as a context of their own (row r reads sample r % x_mod, class id r % ids_mod,
 // no class at all from row null_from on -- the CFG layout of fc_unet_integrate).
 static FwdCtx slice_ctx(const FwdCtx& c, int r0, int n, size_t sample_floats) {
@@ -675,9 +528,7 @@ int fc_unet_create(const fc_unet_config* cfg, int device, fc_unet** out) {
     FC_TRY(fc_check_device(device));
     FC_HIP(hipSetDevice(device));
     FC_TRY(conv_init());
-    FC_HIP(hipMalloc(reinterpret_cast<void**>(&u->raw), (size_t)u->raw_numel * sizeof(float)));
-    FC_HIP(hipMalloc(reinterpret_cast<void**>(&u->packed), (size_t)u->packed_numel * sizeof(float)));
-    FC_HIP(hipMemset(u->raw, 0, (size_t)u->raw_numel * sizeof(float)));
+    FC_TRY(u->alloc_device());
     const int half = cfg->dim / 2;
     std::vector<float> fr(half);
     const double lf = std::log(10000.0) / (half - 1);  // unet.py:26
@@ -701,8 +552,7 @@ void fc_unet_destroy(fc_unet* u) {
     (void)hipDeviceSynchronize();
     free_plan(u);
     if (u->ts_dev) (void)hipFree(u->ts_dev);
-    if (u->raw) (void)hipFree(u->raw);
-    if (u->packed) (void)hipFree(u->packed);
+    u->free_device();
     if (u->freqs) (void)hipFree(u->freqs);
     if (u->stream) (void)hipStreamDestroy(u->stream);
     if (u->ev_in) (void)hipEventDestroy(u->ev_in);
@@ -716,12 +566,8 @@ void fc_unet_destroy(fc_unet* u) {
 int fc_unet_param_count(const fc_unet* u) { return u ? (int)u->params.size() : 0; }
 
 int fc_unet_param_info(const fc_unet* u, int i, const char** name, int64_t shape[4], int64_t* offset) {
-    if (!u || i < 0 || i >= (int)u->params.size()) return fail(FC_E_ARG, "fc_unet_param_info: index out of range");
-    const Param& p = u->params[i];
-    if (name) *name = p.name.c_str();
-    if (shape) for (int k = 0; k < 4; ++k) shape[k] = p.shape[k];
-    if (offset) *offset = p.offset;
-    return FC_OK;
+    if (!u) return fail(FC_E_ARG, "fc_unet_param_info: null handle");
+    return u->info(i, name, shape, offset);
 }
 
 int64_t fc_unet_param_numel(const fc_unet* u) { return u ? u->raw_numel : 0; }
@@ -735,14 +581,8 @@ int fc_unet_set_time_freqs(fc_unet* u, const float* freqs_host, int n) {
 int fc_unet_load_params(fc_unet* u, const float* flat, int64_t numel, int on_device, void* stream) {
     if (!u || !flat) return fail(FC_E_ARG, "fc_unet_load_params: null argument");
     if (u->device < 0) return fail(FC_E_STATE, "unet: created with device < 0 (description only)");
-    if (numel != u->raw_numel) return fail(FC_E_ARG, "fc_unet_load_params: expected " + std::to_string(u->raw_numel) + " floats (padded table layout)");
-    hipStream_t s = static_cast<hipStream_t>(stream);
     FC_HIP(hipSetDevice(u->device));
-    FC_HIP(hipMemcpyAsync(u->raw, flat, (size_t)numel * sizeof(float), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
-    FC_TRY(run_pack(u, s));
-    if (!on_device) FC_HIP(hipStreamSynchronize(s));  // the host buffer may be freed by the caller on return
-    u->loaded = true;
-    return FC_OK;
+    return u->load(flat, numel, on_device, static_cast<hipStream_t>(stream));
 }
 
 int fc_unet_reserve(fc_unet* u, int max_batch, int height, int width) {

@@ -137,6 +137,28 @@ int fc_debug_conv(const float* src0_nhwc, int c0, const float* src1_nhwc, int c1
                   float* ms_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * SD-VAE codec  (replaces flocoder/codecs.py:631-663 SD_VAE_Wrapper -> diffusers AutoencoderKL, sd-vae-ft-mse config)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct fc_vae fc_vae;
+/* device >= 0: a gfx950 device; device < 0: description only (parameter table). */
+int fc_vae_create(int device, fc_vae** out);
+void fc_vae_destroy(fc_vae* v);
+/* Parameter table: names/shapes are the upstream AutoencoderKL state_dict keys ("encoder.conv_in.weight", ...). */
+int fc_vae_param_count(const fc_vae* v);
+int64_t fc_vae_param_numel(const fc_vae* v);
+int fc_vae_param_info(const fc_vae* v, int i, const char** name, int64_t shape[4], int64_t* offset);
+int fc_vae_load_params(fc_vae* v, const float* flat, int64_t numel, int on_device, void* stream);
+/* Plans + arenas.  Images HxW (powers of two >= 64), latents (H/8)x(W/8). */
+int fc_vae_reserve_encode(fc_vae* v, int max_batch, int height, int width);
+int fc_vae_reserve_decode(fc_vae* v, int max_batch, int lat_height, int lat_width);
+/* mean = vae.encode(x).latent_dist.mean  (codecs.py:642): x_dev [B,3,H,W] -> mean_out_dev [B,4,H/8,W/8]; no scaling factor. */
+int fc_vae_encode(fc_vae* v, const float* x_dev, float* mean_out_dev, int batch, int height, int width, void* stream);
+/* x = vae.decode(z).sample  (codecs.py:651): z_dev [B,4,h,w] -> x_out_dev [B,3,8h,8w]. */
+int fc_vae_decode(fc_vae* v, const float* z_dev, float* x_out_dev, int batch, int lat_height, int lat_width, void* stream);
+double fc_vae_flops_per_sample(const fc_vae* v, int decode);
+int fc_vae_plan_launches(const fc_vae* v, int decode);
+
+/* ------------------------------------------------------------------------------------------------
  * Greedy OT pairing  (replaces flocoder/ot.py:63-84 compute_ot_pairing)
  * ---------------------------------------------------------------------------------------------- */
 /* source_dev/target_dev [B,D] fp32; dist_ws_dev workspace of B*B floats; perm_out_dev [B] int64. */
