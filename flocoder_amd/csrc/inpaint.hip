@@ -1,0 +1,179 @@
+// Inpainting conditioning (flocoder/inpainting.py:161-253): MaskEncoder and mask_blending.
+//
+// MaskEncoder turns a 1x128x128 pixel mask into a 4x8x8 latent-shaped conditioning signal with five tiny, oddly shaped
+// convolutions (1/17/33 channels, 4x4 stride 4).  That is ~3 MFLOP per sample -- launch-bound, not MFMA work -- so it
+// runs as direct convolutions on the reference's NCHW layout: one thread per output element, weights read through the
+// scalar/L1 path, activation fused, results written into a channel slice so torch.cat never materialises.
+#include <memory>
+
+#include "plan.h"
+
+using namespace fc;
+
+namespace fc {
+
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_SIGMOID = 2 };
+
+// out[b][co_off + co][y][x] = act(bias[co] + sum_{ci,ky,kx} w[co][ci][ky][kx] * in[b][ci][y*s - p + ky][x*s - p + kx])
+__global__ void __launch_bounds__(256) direct_conv_kernel(const float* in, const float* w, const float* bias, float* out, int B, int Cin, int Hin,
+                                                          int Win, int Cout, int Ho, int Wo, int KS, int stride, int pad, int act, int CoutTot,
+                                                          int co_off) {
+    const size_t total = (size_t)B * Cout * Ho * Wo;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int x = (int)(i % Wo);
+        size_t r = i / Wo;
+        const int y = (int)(r % Ho); r /= Ho;
+        const int co = (int)(r % Cout), b = (int)(r / Cout);
+        float acc = bias ? bias[co] : 0.f;
+        const float* wb = w + (size_t)co * Cin * KS * KS;
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float* ip = in + ((size_t)b * Cin + ci) * Hin * Win;
+            for (int ky = 0; ky < KS; ++ky) {
+                const int iy = y * stride - pad + ky;
+                if (iy < 0 || iy >= Hin) continue;
+                for (int kx = 0; kx < KS; ++kx) {
+                    const int ix = x * stride - pad + kx;
+                    if (ix >= 0 && ix < Win) acc += wb[(ci * KS + ky) * KS + kx] * ip[(size_t)iy * Win + ix];
+                }
+            }
+        }
+        if (act == ACT_SILU) acc = acc / (1.0f + __expf(-acc));
+        else if (act == ACT_SIGMOID) acc = 1.0f / (1.0f + __expf(-acc));
+        out[(((size_t)b * CoutTot + co_off + co) * Ho + y) * Wo + x] = acc;
+    }
+}
+
+// AvgPool2d(k, stride k) of channel `ci` of `in` into channel `co_off` of `out`
+__global__ void __launch_bounds__(256) avgpool_kernel(const float* in, float* out, int B, int Cin, int ci, int Hin, int Win, int k, int CoutTot, int co_off) {
+    const int Ho = Hin / k, Wo = Win / k;
+    const size_t total = (size_t)B * Ho * Wo;
+    const float inv = 1.0f / (float)(k * k);
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int x = (int)(i % Wo), y = (int)((i / Wo) % Ho), b = (int)(i / ((size_t)Wo * Ho));
+        const float* ip = in + ((size_t)b * Cin + ci) * Hin * Win;
+        float s = 0.f;
+        for (int dy = 0; dy < k; ++dy)
+            for (int dx = 0; dx < k; ++dx) s += ip[(size_t)(y * k + dy) * Win + x * k + dx];
+        out[(((size_t)b * CoutTot + co_off) * Ho + y) * Wo + x] = s * inv;
+    }
+}
+
+// source + mask * (noise - source)   (inpainting.py:250-253)
+__global__ void __launch_bounds__(256) mask_blend_kernel(const float* src, const float* mask, const float* noise, float* out, size_t n) {
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = __fadd_rn(src[i], __fmul_rn(mask[i], __fsub_rn(noise[i], src[i])));
+}
+
+static int grid1(size_t total) { size_t g = (total + 255) / 256; return (int)(g < 4096 ? (g ? g : 1) : 4096); }
+
+static int dconv(const float* in, const float* w, const float* bias, float* out, int B, int Cin, int Hin, int Win, int Cout, int KS, int stride, int pad,
+                 int act, int CoutTot, int co_off, hipStream_t s) {
+    const int Ho = (Hin + 2 * pad - KS) / stride + 1, Wo = (Win + 2 * pad - KS) / stride + 1;
+    hipLaunchKernelGGL(direct_conv_kernel, dim3(grid1((size_t)B * Cout * Ho * Wo)), dim3(256), 0, s, in, w, bias, out, B, Cin, Hin, Win, Cout, Ho, Wo,
+                       KS, stride, pad, act, CoutTot, co_off);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+static int apool(const float* in, float* out, int B, int Cin, int ci, int Hin, int Win, int k, int CoutTot, int co_off, hipStream_t s) {
+    hipLaunchKernelGGL(avgpool_kernel, dim3(grid1((size_t)B * (Hin / k) * (Win / k))), dim3(256), 0, s, in, out, B, Cin, ci, Hin, Win, k, CoutTot, co_off);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+}  // namespace fc
+
+// MaskEncoder(output_channels=4, shrink_fac=4, mode='pool', final_act=sigmoid)  (inpainting.py:161-245)
+struct fc_mask_encoder : fc::ParamStore {
+    int device = 0, out_ch = 4, shrink = 4;
+    int B = 0, H = 0, W = 0;
+    float *t1 = nullptr, *s1 = nullptr, *t2 = nullptr, *s2 = nullptr;   // conv1 outputs and [skip | learned] stages
+};
+
+extern "C" {
+
+int fc_mask_encoder_create(int device, fc_mask_encoder** out) {
+    if (!out) return fail(FC_E_ARG, "fc_mask_encoder_create: null argument");
+    std::unique_ptr<fc_mask_encoder> m(new fc_mask_encoder);
+    m->device = device;
+    const int k = m->shrink;
+    m->declare("layers.0.conv1.weight", {16, 1, k, k});  m->declare("layers.0.conv1.bias", {16});
+    m->declare("layers.0.conv2.weight", {16, 16, 3, 3}); m->declare("layers.0.conv2.bias", {16});
+    m->declare("layers.1.conv1.weight", {32, 17, k, k}); m->declare("layers.1.conv1.bias", {32});
+    m->declare("layers.1.conv2.weight", {32, 32, 3, 3}); m->declare("layers.1.conv2.bias", {32});
+    m->declare("layers.2.weight", {m->out_ch - 1, 33, 1, 1}); m->declare("layers.2.bias", {m->out_ch - 1});
+    if (device < 0) { *out = m.release(); return FC_OK; }
+    FC_TRY(fc_check_device(device));
+    FC_HIP(hipSetDevice(device));
+    FC_TRY(m->alloc_device());
+    *out = m.release();
+    return FC_OK;
+}
+
+static void me_free_buffers(fc_mask_encoder* m) {
+    for (float** p : {&m->t1, &m->s1, &m->t2, &m->s2}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    m->B = 0;
+}
+
+void fc_mask_encoder_destroy(fc_mask_encoder* m) {
+    if (!m) return;
+    if (m->device >= 0) { (void)hipSetDevice(m->device); (void)hipDeviceSynchronize(); me_free_buffers(m); m->free_device(); }
+    delete m;
+}
+int fc_mask_encoder_param_count(const fc_mask_encoder* m) { return m ? (int)m->params.size() : 0; }
+int64_t fc_mask_encoder_param_numel(const fc_mask_encoder* m) { return m ? m->raw_numel : 0; }
+int fc_mask_encoder_param_info(const fc_mask_encoder* m, int i, const char** name, int64_t shape[4], int64_t* offset) {
+    if (!m) return fail(FC_E_ARG, "fc_mask_encoder_param_info: null handle");
+    return m->info(i, name, shape, offset);
+}
+int fc_mask_encoder_load_params(fc_mask_encoder* m, const float* flat, int64_t numel, int on_device, void* stream) {
+    if (!m || !flat || m->device < 0) return fail(FC_E_ARG, "fc_mask_encoder_load_params: bad argument");
+    FC_HIP(hipSetDevice(m->device));
+    return m->load(flat, numel, on_device, static_cast<hipStream_t>(stream));
+}
+int fc_mask_encoder_reserve(fc_mask_encoder* m, int max_batch, int height, int width) {
+    if (!m || m->device < 0 || max_batch < 1) return fail(FC_E_ARG, "fc_mask_encoder_reserve: bad argument");
+    const int k = m->shrink;
+    if (height % (k * k) || width % (k * k)) return fail(FC_E_SHAPE, "mask encoder: mask height/width must be multiples of shrink_fac^2");
+    if (m->B >= max_batch && m->H == height && m->W == width) return FC_OK;
+    FC_HIP(hipSetDevice(m->device));
+    FC_HIP(hipDeviceSynchronize());
+    me_free_buffers(m);
+    const size_t h1 = height / k, w1 = width / k, h2 = h1 / k, w2 = w1 / k, b = max_batch;
+    FC_HIP(hipMalloc(reinterpret_cast<void**>(&m->t1), b * 16 * h1 * w1 * sizeof(float)));
+    FC_HIP(hipMalloc(reinterpret_cast<void**>(&m->s1), b * 17 * h1 * w1 * sizeof(float)));
+    FC_HIP(hipMalloc(reinterpret_cast<void**>(&m->t2), b * 32 * h2 * w2 * sizeof(float)));
+    FC_HIP(hipMalloc(reinterpret_cast<void**>(&m->s2), b * 33 * h2 * w2 * sizeof(float)));
+    m->B = max_batch; m->H = height; m->W = width;
+    return FC_OK;
+}
+
+// mask_pixels_dev [B,1,H,W] fp32 (0/1) -> mask_latents_dev [B,4,H/16,W/16]: channel 0 = 16x average-pooled raw mask, channels 1-3
+// learned + sigmoid  (inpainting.py:235-245)
+int fc_mask_encoder_forward(fc_mask_encoder* m, const float* mask_pixels_dev, float* mask_latents_dev, int batch, int height, int width, void* stream) {
+    if (!m || !mask_pixels_dev || !mask_latents_dev) return fail(FC_E_ARG, "fc_mask_encoder_forward: null argument");
+    if (!m->loaded) return fail(FC_E_STATE, "mask encoder: weights not loaded");
+    if (m->B < batch || m->H != height || m->W != width) return fail(FC_E_STATE, "mask encoder: call fc_mask_encoder_reserve first");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int k = m->shrink, B = batch, h1 = height / k, w1 = width / k, h2 = h1 / k, w2 = w1 / k, oc = m->out_ch;
+    // DownsampleBlock 0: [avgpool4(mask) | silu(conv3x3(silu(conv4x4/s4(mask))))] -> 17 channels
+    FC_TRY(dconv(mask_pixels_dev, m->R("layers.0.conv1.weight"), m->R("layers.0.conv1.bias"), m->t1, B, 1, height, width, 16, k, k, 0, ACT_SILU, 16, 0, s));
+    FC_TRY(apool(mask_pixels_dev, m->s1, B, 1, 0, height, width, k, 17, 0, s));
+    FC_TRY(dconv(m->t1, m->R("layers.0.conv2.weight"), m->R("layers.0.conv2.bias"), m->s1, B, 16, h1, w1, 16, 3, 1, 1, ACT_SILU, 17, 1, s));
+    // DownsampleBlock 1 on the 17-channel stage (its channel 0 is the pooled mask) -> 33 channels
+    FC_TRY(dconv(m->s1, m->R("layers.1.conv1.weight"), m->R("layers.1.conv1.bias"), m->t2, B, 17, h1, w1, 32, k, k, 0, ACT_SILU, 32, 0, s));
+    FC_TRY(apool(m->s1, m->s2, B, 17, 0, h1, w1, k, 33, 0, s));
+    FC_TRY(dconv(m->t2, m->R("layers.1.conv2.weight"), m->R("layers.1.conv2.bias"), m->s2, B, 32, h2, w2, 32, 3, 1, 1, ACT_SILU, 33, 1, s));
+    // 1x1 conv 33 -> 3 + sigmoid into channels 1..3; channel 0 = AvgPool2d(16) of the raw mask
+    FC_TRY(dconv(m->s2, m->R("layers.2.weight"), m->R("layers.2.bias"), mask_latents_dev, B, 33, h2, w2, oc - 1, 1, 1, 0, ACT_SIGMOID, oc, 1, s));
+    return apool(mask_pixels_dev, mask_latents_dev, B, 1, 0, height, width, k * k, oc, 0, s);
+}
+
+int fc_mask_blend(const float* source_dev, const float* mask_dev, const float* noise_dev, float* out_dev, int64_t numel, void* stream) {
+    if (!source_dev || !mask_dev || !noise_dev || !out_dev) return fail(FC_E_ARG, "fc_mask_blend: null argument");
+    hipLaunchKernelGGL(mask_blend_kernel, dim3(grid1((size_t)numel)), dim3(256), 0, static_cast<hipStream_t>(stream), source_dev, mask_dev, noise_dev, out_dev,
+                       (size_t)numel);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+"""Inpainting conditioning: host-side mirror of ``flocoder/inpainting.py``'s ``MaskEncoder`` / ``mask_blending``
+(inpainting.py:161-253) over the gfx950 library.  The mask *generators*, ``InpaintingDataset`` and the diagnostics of that
+file are data preparation and stay out of scope."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+from torch import nn
+
+from . import _binding as B
+
+
+class _Node(nn.Module):
+    pass
+
+
+class MaskEncoder(nn.Module):
+    """inpainting.py:182-245 with the defaults the flow trainer uses (output_channels=4, shrink_fac=4, mode='pool', sigmoid):
+    pixel mask [B,1,H,W] -> [B,4,H/16,W/16]; channel 0 is the 16x average-pooled raw mask, channels 1-3 are learned.
+    Same ``state_dict`` keys as upstream (``layers.0.conv1.weight`` ...) and the same default init / RNG order."""
+
+    def __init__(self, output_channels=4, shrink_fac=4, mode='pool', final_act=torch.sigmoid):
+        super().__init__()
+        if output_channels != 4 or shrink_fac != 4 or mode != 'pool':
+            raise NotImplementedError("only the configuration train_flow.py instantiates (MaskEncoder()) is built")
+        lib = B.lib()
+        h = C.c_void_p()
+        B.check(lib.fc_mask_encoder_create(-1, C.byref(h)))
+        self._table = []
+        for i in range(lib.fc_mask_encoder_param_count(h)):
+            name, shape, off = C.c_char_p(), (C.c_int64 * 4)(), C.c_int64()
+            B.check(lib.fc_mask_encoder_param_info(h, i, C.byref(name), C.byref(shape), C.byref(off)))
+            self._table.append((name.value.decode(), tuple(int(s) for s in shape if s), int(off.value)))
+        self._flat_numel = int(lib.fc_mask_encoder_param_numel(h))
+        lib.fc_mask_encoder_destroy(h)
+        for name, shape, _ in self._table:                     # registration order = upstream construction order
+            node = self
+            *path, leaf = name.split(".")
+            for part in path:
+                if not hasattr(node, part):
+                    node.add_module(part, _Node())
+                node = getattr(node, part)
+            p = nn.Parameter(torch.empty(shape))
+            with torch.no_grad():                              # nn.Conv2d defaults, weight then bias
+                if len(shape) > 1:
+                    nn.init.kaiming_uniform_(p, a=math.sqrt(5))
+                    fan_in = math.prod(shape[1:])
+                else:
+                    p.uniform_(-1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in))
+            node.register_parameter(leaf, p)
+        self._handle, self._handle_device, self._synced = None, None, None
+
+    def _native(self, device):
+        lib = B.lib()
+        if self._handle is None or self._handle_device != device:
+            self._release()
+            h = C.c_void_p()
+            B.check(lib.fc_mask_encoder_create(device.index or 0, C.byref(h)))
+            self._handle, self._handle_device, self._synced = h, device, None
+        ver = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if ver != self._synced:
+            flat = torch.zeros(self._flat_numel, device=device)
+            sd = dict(self.named_parameters())
+            for name, shape, off in self._table:
+                flat[off:off + math.prod(shape)] = sd[name].detach().reshape(-1).to(device)
+            B.check(lib.fc_mask_encoder_load_params(self._handle, flat.data_ptr(), flat.numel(), 1, B.current_stream(device)))
+            torch.cuda.current_stream(device).synchronize()
+            self._synced = ver
+        return self._handle
+
+    def _release(self):
+        if getattr(self, "_handle", None) is not None:
+            B.lib().fc_mask_encoder_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    @torch.no_grad()
+    def forward(self, mask_pixels):
+        if not mask_pixels.is_cuda:
+            raise RuntimeError("flocoder_amd.MaskEncoder runs on MI355X (gfx950) only; there is no CPU path")
+        if mask_pixels.dtype in (torch.uint8, torch.int32, torch.int64, torch.bool):      # inpainting.py:236-237
+            mask_pixels = mask_pixels.float()
+        x = mask_pixels.contiguous().float()
+        bsz, ch, h, w = x.shape
+        if ch != 1:
+            raise ValueError("mask_pixels must have one channel")
+        hnd = self._native(x.device)
+        B.check(B.lib().fc_mask_encoder_reserve(hnd, bsz, h, w))
+        out = torch.empty(bsz, 4, h // 16, w // 16, device=x.device)
+        B.check(B.lib().fc_mask_encoder_forward(hnd, B.ptr(x), B.ptr(out), bsz, h, w, B.current_stream(x.device)))
+        return out
+
+
+def mask_blending(source, mask, noise=None):
+    """inpainting.py:250-253: source + mask*(noise - source)."""
+    if noise is None:
+        noise = torch.randn_like(source)
+    if not source.is_cuda:
+        raise RuntimeError("flocoder_amd.mask_blending runs on MI355X (gfx950) only; there is no CPU path")
+    s, m, n = (t.contiguous().float() for t in (source, mask.expand_as(source), noise))
+    out = torch.empty_like(s)
+    B.check(B.lib().fc_mask_blend(B.ptr(s), B.ptr(m), B.ptr(n), B.ptr(out), s.numel(), B.current_stream(s.device)))
+    return out

@@ -159,6 +159,23 @@ double fc_vae_flops_per_sample(const fc_vae* v, int decode);
 int fc_vae_plan_launches(const fc_vae* v, int decode);
 
 /* ------------------------------------------------------------------------------------------------
+ * Inpainting conditioning  (replaces flocoder/inpainting.py:161-253 MaskEncoder / mask_blending)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct fc_mask_encoder fc_mask_encoder;
+int fc_mask_encoder_create(int device, fc_mask_encoder** out);        /* device < 0: description only */
+void fc_mask_encoder_destroy(fc_mask_encoder* m);
+int fc_mask_encoder_param_count(const fc_mask_encoder* m);            /* names: "layers.0.conv1.weight", ... */
+int64_t fc_mask_encoder_param_numel(const fc_mask_encoder* m);
+int fc_mask_encoder_param_info(const fc_mask_encoder* m, int i, const char** name, int64_t shape[4], int64_t* offset);
+int fc_mask_encoder_load_params(fc_mask_encoder* m, const float* flat, int64_t numel, int on_device, void* stream);
+int fc_mask_encoder_reserve(fc_mask_encoder* m, int max_batch, int height, int width);
+/* MaskEncoder.forward (inpainting.py:235-245): mask_pixels_dev [B,1,H,W] fp32 -> mask_latents_dev [B,4,H/16,W/16]. */
+int fc_mask_encoder_forward(fc_mask_encoder* m, const float* mask_pixels_dev, float* mask_latents_dev, int batch, int height, int width,
+                            void* stream);
+/* mask_blending (inpainting.py:250-253): out = source + mask * (noise - source), elementwise over numel floats. */
+int fc_mask_blend(const float* source_dev, const float* mask_dev, const float* noise_dev, float* out_dev, int64_t numel, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Greedy OT pairing  (replaces flocoder/ot.py:63-84 compute_ot_pairing)
  * ---------------------------------------------------------------------------------------------- */
 /* source_dev/target_dev [B,D] fp32; dist_ws_dev workspace of B*B floats; perm_out_dev [B] int64. */

@@ -140,3 +140,40 @@ def test_ot_pairing_matches_oracle():
         perm, dist = ot_pairing(s.to(dev()), t.to(dev()))
         assert torch.equal(perm.cpu(), fo.ot_pairing_from_distances(dist.cpu()))
         assert sorted(perm.tolist()) == list(range(B))
+
+
+def test_mask_encoder_and_blending_match_reference_goldens():
+    """MaskEncoder / mask_blending through the C ABI vs the golden vectors the reference produced (g8) and the oracle."""
+    from flocoder_amd.inpainting import MaskEncoder, mask_blending
+    from oracle import flow_oracle as fo
+    from oracle.synth import synth_input, synth_state_dict
+    from conftest import load_golden
+    g = load_golden("g8_mask_encoder")
+    me = MaskEncoder()
+    assert {k: list(v.shape) for k, v in me.state_dict().items()} == g["shapes"]
+    sd = synth_state_dict(g["shapes"], 8)
+    me.load_state_dict(sd)
+    me = me.to(dev())
+    mp = (synth_input("g8.mask", (2, 1, 128, 128), 8) > 0.3).float()
+    ml = me(mp.to(dev()))
+    assert ml.shape == (2, 4, 8, 8) and rel_l2(ml.cpu(), g["mask_latents"]) < 1e-5
+    assert rel_l2(me(mp.bool().to(dev())).cpu(), g["mask_latents_bool"]) < 1e-5          # integer / bool masks are cast (inpainting.py:236)
+    src, noise = synth_input("g8.src", (2, 4, 8, 8), 8), synth_input("g8.noise", (2, 4, 8, 8), 8)
+    assert rel_l2(mask_blending(src.to(dev()), ml, noise.to(dev())).cpu(), g["blended"]) < 1e-5
+    # edge cases: all-ones / all-zeros masks (the anchors train_flow.py:362-371 trains against), other sizes, batch 1
+    for val, size in ((1.0, 128), (0.0, 128), (1.0, 64), (0.0, 256)):
+        m = torch.full((1, 1, size, size), val)
+        out = me(m.to(dev())).cpu()
+        assert out.shape == (1, 4, size // 16, size // 16) and rel_l2(out, fo.mask_encoder_forward(sd, m)) < 1e-5
+        assert torch.all(out[:, 0] == val)
+    with pytest.raises(ValueError, match="multiples"):
+        me(torch.zeros(1, 1, 24, 24, device=dev()))
+
+
+def test_ot_python_surface():
+    from flocoder_amd.ot import compute_ot_pairing
+    from oracle import flow_oracle as fo
+    s, t = rnd(32, 4, 8, 8, seed=1), rnd(32, 4, 8, 8, seed=2)
+    perm = compute_ot_pairing(s.to(dev()), t.to(dev()))
+    assert perm.dtype == torch.int64 and perm.device.type == "cuda"
+    assert torch.equal(perm.cpu(), fo.ot_pairing_greedy(s, t))
