@@ -1,0 +1,131 @@
+"""CPU restatement of flocoder's VQVAE codec encode / decode path (codecs.py:150-574), NATTEN-less.
+
+TEST INFRASTRUCTURE ONLY -- see ``oracle/__init__.py``.  Parity status: PINNED for ``encode`` and ``decode`` --
+``tools/make_golden.py`` runs the reference's own ``VQVAE`` (with a stand-in for the absent ``vector_quantize_pytorch``
+package, which neither method calls) on seeded weights and ``tests/test_oracle_golden.py`` holds this file to the result
+(fixture g9).  ``quantize`` (ResidualVQ, third-party, absent) is NOT restated: parity unpinned, out of the first build
+(SURVEY.md 8c).  NATTEN is absent here, so ``attention='natten'`` blocks have no attention (codecs.py:170-175);
+eval mode: dropout is the identity and NoiseInjection is a no-op at noise_strength 0 (codecs.py:229-232).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+
+
+def gn_groups(proposed: int, channels: int) -> int:
+    """codecs.py:34-44."""
+    if channels % proposed == 0:
+        return proposed
+    for c in range(proposed, channels):
+        if channels % c == 0:
+            return c
+    return 1
+
+
+def _conv(sd, n, x, padding=0, stride=1):
+    return F.conv2d(x, sd[n + ".weight"], sd.get(n + ".bias"), stride=stride, padding=padding)
+
+
+def _gn(sd, n, x, proposed, eps=1e-5):
+    c = x.shape[1]
+    return F.group_norm(x, gn_groups(proposed, c), sd[n + ".weight"], sd[n + ".bias"], eps=eps)
+
+
+def attn_block(sd: SD, n: str, x: Tensor) -> Tensor:
+    """AttnBlock, codecs.py:53-89: GroupNorm(32, eps 1e-6), 1x1 q/k/v, softmax(q^T k c^-1/2) over keys, proj_out, residual."""
+    b, c, h, w = x.shape
+    t = F.group_norm(x, gn_groups(32, c), sd[n + ".norm.norm.weight"], sd[n + ".norm.norm.bias"], eps=1e-6)
+    q, k, v = _conv(sd, n + ".q", t), _conv(sd, n + ".k", t), _conv(sd, n + ".v", t)
+    q = q.reshape(b, c, h * w).permute(0, 2, 1)
+    k = k.reshape(b, c, h * w)
+    a = torch.softmax(torch.bmm(q, k) * int(c) ** -0.5, dim=2)
+    o = torch.bmm(v.reshape(b, c, h * w), a.permute(0, 2, 1)).reshape(b, c, h, w)
+    return x + _conv(sd, n + ".proj_out", o)
+
+
+def res_block(sd: SD, n: str, x: Tensor, stride: int = 1) -> Tensor:
+    """EncDecResidualBlock._forward, codecs.py:178-209 (eval): silu(norm1(conv1 x)) [-> attn] -> norm2(conv2 .) + identity -> silu."""
+    out = F.silu(_gn(sd, n + ".norm1", _conv(sd, n + ".conv1", x, padding=1, stride=stride), 8))
+    if (n + ".attn.q.weight") in sd:                       # attention='full'; 'natten' without NATTEN has no attn
+        out = attn_block(sd, n + ".attn", out)
+    out = _gn(sd, n + ".norm2", _conv(sd, n + ".conv2", out, padding=1), 8)
+    if (n + ".downsample.0.weight") in sd:
+        x = _gn(sd, n + ".downsample.1", _conv(sd, n + ".downsample.0", x, stride=stride), 8)
+    return F.silu(out + x)
+
+
+def rope(x: Tensor, scale: float = math.log(10000.0)) -> Tensor:
+    """SpatialNonLocalAttention._apply_rope, codecs.py:351-369, on [b, hw, c]."""
+    b, hw, c = x.shape
+    if c % 2 != 0:
+        x = F.pad(x, (0, 1)); c = x.shape[-1]
+    pos = torch.arange(hw).unsqueeze(1)
+    inv_freq = torch.exp(-torch.arange(0, c // 2) * scale / (c // 2))
+    pe = pos * inv_freq.unsqueeze(0)
+    ps, pc = torch.sin(pe).to(x.dtype), torch.cos(pe).to(x.dtype)
+    xe, xo = x[..., 0::2], x[..., 1::2]
+    out = torch.empty_like(x)
+    out[..., 0::2] = xe * pc - xo * ps
+    out[..., 1::2] = xo * pc + xe * ps
+    return out
+
+
+def spatial_nonlocal_attention(sd: SD, n: str, x: Tensor) -> Tensor:
+    """codecs.py:371-383."""
+    b, c, h, w = x.shape
+    q = rope(_conv(sd, n + ".q_proj", x).reshape(b, -1, h * w).permute(0, 2, 1))
+    k = rope(_conv(sd, n + ".k_proj", x).reshape(b, -1, h * w).permute(0, 2, 1))
+    v = _conv(sd, n + ".v_proj", x).reshape(b, c, h * w).permute(0, 2, 1)
+    a = F.softmax(torch.bmm(q, k.transpose(1, 2)) * (q.size(-1) ** -0.5), dim=-1)
+    o = torch.bmm(a, v).permute(0, 2, 1).reshape(b, c, h, w)
+    return x + _conv(sd, n + ".out_proj", o)
+
+
+def n_downsamples(sd: SD) -> int:
+    blocks = sorted({int(k.split(".")[1]) for k in sd if k.startswith("encoder.") and ".conv1.weight" in k})
+    return (len(blocks) - 1) // 2
+
+
+def encode(sd: SD, x: Tensor) -> Tensor:
+    """VQVAE.encode = self.encoder(x), codecs.py:414-443,492-502: 2 residual blocks per downsample (the first with stride 2), one
+    more to internal_dim, a 1x1 conv, then the compress stack conv1x1 -> GroupNorm -> SiLU -> conv3x3."""
+    nd = n_downsamples(sd)
+    h = x
+    for i in range(nd):
+        h = res_block(sd, f"encoder.{2 * i}", h, stride=2)
+        h = res_block(sd, f"encoder.{2 * i + 1}", h)
+    h = res_block(sd, f"encoder.{2 * nd}", h)
+    h = _conv(sd, f"encoder.{2 * nd + 1}", h)
+    h = _conv(sd, f"encoder.{2 * nd + 2}", h)
+    h = F.silu(_gn(sd, f"encoder.{2 * nd + 3}", h, 2))
+    return _conv(sd, f"encoder.{2 * nd + 5}", h, padding=1)
+
+
+def decode(sd: SD, z: Tensor) -> Tensor:
+    """VQVAE.decode -> Decoder.forward at noise_strength 0, codecs.py:245-316,523-525."""
+    nd = n_downsamples(sd)
+    L = "decoder.layers."
+    i = 0
+    h = z
+    if (L + "0.q_proj.weight") in sd:
+        h = spatial_nonlocal_attention(sd, L + "0", h); i = 1
+    h = _conv(sd, L + str(i), h)
+    emb = z.shape[1]
+    h = F.silu(_gn(sd, L + str(i + 1), h, emb))
+    h = _conv(sd, L + str(i + 3), h)
+    h = res_block(sd, L + str(i + 5), h)                   # i+4 is a NoiseInjection
+    i += 6
+    for _ in range(nd):
+        h = F.pixel_shuffle(F.silu(_conv(sd, L + str(i), h, padding=1)), 2)      # conv, SiLU, PixelShuffle(2), NoiseInjection
+        h = res_block(sd, L + str(i + 4), h)
+        h = res_block(sd, L + str(i + 6), h)                                       # i+5 is a NoiseInjection
+        i += 7
+    h = F.silu(_conv(sd, L + str(i + 1), h, padding=1))   # i is a NoiseInjection
+    return _conv(sd, L + str(i + 4), h, padding=1)        # i+2 SiLU, i+3 NoiseInjection

@@ -119,3 +119,17 @@ def test_g8_mask_encoder():
     assert rel_l2(fo.mask_encoder_forward(sd, mp.bool()), g["mask_latents_bool"]) < TOL
     src, noise = synth_input("g8.src", (2, 4, 8, 8), 8), synth_input("g8.noise", (2, 4, 8, 8), 8)
     assert rel_l2(fo.mask_blending(src, ml, noise), g["blended"]) < TOL
+
+
+@pytest.mark.parametrize("tag,in_ch", [("midi_vqgan", 3), ("gray_nd4_small", 1)])
+def test_g9_vqvae_encode_decode(tag, in_ch):
+    """oracle/vqvae_oracle.py against the reference's own VQVAE.encode / .decode (NATTEN-less, eval)."""
+    from oracle import vqvae_oracle as vq
+    g = load_golden("g9_vqvae")
+    shapes = g[tag + "_shapes"]
+    sd = synth_state_dict(shapes, 9)
+    x = torch.sigmoid(synth_input("g9.x." + tag, (1, in_ch, 128, 128), 9, scale=2.0))
+    z = vq.encode(sd, x)
+    assert tuple(z.shape) == tuple(g[tag + "_z"].shape) and rel_l2(z, g[tag + "_z"]) < 5e-6
+    y = vq.decode(sd, synth_input("g9.z." + tag, tuple(z.shape), 9))
+    assert tuple(y.shape) == (1, in_ch, 128, 128) and rel_l2(y, g[tag + "_recon"]) < 5e-6

@@ -42,13 +42,19 @@ def import_reference():
     _stand_in("flocoder.viz", save_img_grid=None)
     _stand_in("flocoder.metrics", g2rgb=None, compute_sample_metrics=None)
     from flocoder import unet, sampling
+    # vector_quantize_pytorch is absent; VQVAE.__init__ builds a ResidualVQ that encode()/decode() never call
+    class _RVQ(torch.nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+    _stand_in("vector_quantize_pytorch", VectorQuantize=_RVQ, ResidualVQ=_RVQ)
 
     def load(name):
         spec = importlib.util.spec_from_file_location("ref_" + name, os.path.join(REF, "flocoder", name + ".py"))
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
         return mod
-    return unet, sampling, load("ot"), load("inpainting")
+    from flocoder import codecs
+    return unet, sampling, load("ot"), load("inpainting"), codecs
 
 
 def shapes_of(module):
@@ -85,7 +91,7 @@ UNET_CASES = [  # tag, dim, n_classes, mask_cond, B, seed
 @torch.no_grad()
 def main():
     torch.set_num_threads(8)
-    unet, sampling, ot, inpainting = import_reference()
+    unet, sampling, ot, inpainting, codecs = import_reference()
 
     # ---- G0: state_dict layout and default initialisation under a fixed seed -----------------
     g0 = {}
@@ -218,6 +224,25 @@ def main():
     srcl, noise = synth_input("g8.src", (2, 4, 8, 8), 8), synth_input("g8.noise", (2, 4, 8, 8), 8)
     npz("g8_mask_encoder", shapes=shapes, mask_latents=ml, mask_latents_bool=me(mp.bool()),
         blended=inpainting.mask_blending(srcl, ml, noise))
+
+    # ---- G9: VQVAE encode / decode (NATTEN-less), the midi_vqgan.yaml shape and a reduced 4-downsample grayscale one ----
+    import contextlib, io
+    arrays = {}
+    for tag, kw, hw in (("midi_vqgan", dict(in_channels=3, hidden_channels=256, num_downsamples=3, internal_dim=128, vq_embedding_dim=4), 128),
+                        ("gray_nd4_small", dict(in_channels=1, hidden_channels=32, num_downsamples=4, internal_dim=32, vq_embedding_dim=4), 128)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = codecs.VQVAE(vq_num_embeddings=32, codebook_levels=2, no_natten=True, **kw).eval()
+        shapes = {k: list(v.shape) for k, v in m.state_dict().items() if k != "codebook_usage"}
+        sd = synth_state_dict(shapes, 9)
+        m.load_state_dict(sd, strict=False)
+        x = torch.sigmoid(synth_input("g9.x." + tag, (1, kw["in_channels"], hw, hw), 9, scale=2.0))
+        with contextlib.redirect_stdout(io.StringIO()):
+            z = m.encode(x, debug=False)
+            y = m.decode(synth_input("g9.z." + tag, tuple(z.shape), 9))
+        arrays[tag + "_shapes"] = shapes
+        arrays[tag + "_z"] = z
+        arrays[tag + "_recon"] = y
+    npz("g9_vqvae", **arrays)
 
 
 if __name__ == "__main__":
