@@ -62,6 +62,17 @@ SIGNATURES = {
     "fc_vae_decode": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "fc_vae_flops_per_sample": (C.c_double, [_vp, _i]),
     "fc_vae_plan_launches": (_i, [_vp, _i]),
+    "fc_vqvae_create": (_i, [_i, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "fc_vqvae_destroy": (None, [_vp]),
+    "fc_vqvae_param_count": (_i, [_vp]),
+    "fc_vqvae_param_numel": (_i64, [_vp]),
+    "fc_vqvae_param_info": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_i64 * 4), C.POINTER(_i64)]),
+    "fc_vqvae_load_params": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "fc_vqvae_reserve_encode": (_i, [_vp, _i, _i, _i]),
+    "fc_vqvae_reserve_decode": (_i, [_vp, _i, _i, _i]),
+    "fc_vqvae_encode": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "fc_vqvae_decode": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "fc_vqvae_flops_per_sample": (C.c_double, [_vp, _i]),
     "fc_mask_encoder_create": (_i, [_i, C.POINTER(_vp)]),
     "fc_mask_encoder_destroy": (None, [_vp]),
     "fc_mask_encoder_param_count": (_i, [_vp]),

@@ -3,7 +3,7 @@
 ``setup_codec(config, device, no_natten=False, load_checkpoint=True, eval=True)`` returns an object with the protocol the
 flow path consumes: ``encode(x) -> z``, ``decode(z, orig_size=None, noise_strength=0.0) -> x``,
 ``forward(x, noise_strength, minval, get_stats)``, ``in_channels``, ``parameters()``.  The SD codec runs on the gfx950
-library (``fc_vae_*``); there is no CPU path for it.
+library (``fc_vae_*``) and the VQVAE's encode / decode on ``fc_vqvae_*``; there is no CPU path for either.
 """
 from __future__ import annotations
 
@@ -218,6 +218,156 @@ class SD_VAE_Wrapper(nn.Module):
         return float(B.lib().fc_vae_flops_per_sample(self._handle, int(decode))) if self._handle else 0.0
 
 
+class _NoiseInjectionParams(nn.Module):
+    """Parameter holder for NoiseInjection (codecs.py:217-241): a no-op at noise_strength 0, which is all the flow path uses;
+    the tensors exist so reference checkpoints round-trip through ``state_dict``."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.to_noise_scale = nn.Conv2d(channels, channels, 1)
+        self.to_noise_bias = nn.Conv2d(channels, channels, 1)
+        nn.init.zeros_(self.to_noise_scale.weight)
+        nn.init.zeros_(self.to_noise_bias.weight)
+
+
+class VQVAE(nn.Module):
+    """codecs.py:395-574 -- encode / decode on the gfx950 library (``fc_vqvae_*``), NATTEN-less, eval mode.
+
+    Parameters carry the reference's state_dict names (``encoder.0.conv1.weight`` ... ``decoder.layers.0.q_proj.weight`` ...), so
+    ``load_state_dict(ckpt['model_state_dict'], strict=False)`` takes a reference checkpoint as is.  ``quantize`` / ``forward``
+    need ResidualVQ (third-party ``vector_quantize_pytorch``, not restated -- SURVEY.md 8c) and raise NotImplementedError, as does
+    ``decode`` with a non-zero ``noise_strength`` (training-time NoiseInjection)."""
+
+    def __init__(self, in_channels=3, hidden_channels=256, num_downsamples=3, vq_num_embeddings=512, internal_dim=256,
+                 codebook_levels=3, vq_embedding_dim=4, commitment_weight=0.25, use_checkpoint=False, no_natten=False,
+                 encoder_nonlocal=False, decoder_nonlocal=True):
+        super().__init__()
+        if encoder_nonlocal:
+            raise NotImplementedError("VQVAE(encoder_nonlocal=True) is not built (no reference config uses it)")
+        self.in_channels, self.num_downsamples = in_channels, num_downsamples
+        self.codebook_levels, self.vq_num_embeddings = codebook_levels, vq_num_embeddings
+        self.vq_embedding_dim, self.indices, self.info = vq_embedding_dim, None, None
+        self._cfg = (in_channels, hidden_channels, num_downsamples, internal_dim, vq_embedding_dim, int(bool(decoder_nonlocal)))
+        lib = B.lib()
+        h = C.c_void_p()
+        B.check(lib.fc_vqvae_create(*self._cfg, -1, C.byref(h)))
+        try:
+            self._table = []
+            for i in range(lib.fc_vqvae_param_count(h)):
+                name, shape, off = C.c_char_p(), (C.c_int64 * 4)(), C.c_int64()
+                B.check(lib.fc_vqvae_param_info(h, i, C.byref(name), C.byref(shape), C.byref(off)))
+                self._table.append((name.value.decode(), tuple(int(s) for s in shape if s), int(off.value)))
+            self._flat_numel = int(lib.fc_vqvae_param_numel(h))
+        finally:
+            lib.fc_vqvae_destroy(h)
+        for name, shape, _ in self._table:
+            node = self
+            *path, leaf = name.split(".")
+            for part in path:
+                if not hasattr(node, part):
+                    node.add_module(part, _Node())
+                node = getattr(node, part)
+            p = torch.empty(shape, dtype=torch.float32)
+            if leaf == "weight" and len(shape) > 1:                       # nn.Conv2d default init (kaiming_uniform, a=sqrt(5))
+                nn.init.kaiming_uniform_(p, a=math.sqrt(5))
+            elif leaf == "weight":
+                p.fill_(1.0)                                              # GroupNorm
+            else:
+                wname = name[:-4] + "weight"
+                wshape = next(s for n, s, _ in self._table if n == wname)
+                bound = 1.0 / math.sqrt(math.prod(wshape[1:])) if len(wshape) > 1 else 0.0
+                p.uniform_(-bound, bound) if bound else p.zero_()
+            node.register_parameter(leaf, nn.Parameter(p, requires_grad=False))
+        # NoiseInjection tensors of the reference's Decoder (codecs.py:259,283-300): present in checkpoints, unused at strength 0
+        i0 = 1 if decoder_nonlocal else 0
+        cur = hidden_channels * 2 ** (num_downsamples - 1)
+        self.decoder.layers.add_module(str(i0 + 4), _NoiseInjectionParams(cur))
+        i = i0 + 6
+        for lvl in range(num_downsamples - 1, -1, -1):
+            co = hidden_channels * 2 ** max(0, lvl - 1) if lvl else hidden_channels
+            self.decoder.layers.add_module(str(i + 3), _NoiseInjectionParams(cur))
+            self.decoder.layers.add_module(str(i + 5), _NoiseInjectionParams(co))
+            cur, i = co, i + 7
+        self.decoder.layers.add_module(str(i), _NoiseInjectionParams(cur))
+        self.decoder.layers.add_module(str(i + 3), _NoiseInjectionParams(64))
+        self.register_buffer('codebook_usage', torch.zeros(codebook_levels, vq_num_embeddings))
+        self.usage_count = 0
+        self._handle, self._handle_device, self._synced = None, None, None
+
+    def _native(self, device):
+        lib = B.lib()
+        if self._handle is None or self._handle_device != device:
+            self._release()
+            h = C.c_void_p()
+            B.check(lib.fc_vqvae_create(*self._cfg, device.index or 0, C.byref(h)))
+            self._handle, self._handle_device, self._synced = h, device, None
+        sd = dict(self.named_parameters())
+        ver = tuple((sd[n].data_ptr(), sd[n]._version) for n, _, _ in self._table)
+        if ver != self._synced:
+            flat = torch.zeros(self._flat_numel, dtype=torch.float32, device=device)
+            for name, shape, off in self._table:
+                flat[off:off + math.prod(shape)] = sd[name].detach().reshape(-1).to(device)
+            B.check(lib.fc_vqvae_load_params(self._handle, flat.data_ptr(), flat.numel(), 1, B.current_stream(device)))
+            torch.cuda.current_stream(device).synchronize()
+            self._synced = ver
+        return self._handle
+
+    def _release(self):
+        if getattr(self, "_handle", None) is not None:
+            B.lib().fc_vqvae_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    @torch.no_grad()
+    def encode(self, x, debug=False):
+        """z = self.encoder(x) (codecs.py:492-502): [B,in_channels,H,W] -> [B,vq_embedding_dim,H>>nd,W>>nd], pre-quantisation."""
+        if not x.is_cuda:
+            raise RuntimeError("flocoder_amd.VQVAE runs on MI355X (gfx950) only; there is no CPU path")
+        bsz, ch, h, w = x.shape
+        if ch != self.in_channels:
+            raise ValueError(f"VQVAE expects {self.in_channels}-channel input, got {ch}")
+        x = x.contiguous().float()
+        hnd = self._native(x.device)
+        B.check(B.lib().fc_vqvae_reserve_encode(hnd, bsz, h, w))
+        nd = self.num_downsamples
+        out = torch.empty(bsz, self.vq_embedding_dim, h >> nd, w >> nd, device=x.device, dtype=torch.float32)
+        B.check(B.lib().fc_vqvae_encode(hnd, B.ptr(x), B.ptr(out), bsz, h, w, B.current_stream(x.device)))
+        return out
+
+    @torch.no_grad()
+    def decode(self, z_q, noise_strength=0.0):
+        """self.decoder(z_q, noise_strength) (codecs.py:523-525) at noise_strength 0."""
+        if noise_strength:
+            raise NotImplementedError("VQVAE.decode: noise_strength != 0 (training-time NoiseInjection) is not built")
+        if not z_q.is_cuda:
+            raise RuntimeError("flocoder_amd.VQVAE runs on MI355X (gfx950) only; there is no CPU path")
+        bsz, ch, h, w = z_q.shape
+        if ch != self.vq_embedding_dim:
+            raise ValueError(f"VQVAE latents have {self.vq_embedding_dim} channels, got {ch}")
+        z = z_q.contiguous().float()
+        hnd = self._native(z.device)
+        B.check(B.lib().fc_vqvae_reserve_decode(hnd, bsz, h, w))
+        nd = self.num_downsamples
+        out = torch.empty(bsz, self.in_channels, h << nd, w << nd, device=z.device, dtype=torch.float32)
+        B.check(B.lib().fc_vqvae_decode(hnd, B.ptr(z), B.ptr(out), bsz, h, w, B.current_stream(z.device)))
+        return out
+
+    def quantize(self, z, debug=False):
+        raise NotImplementedError("VQVAE.quantize needs ResidualVQ (vector_quantize_pytorch, third-party): not part of this build "
+                                  "(SURVEY.md 8c); run with preencoding.quantize=false")
+
+    def forward(self, x, noise_strength=None, minval=0, get_stats=False):
+        raise NotImplementedError("VQVAE.forward goes through quantize(); use encode()/decode() (the flow path never calls forward)")
+
+    def flops_per_sample(self, decode=True) -> float:
+        return float(B.lib().fc_vqvae_flops_per_sample(self._handle, int(decode))) if self._handle else 0.0
+
+
 def _read_weights(path: str) -> Dict[str, torch.Tensor]:
     path = os.path.expanduser(path)
     if os.path.isdir(path):
@@ -254,10 +404,19 @@ def setup_codec(config, device, no_natten=False, load_checkpoint=True, eval=True
     elif choice == "vqgan_plus":
         raise NotImplementedError("codec 'vqgan_plus' is codec-training territory and outside the flow hot path (SURVEY.md 2)")
     else:
-        # the reference builds its VQVAE here (codecs.py:707-737); that codec is SURVEY 8 row C2, not built yet
-        for key in ('in_channels', 'hidden_channels', 'num_downsamples', 'internal_dim', 'vq_embedding_dim', 'codebook_levels',
-                    'vq_num_embeddings', 'commitment_weight'):
-            ldcfg(config, key, verbose=False)
+        print("Loading VQVAE model")
+        codec = VQVAE(                                                    # codecs.py:707-718
+            in_channels=ldcfg(config, 'in_channels', 3, verbose=False),
+            hidden_channels=ldcfg(config, 'hidden_channels', 256, verbose=False),
+            num_downsamples=ldcfg(config, 'num_downsamples', 3, verbose=False),
+            internal_dim=ldcfg(config, 'internal_dim', 256, verbose=False),
+            vq_embedding_dim=ldcfg(config, 'vq_embedding_dim', 4, verbose=False),
+            codebook_levels=ldcfg(config, 'codebook_levels', 4, verbose=False),
+            vq_num_embeddings=ldcfg(config, 'vq_num_embeddings', 512, verbose=False),
+            commitment_weight=ldcfg(config, 'commitment_weight', 0.5, verbose=False),
+            use_checkpoint=not config.get('no_grad_ckpt', False),
+            no_natten=no_natten,
+        ).to(device)
         if load_checkpoint:
             if 'vqgan_checkpoint' in config:
                 path = config.vqgan_checkpoint
@@ -267,7 +426,12 @@ def setup_codec(config, device, no_natten=False, load_checkpoint=True, eval=True
                 raise ValueError("Could not find codec checkpoint path in config")
             if path.lower() != "sd" and not os.path.exists(path):
                 raise FileNotFoundError(f"Codec checkpoint file {path} not found.")
-        raise NotImplementedError("the VQVAE codec (codecs.py:395-574) is not built yet in this implementation")
+            print(f"Loading codec checkpoint from {path}")
+            try:
+                checkpoint = torch.load(path, map_location=device, weights_only=True)
+            except Exception:
+                checkpoint = torch.load(path, map_location=device, weights_only=False)
+            codec.load_state_dict(checkpoint['model_state_dict'], strict=False)   # strict=False: vq.* / NATTEN keys are ignored
     if eval:
         codec = codec.eval()
     print("Codec model ready")

@@ -233,6 +233,76 @@ int softmax_rows_launch(float* x, long rows, int cols, float scale, hipStream_t 
     return FC_OK;
 }
 
+// SpatialNonLocalAttention (codecs.py:337-383): 1x1 q/k projections to Cr = max(1, C/2) channels (padded to even), rotary position
+// encoding by token index, softmax(q k^T Cp^-1/2) v with v = 1x1 conv C->C, out_proj, residual.  C is the VQ embedding width (4):
+// one thread per query token walks every key with an online softmax; k/v of the sample sit in LDS.   grid (B), 256 threads
+constexpr int RA_MAXC = 8;
+__global__ void __launch_bounds__(256) rope_attn_kernel(const float* x, const float* wq, const float* bq, const float* wk, const float* bk,
+                                                        const float* wv, const float* bv, const float* wo, const float* bo, float* out, int n, int C,
+                                                        int Cr) {
+    extern __shared__ float sm[];       // k [n][Cp] | v [n][C]
+    const int Cp = (Cr + 1) & ~1;
+    float* ks = sm;
+    float* vs = sm + (size_t)n * Cp;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* xb = x + (size_t)b * n * C;
+    const float lscale = logf(10000.0f);
+    auto project_rope = [&](const float* w, const float* bias, const float* xi, int pos, float* o) {
+        float t[RA_MAXC];
+        for (int r = 0; r < Cp; ++r) {
+            float a = 0.f;
+            if (r < Cr) { a = bias[r]; for (int c = 0; c < C; ++c) a += w[r * C + c] * xi[c]; }
+            t[r] = a;
+        }
+        for (int p2 = 0; p2 < Cp / 2; ++p2) {                   // codecs.py:357-368
+            const float ang = (float)pos * expf(-(float)p2 * lscale / (float)(Cp / 2));
+            const float sn = sinf(ang), cs = cosf(ang);
+            o[2 * p2] = t[2 * p2] * cs - t[2 * p2 + 1] * sn;
+            o[2 * p2 + 1] = t[2 * p2 + 1] * cs + t[2 * p2] * sn;
+        }
+    };
+    for (int j = tid; j < n; j += 256) {
+        float xi[RA_MAXC];
+        for (int c = 0; c < C; ++c) xi[c] = xb[(size_t)j * C + c];
+        project_rope(wk, bk, xi, j, ks + (size_t)j * Cp);
+        for (int c = 0; c < C; ++c) { float a = bv[c]; for (int d = 0; d < C; ++d) a += wv[c * C + d] * xi[d]; vs[(size_t)j * C + c] = a; }
+    }
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)Cp);
+    for (int i = tid; i < n; i += 256) {
+        float xi[RA_MAXC], q[RA_MAXC], acc[RA_MAXC];
+        for (int c = 0; c < C; ++c) { xi[c] = xb[(size_t)i * C + c]; acc[c] = 0.f; }
+        project_rope(wq, bq, xi, i, q);
+        float m = -INFINITY, l = 0.f;
+        for (int j = 0; j < n; ++j) {
+            float sdot = 0.f;
+            for (int r = 0; r < Cp; ++r) sdot += q[r] * ks[(size_t)j * Cp + r];
+            sdot *= scale;
+            const float mn = fmaxf(m, sdot), corr = __expf(m - mn), pj = __expf(sdot - mn);
+            l = l * corr + pj;
+            for (int c = 0; c < C; ++c) acc[c] = acc[c] * corr + pj * vs[(size_t)j * C + c];
+            m = mn;
+        }
+        for (int c = 0; c < C; ++c) acc[c] /= l;
+        for (int c = 0; c < C; ++c) {
+            float a = bo[c];
+            for (int d = 0; d < C; ++d) a += wo[c * C + d] * acc[d];
+            out[((size_t)b * n + i) * C + c] = xi[c] + a;
+        }
+    }
+}
+
+int rope_attn_launch(const float* x, const float* wq, const float* bq, const float* wk, const float* bk, const float* wv, const float* bv,
+                     const float* wo, const float* bo, float* out, int B, int n, int C, int Cr, hipStream_t s) {
+    const int Cp = (Cr + 1) & ~1;
+    if (C > RA_MAXC || Cp > RA_MAXC) return fail(FC_E_SHAPE, "rope_attn: more than 8 channels");
+    const size_t lds = (size_t)n * (Cp + C) * sizeof(float);
+    if (lds > 64 * 1024) return fail(FC_E_SHAPE, "rope_attn: too many tokens");
+    hipLaunchKernelGGL(rope_attn_kernel, dim3(B), dim3(256), lds, s, x, wq, bq, wk, bk, wv, bv, wo, bo, out, n, C, Cr);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
 int attn_small_launch(const float* qkv, float* out, int B, int n, int heads, hipStream_t s) {
     if (n > 64) return fail(FC_E_SHAPE, "attn_small: more than 64 tokens");
     hipLaunchKernelGGL(attn_small_kernel, dim3(B * heads), dim3(256), 0, s, qkv, out, n, heads);

@@ -101,6 +101,8 @@ struct FinalizeArgs {       // y = act(gn(h)) + res, optional GroupNorm(1) parti
     const float* h = nullptr;
     SrcXform xf;            // mode 1 or 2 (ss may be null)
     const float* res = nullptr;
+    SrcXform xf_res;        // mode 1: the residual is GroupNorm'ed too (EncDecResidualBlock.downsample, codecs.py:164-167)
+    int act_after_add = 0;  // 1: y = SiLU(gn(h) + res') instead of SiLU(gn(h)) + res   (codecs.py:204-206)
     float* y = nullptr;
     float* stats_out = nullptr;  // G = 1
     int B = 0, HW = 0, C = 0;
@@ -115,6 +117,8 @@ int final_conv_launch(const float* x_nhwc, const float* w /*[Cin][Cout]*/, const
                       int HW, int Cout, hipStream_t s);
 int nchw_to_nhwc_launch(const float* src, float* dst, int B, int C, int HW, int Cpad, int src_batch_mod, hipStream_t s);
 int nhwc_to_nchw_launch(const float* src, float* dst, int B, int C, int HW, int Cpad, hipStream_t s);
+// nn.PixelShuffle(2) on NHWC: src [B][H][W][4C] (channel c*4 + i*2 + j) -> dst [B][2H][2W][C]
+int pixel_shuffle2_nhwc_launch(const float* src, float* dst, int B, int H, int W, int C, hipStream_t s);
 int bilinear_nhwc_launch(const float* src, float* dst, int B, int C, int Hs, int Ws, int Hd, int Wd, hipStream_t s);
 
 struct TembArgs {
@@ -137,6 +141,9 @@ int ss_launch(const float* t, const float* wt, const float* bias, float* ss, int
 int linattn_ctx_launch(const float* qkv, float* ctx /*[B][heads][32][32]*/, int B, int n, int heads, hipStream_t s);
 int linattn_apply_launch(const float* qkv, const float* ctx, float* out /*[B][n][heads*32]*/, int B, int n, int heads,
                          hipStream_t s);
+// SpatialNonLocalAttention (codecs.py:337-383) for a handful of channels: x NHWC [B][n][C] -> x + out_proj(softmax(rope(q) rope(k)^T) v)
+int rope_attn_launch(const float* x, const float* wq, const float* bq, const float* wk, const float* bk, const float* wv, const float* bv,
+                     const float* wo, const float* bo, float* out, int B, int n, int C, int Cr, hipStream_t s);
 // Softmax attention core (unet.py:114-121), n <= 64
 int attn_small_launch(const float* qkv, float* out, int B, int n, int heads, hipStream_t s);
 

@@ -40,10 +40,23 @@ __global__ void __launch_bounds__(256) finalize_kernel(const FinalizeArgs a, int
     float* gm = sm;                 // [G][2]
     float* A = sm + 2 * a.xf.G;     // [C]
     float* Bv = A + a.C;            // [C]
+    float* gr = Bv + a.C;           // [Gres][2], [C], [C]: the same for a normalised residual
+    float* Ar = gr + 2 * (a.xf_res.mode ? a.xf_res.G : 0);
+    float* Br = Ar + (a.xf_res.mode ? a.C : 0);
     __shared__ float red[4];
     const int b = blockIdx.y, tid = threadIdx.x;
     for (int g = tid; g < a.xf.G; g += 256) combine_partials(a.xf, b, g, &gm[2 * g], &gm[2 * g + 1]);
+    if (a.xf_res.mode)
+        for (int g = tid; g < a.xf_res.G; g += 256) combine_partials(a.xf_res, b, g, &gr[2 * g], &gr[2 * g + 1]);
     __syncthreads();
+    if (a.xf_res.mode) {
+        const int cpr = a.C / a.xf_res.G;
+        for (int c = tid; c < a.C; c += 256) {
+            const float s = gr[2 * (c / cpr) + 1] * a.xf_res.gamma[c];
+            Ar[c] = s;
+            Br[c] = a.xf_res.beta[c] - gr[2 * (c / cpr)] * s;
+        }
+    }
     const int cpg = a.C / a.xf.G;
     for (int c = tid; c < a.C; c += 256) {
         const int g = c / cpg;
@@ -61,7 +74,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(const FinalizeArgs a, int
     __syncthreads();
     const int per = a.HW * a.C / bps;  // elements of this block (multiple of 4)
     const size_t base = (size_t)b * a.HW * a.C + (size_t)blockIdx.x * per;
-    const bool act = a.xf.mode == 2;
+    const bool act = a.xf.mode == 2 && !a.act_after_add, act2 = a.act_after_add != 0, nres = a.xf_res.mode != 0;
     float s = 0.f, q = 0.f;
     for (int i = 4 * tid; i < per; i += 1024) {
         const int c = (int)((blockIdx.x * (size_t)per + i) % a.C);
@@ -72,9 +85,11 @@ __global__ void __launch_bounds__(256) finalize_kernel(const FinalizeArgs a, int
         v.w = A[c + 3] * v.w + Bv[c + 3];
         if (act) { v.x = silu_e(v.x); v.y = silu_e(v.y); v.z = silu_e(v.z); v.w = silu_e(v.w); }
         if (a.res) {
-            const float4 r = *reinterpret_cast<const float4*>(a.res + base + i);
+            float4 r = *reinterpret_cast<const float4*>(a.res + base + i);
+            if (nres) { r.x = Ar[c] * r.x + Br[c]; r.y = Ar[c + 1] * r.y + Br[c + 1]; r.z = Ar[c + 2] * r.z + Br[c + 2]; r.w = Ar[c + 3] * r.w + Br[c + 3]; }
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
         }
+        if (act2) { v.x = silu_e(v.x); v.y = silu_e(v.y); v.z = silu_e(v.z); v.w = silu_e(v.w); }
         *reinterpret_cast<float4*>(a.y + base + i) = v;
         s += (v.x + v.y) + (v.z + v.w);
         q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
@@ -102,7 +117,7 @@ int finalize_launch(const FinalizeArgs& a, hipStream_t s) {
     if (a.C & 3) return fail(FC_E_SHAPE, "finalize: C must be a multiple of 4");
     if (!a.xf.mode || !a.xf.stats) return fail(FC_E_ARG, "finalize: needs GroupNorm statistics");
     const int bps = finalize_blocks_per_sample(a.HW, a.C);
-    const size_t lds = (size_t)(2 * a.xf.G + 2 * a.C) * sizeof(float);
+    const size_t lds = (size_t)(2 * a.xf.G + 2 * a.C + (a.xf_res.mode ? 2 * a.xf_res.G + 2 * a.C : 0)) * sizeof(float);
     hipLaunchKernelGGL(finalize_kernel, dim3(bps, a.B), dim3(256), lds, s, a, bps);
     FC_HIP(hipGetLastError());
     return FC_OK;
@@ -231,6 +246,22 @@ int nchw_to_nhwc_launch(const float* src, float* dst, int B, int C, int HW, int 
 }
 int nhwc_to_nchw_launch(const float* src, float* dst, int B, int C, int HW, int Cpad, hipStream_t s) {
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((size_t)B * C * HW)), dim3(256), 0, s, src, dst, B, C, HW, Cpad);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+__global__ void __launch_bounds__(256) pixel_shuffle2_kernel(const float* src, float* dst, int B, int H, int W, int C) {
+    const size_t total = (size_t)B * 4 * H * W * C;          // one thread per destination element
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int X = (int)(r % (2 * W)); r /= 2 * W;
+        const int Y = (int)(r % (2 * H)), b = (int)(r / (2 * H));
+        dst[i] = src[(((size_t)b * H + (Y >> 1)) * W + (X >> 1)) * 4 * C + c * 4 + (Y & 1) * 2 + (X & 1)];
+    }
+}
+int pixel_shuffle2_nhwc_launch(const float* src, float* dst, int B, int H, int W, int C, hipStream_t s) {
+    hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3(grid_for((size_t)B * 4 * H * W * C)), dim3(256), 0, s, src, dst, B, H, W, C);
     FC_HIP(hipGetLastError());
     return FC_OK;
 }

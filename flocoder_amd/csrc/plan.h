@@ -1,6 +1,7 @@
 // Generic pieces of the native runtimes (unet.hip, vae.hip): parameter store with the reference's state_dict names, weight
 // packing, launch plan over a fixed activation arena, and the builder that emits implicit-GEMM launches.
 #pragma once
+#include <cmath>
 #include <functional>
 #include <map>
 #include <string>
@@ -206,6 +207,56 @@ struct PlanBuilder {
             float* sp = st->p; const float* xp = out.p; const int HW = out.H * out.W, C = out.C, G = want_G;
             push([=](const FwdCtx& c, hipStream_t s) { return gn_stats_launch(xp, sp, c.B, HW, C, G, s); }, "gn_stats");
         }
+    }
+
+    // Single-head softmax attention over the h*w tokens of x with d = C (diffusers' VAE mid-block attention, VQGAN's AttnBlock):
+    //   out = proj(softmax(q k^T / sqrt(C)) v) + x,   q/k/v = 1x1 conv of GroupNorm(x)
+    // as three 1x1 convs with the norm in their loader, a batched transpose, two per-sample-weight GEMMs on the conv kernel and a
+    // one-pass row softmax.  w* are packed [Cin][Cout]; want_G > 0 also returns GroupNorm partials of the sum.
+    struct AttnWeights { const float *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo; };
+    Act attention_block(const Act& x, const SrcXform& norm_x, const AttnWeights& w, int want_G, Stat* so) {
+        const int C = x.C, hw = x.H * x.W;
+        Act q = act(C, x.H, x.W), k = act(C, x.H, x.W), vv = act(C, x.H, x.W);
+        const float* ws[3] = {w.wq, w.wk, w.wv};
+        const float* bs[3] = {w.bq, w.bk, w.bv};
+        const Act* outs[3] = {&q, &k, &vv};
+        for (int i = 0; i < 3; ++i) {
+            ConvArgs a;
+            a.s0.p = x.p; a.s0.C = C; a.s0.xf = norm_x;
+            a.Hs = x.H; a.Ws = x.W; a.KS = 1;
+            a.w = ws[i]; a.bias = bs[i];
+            conv(a, *outs[i], 0, nullptr);
+        }
+        float* kt = dmalloc((size_t)B * C * hw);                    // k^T per sample: [C][n]
+        const float* kp = k.p;
+        push([=](const FwdCtx& c, hipStream_t s) { return transpose_batched_launch(kp, kt, c.B, hw, C, s); }, "transpose");
+        Act sc = act(hw, x.H, x.W);                                 // scores [B][n][n]
+        {
+            ConvArgs a;
+            a.s0.p = q.p; a.s0.C = C; a.Hs = x.H; a.Ws = x.W; a.KS = 1;
+            a.w = kt; a.w_batch_stride = C * hw;
+            conv(a, sc, 0, nullptr);
+        }
+        float* sp = sc.p;
+        const float scale = 1.0f / sqrtf((float)C);
+        push([=](const FwdCtx& c, hipStream_t s) { return softmax_rows_launch(sp, (long)c.B * hw, hw, scale, s); }, "softmax_rows");
+        Act o = act(C, x.H, x.W);
+        {
+            ConvArgs a;
+            a.s0.p = sc.p; a.s0.C = hw; a.Hs = x.H; a.Ws = x.W; a.KS = 1;
+            a.w = vv.p; a.w_batch_stride = hw * C;
+            conv(a, o, 0, nullptr);
+        }
+        Act out = act(C, x.H, x.W);
+        {
+            ConvArgs a;
+            a.s0.p = o.p; a.s0.C = C; a.Hs = x.H; a.Ws = x.W; a.KS = 1;
+            a.w = w.wo; a.bias = w.bo;
+            a.add = x.p; a.stats_post = 1;
+            conv(a, out, want_G, so);
+        }
+        release(q); release(k); release(vv); release(sc); release(o);
+        return out;
     }
 };
 

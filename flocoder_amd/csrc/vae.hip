@@ -128,47 +128,9 @@ struct VBuilder : PlanBuilder {
     // mid-block attention: out = to_out(softmax(q k^T / sqrt(C)) v) + x, q/k/v = Linear(GroupNorm(x))
     Act attention(const std::string& n, const Act& x, const Stat& sx, Stat* so) {
         scope = n;
-        const int C = x.C, hw = x.H * x.W;
-        Act q = act(C, x.H, x.W), k = act(C, x.H, x.W), vv = act(C, x.H, x.W);
-        const char* names[3] = {".to_q", ".to_k", ".to_v"};
-        const Act* outs[3] = {&q, &k, &vv};
-        for (int i = 0; i < 3; ++i) {
-            ConvArgs a;
-            a.s0.p = x.p; a.s0.C = C; a.s0.xf = gn(sx, n + ".group_norm", 1);
-            a.Hs = x.H; a.Ws = x.W; a.KS = 1;
-            a.w = v->P(n + names[i] + ".weight"); a.bias = v->R(n + names[i] + ".bias");
-            conv(a, *outs[i], 0, nullptr);
-        }
-        float* kt = dmalloc((size_t)B * C * hw);                    // k^T per sample: [C][n]
-        const float* kp = k.p;
-        push([=](const FwdCtx& c, hipStream_t s) { return transpose_batched_launch(kp, kt, c.B, hw, C, s); }, "transpose");
-        Act sc = act(hw, x.H, x.W);                                 // scores [B][n][n]
-        {
-            ConvArgs a;
-            a.s0.p = q.p; a.s0.C = C; a.Hs = x.H; a.Ws = x.W; a.KS = 1;
-            a.w = kt; a.w_batch_stride = C * hw;
-            conv(a, sc, 0, nullptr);
-        }
-        float* sp = sc.p;
-        const float scale = 1.0f / sqrtf((float)C);
-        push([=](const FwdCtx& c, hipStream_t s) { return softmax_rows_launch(sp, (long)c.B * hw, hw, scale, s); }, "softmax_rows");
-        Act o = act(C, x.H, x.W);
-        {
-            ConvArgs a;
-            a.s0.p = sc.p; a.s0.C = hw; a.Hs = x.H; a.Ws = x.W; a.KS = 1;
-            a.w = vv.p; a.w_batch_stride = hw * C;
-            conv(a, o, 0, nullptr);
-        }
-        Act out = act(C, x.H, x.W);
-        {
-            ConvArgs a;
-            a.s0.p = o.p; a.s0.C = C; a.Hs = x.H; a.Ws = x.W; a.KS = 1;
-            a.w = v->P(n + ".to_out.0.weight"); a.bias = v->R(n + ".to_out.0.bias");
-            a.add = x.p; a.stats_post = 1;
-            conv(a, out, v->groups, so);
-        }
-        release(q); release(k); release(vv); release(sc); release(o);
-        return out;
+        AttnWeights w{v->P(n + ".to_q.weight"), v->R(n + ".to_q.bias"), v->P(n + ".to_k.weight"), v->R(n + ".to_k.bias"),
+                      v->P(n + ".to_v.weight"), v->R(n + ".to_v.bias"), v->P(n + ".to_out.0.weight"), v->R(n + ".to_out.0.bias")};
+        return attention_block(x, gn(sx, n + ".group_norm", 1), w, v->groups, so);
     }
 
     Act mid(const std::string& n, Act x, Stat sx, Stat* so) {

@@ -159,6 +159,30 @@ double fc_vae_flops_per_sample(const fc_vae* v, int decode);
 int fc_vae_plan_launches(const fc_vae* v, int decode);
 
 /* ------------------------------------------------------------------------------------------------
+ * VQVAE codec, encode / decode  (replaces flocoder/codecs.py:386-525 VQVAE.encode / VQVAE.decode with
+ * EncDecResidualBlock :150-214, AttnBlock :53-89, Decoder :217-316, SpatialNonLocalAttention :337-383; no NATTEN, eval)
+ * quantize() (third-party ResidualVQ) is not part of this library.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct fc_vqvae fc_vqvae;
+/* Constructor arguments of VQVAE (codecs.py:399-405); widths must be multiples of 4.  device < 0: description only. */
+int fc_vqvae_create(int in_channels, int hidden_channels, int num_downsamples, int internal_dim, int vq_embedding_dim, int decoder_nonlocal,
+                    int device, fc_vqvae** out);
+void fc_vqvae_destroy(fc_vqvae* v);
+/* Parameter table: the reference's state_dict keys ("encoder.0.conv1.weight", "decoder.layers.0.q_proj.weight", ...). */
+int fc_vqvae_param_count(const fc_vqvae* v);
+int64_t fc_vqvae_param_numel(const fc_vqvae* v);
+int fc_vqvae_param_info(const fc_vqvae* v, int i, const char** name, int64_t shape[4], int64_t* offset);
+int fc_vqvae_load_params(fc_vqvae* v, const float* flat, int64_t numel, int on_device, void* stream);
+/* Plans + arenas.  Images HxW (powers of two), latents (H >> num_downsamples) x (W >> num_downsamples), >= 4 per side. */
+int fc_vqvae_reserve_encode(fc_vqvae* v, int max_batch, int height, int width);
+int fc_vqvae_reserve_decode(fc_vqvae* v, int max_batch, int lat_height, int lat_width);
+/* z = vqvae.encode(x)  (codecs.py:492-502): x_dev [B,in_channels,H,W] -> z_out_dev [B,vq_embedding_dim,h,w] (pre-quantisation). */
+int fc_vqvae_encode(fc_vqvae* v, const float* x_dev, float* z_out_dev, int batch, int height, int width, void* stream);
+/* x = vqvae.decode(z_q)  (codecs.py:523-525, noise_strength 0): z_dev [B,vq_embedding_dim,h,w] -> x_out_dev [B,in_channels,H,W]. */
+int fc_vqvae_decode(fc_vqvae* v, const float* z_dev, float* x_out_dev, int batch, int lat_height, int lat_width, void* stream);
+double fc_vqvae_flops_per_sample(const fc_vqvae* v, int decode);
+
+/* ------------------------------------------------------------------------------------------------
  * Inpainting conditioning  (replaces flocoder/inpainting.py:161-253 MaskEncoder / mask_blending)
  * ---------------------------------------------------------------------------------------------- */
 typedef struct fc_mask_encoder fc_mask_encoder;

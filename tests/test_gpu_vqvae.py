@@ -1,0 +1,69 @@
+"""GPU parity of the VQVAE codec's encode / decode (through the C ABI) against the golden vectors the reference itself produced
+(fixture g9, tools/make_golden.py) and against oracle/vqvae_oracle.py at other batch sizes / resolutions.
+Tolerance rel-L2 <= 2e-5: ~25 stacked fp32 convolutions + GroupNorms; measured values are printed by -s."""
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2
+from oracle import vqvae_oracle as vq
+from oracle.synth import synth_input, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 2e-5
+CFG = {"midi_vqgan": dict(in_channels=3, hidden_channels=256, num_downsamples=3, internal_dim=128, vq_embedding_dim=4),
+       "gray_nd4_small": dict(in_channels=1, hidden_channels=32, num_downsamples=4, internal_dim=32, vq_embedding_dim=4)}
+
+
+def build(tag):
+    from flocoder_amd.codecs import VQVAE
+    g = load_golden("g9_vqvae")
+    sd = synth_state_dict(g[tag + "_shapes"], 9)
+    m = VQVAE(**CFG[tag]).eval()
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and set(missing) <= {"codebook_usage"}
+    return m.to(DEV), sd, g
+
+
+@pytest.mark.parametrize("tag", list(CFG))
+def test_golden_encode_decode(tag):
+    m, sd, g = build(tag)
+    ic = CFG[tag]["in_channels"]
+    x = torch.sigmoid(synth_input("g9.x." + tag, (1, ic, 128, 128), 9, scale=2.0))
+    z = m.encode(x.to(DEV))
+    assert tuple(z.shape) == tuple(g[tag + "_z"].shape)
+    e1 = rel_l2(z.cpu(), g[tag + "_z"])
+    zin = synth_input("g9.z." + tag, tuple(z.shape), 9)
+    y = m.decode(zin.to(DEV))
+    assert tuple(y.shape) == (1, ic, 128, 128)
+    e2 = rel_l2(y.cpu(), g[tag + "_recon"])
+    print(tag, "encode", e1, "decode", e2)
+    assert e1 < TOL and e2 < TOL
+    assert m.flops_per_sample(decode=True) > 0 and m.flops_per_sample(decode=False) > 0
+
+
+def test_batch_and_resolution_vs_oracle():
+    m, sd, _ = build("gray_nd4_small")
+    gen = torch.Generator().manual_seed(3)
+    x = torch.rand(3, 1, 64, 128, generator=gen)
+    z = m.encode(x.to(DEV))
+    assert z.shape == (3, 4, 4, 8) and rel_l2(z.cpu(), vq.encode(sd, x)) < TOL
+    zq = torch.randn(3, 4, 4, 8, generator=gen)
+    y = m.decode(zq.to(DEV))
+    assert y.shape == (3, 1, 64, 128) and rel_l2(y.cpu(), vq.decode(sd, zq)) < TOL
+    assert rel_l2(m.decode(zq[2:3].to(DEV)).cpu(), y[2:3].cpu()) < 1e-5          # batch independence
+    assert torch.equal(m.decode(zq.to(DEV)), y)                                    # bit-reproducible launches
+
+
+def test_protocol_errors():
+    m, _, _ = build("gray_nd4_small")
+    with pytest.raises(NotImplementedError):
+        m.quantize(torch.zeros(1, 4, 8, 8, device=DEV))
+    with pytest.raises(NotImplementedError):
+        m.decode(torch.zeros(1, 4, 8, 8, device=DEV), noise_strength=0.05)
+    with pytest.raises(ValueError):
+        m.encode(torch.zeros(1, 3, 64, 64, device=DEV))
+    with pytest.raises(RuntimeError):
+        m.encode(torch.zeros(1, 1, 64, 64))
+    with pytest.raises(ValueError, match="latent pixels"):                          # latent side < 4: no plan
+        m.encode(torch.zeros(1, 1, 32, 32, device=DEV))
