@@ -133,3 +133,42 @@ def test_g9_vqvae_encode_decode(tag, in_ch):
     assert tuple(z.shape) == tuple(g[tag + "_z"].shape) and rel_l2(z, g[tag + "_z"]) < 5e-6
     y = vq.decode(sd, synth_input("g9.z." + tag, tuple(z.shape), 9))
     assert tuple(y.shape) == (1, in_ch, 128, 128) and rel_l2(y, g[tag + "_recon"]) < 5e-6
+
+
+def test_g10_train_step():
+    """oracle/train_oracle.py against three consecutive training steps of the reference Unet under torch.optim.Adam (step 2
+    without conditioning: class_cond_mlp.* has no gradient and is skipped by Adam).  Gradients: per-tensor sum / abs-sum within
+    1e-4 relative of the abs-sum (fp32 backward, different reduction order); parameters after the step within 2e-6."""
+    from oracle import train_oracle as to
+    g = load_golden("g10_train_step")
+    names = list(g["names"])
+    sd = synth_state_dict(g["shapes"], 10)
+    assert list(sd) == names
+    state = to.new_state(sd)
+    cls = torch.from_numpy(g["cls"])
+    for step in (1, 2, 3):
+        src, tgt = synth_input(f"g10.src{step}", (8, 4, 16, 16), 10), synth_input(f"g10.tgt{step}", (8, 4, 16, 16), 10)
+        t = to.train_time(torch.sigmoid(synth_input(f"g10.u{step}", (8,), 10, scale=1.5)))
+        assert np.array_equal(t.numpy(), g[f"s{step}_t"])
+        cond = {"class_cond": cls, "mask_cond": None} if step != 2 else None
+        loss, grads, v = to.loss_and_grads(sd, src, tgt, t, cond)
+        assert rel_l2(v, g[f"s{step}_v"]) < TOL
+        assert abs(float(loss) - float(g[f"s{step}_loss"])) < 1e-6 * abs(float(g[f"s{step}_loss"]))
+        gsum, gabs = g[f"s{step}_gsum"], g[f"s{step}_gabs"]
+        for i, k in enumerate(names):
+            if np.isnan(gabs[i]):
+                assert grads[k] is None and k.startswith("class_cond_mlp"), k
+                continue
+            assert abs(float(grads[k].double().abs().sum()) - gabs[i]) <= 1e-4 * gabs[i] + 1e-12, k
+            assert abs(float(grads[k].double().sum()) - gsum[i]) <= 1e-4 * gabs[i] + 1e-12, k
+        for k in g["small"]:
+            if f"s{step}_grad_{k}" in g:
+                assert rel_l2(grads[k], g[f"s{step}_grad_{k}"]) < 1e-5, k
+        total = to.adam_ema_step(sd, grads, state)
+        assert abs(float(total) - float(g[f"s{step}_norm"])) < 1e-5 * float(g[f"s{step}_norm"])
+        for i, k in enumerate(names):
+            assert abs(float(sd[k].double().sum()) - g[f"s{step}_psum"][i]) <= 2e-6 * g[f"s{step}_pabs"][i] + 1e-9, k
+            assert abs(float(state["ema"][k].double().sum()) - g[f"s{step}_esum"][i]) <= 2e-6 * g[f"s{step}_eabs"][i] + 1e-9, k
+        for k in g["small"]:
+            assert rel_l2(sd[k], g[f"s{step}_param_{k}"]) < 1e-6, k
+    assert state["step"]["class_cond_mlp.0.weight"] == 2 and state["step"]["init_conv.weight"] == 3

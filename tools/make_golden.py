@@ -244,6 +244,58 @@ def main():
         arrays[tag + "_recon"] = y
     npz("g9_vqvae", **arrays)
 
+    # ---- G10: flow training step (train_flow.py:338-397 restated around the reference Unet, torch autograd, torch.optim.Adam) ----
+    # three consecutive steps on the stl_sd.yaml shape (dim=16, n_classes=10, latents 4x16x16), B=8; step 2 drops the conditioning
+    # (train_flow.py:343-345), so class_cond_mlp.* gets no gradient there and Adam skips it.
+    torch.manual_seed(0)
+    m = unet.Unet(dim=16, channels=4, dim_mults=(1, 2, 4, 8), n_classes=10).train()
+    shapes = load_synth(m, seed=10)
+    B = 8
+    cls = torch.tensor([3, 0, 9, 9, 1, 4, 7, 2])
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    shadow = {k: p.data.clone() for k, p in m.named_parameters()}            # EMA.__init__, train_flow.py:41-44 (decay 0.999, :334)
+    loss_fn = torch.nn.MSELoss()
+    eps = 0.001
+    small = ("final_conv.weight", "final_conv.bias", "init_conv.weight", "class_cond_mlp.0.weight", "time_mlp.1.bias",
+             "downs.0.0.block1.norm.weight", "downs.0.0.mlp.1.bias", "downs.3.2.fn.norm.bias", "mid_attn.fn.fn.to_out.bias",
+             "ups.3.1.block2.proj.bias", "ups.0.2.fn.fn.to_out.1.weight")
+    arrays = {"shapes": shapes, "cls": cls, "small": list(small)}
+    for step in (1, 2, 3):
+      with torch.enable_grad():
+          source = synth_input(f"g10.src{step}", (B, 4, 16, 16), 10)
+          target = synth_input(f"g10.tgt{step}", (B, 4, 16, 16), 10)
+          u = torch.sigmoid(synth_input(f"g10.u{step}", (B,), 10, scale=1.5))
+          cond = {"class_cond": cls, "mask_cond": None} if step != 2 else None
+          opt.zero_grad()
+          t = sampling.warp_time(u * (1 - eps) + eps)
+          t_expand = t.view(-1, 1, 1, 1).repeat(1, target.shape[1], target.shape[2], target.shape[3])
+          x = (1 - t_expand) * source + t_expand * target
+          v_guess = target - source
+          v_model = m(x, t * 999, cond)
+          loss = loss_fn(v_model, v_guess)
+          loss.backward()
+          names = [k for k, _ in m.named_parameters()]
+          gsum = np.array([float("nan") if p.grad is None else float(p.grad.double().sum()) for p in m.parameters()])
+          gabs = np.array([float("nan") if p.grad is None else float(p.grad.double().abs().sum()) for p in m.parameters()])
+          for k, p in m.named_parameters():
+              if k in small and p.grad is not None:
+                  arrays[f"s{step}_grad_{k}"] = p.grad.clone()
+          total = torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=1.0)
+          opt.step()
+          for k, p in m.named_parameters():                                    # EMA.update, train_flow.py:46-54
+              shadow[k] = 0.999 * shadow[k] + (1.0 - 0.999) * p.data
+          arrays.update({f"s{step}_t": t, f"s{step}_loss": loss.detach(), f"s{step}_norm": total, f"s{step}_v": v_model.detach(),
+                         f"s{step}_gsum": gsum, f"s{step}_gabs": gabs,
+                         f"s{step}_psum": np.array([float(p.double().sum()) for p in m.parameters()]),
+                         f"s{step}_pabs": np.array([float(p.double().abs().sum()) for p in m.parameters()]),
+                         f"s{step}_esum": np.array([float(shadow[k].double().sum()) for k in names]),
+                         f"s{step}_eabs": np.array([float(shadow[k].double().abs().sum()) for k in names])})
+          for k, p in m.named_parameters():
+              if k in small:
+                  arrays[f"s{step}_param_{k}"] = p.data.clone()
+    arrays["names"] = names
+    npz("g10_train_step", **arrays)
+
 
 if __name__ == "__main__":
     main()
