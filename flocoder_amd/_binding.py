@@ -50,6 +50,14 @@ SIGNATURES = {
     "fc_debug_copy": (_i, [_vp, _vp, _i64, _vp]),
     "fc_debug_set_conv_stamps": (_i, [_vp]),
     "fc_debug_conv": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _pi, _pf, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _pf, _vp]),
+    "fc_unet_train_reserve": (_i, [_vp, _i, _i, _i]),
+    "fc_unet_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "fc_unet_class_param_range": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "fc_flow_interp": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _vp]),
+    "fc_mse_loss_grad": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "fc_grad_clip_coef": (_i, [_vp, _i64, _vp, _i64, C.c_float, _vp, _vp, _vp]),
+    "fc_adam_ema_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, C.c_float, C.c_float, C.c_float, C.c_float, _i, C.c_float, _i, _vp]),
+    "fc_debug_conv_wgrad": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "fc_vae_create": (_i, [_i, C.POINTER(_vp)]),
     "fc_vae_destroy": (None, [_vp]),
     "fc_vae_param_count": (_i, [_vp]),

@@ -66,3 +66,17 @@ def ot_pairing(source: torch.Tensor, target: torch.Tensor):
     perm = torch.empty(bsz, device=s.device, dtype=torch.int64)
     B.check(B.lib().fc_ot_pairing(B.ptr(s), B.ptr(t), bsz, s.shape[1], B.ptr(dist), B.ptr(perm), B.current_stream(s.device)))
     return perm, dist
+
+
+def conv_wgrad_debug(x0: torch.Tensor, dy: torch.Tensor, ks: int, x1=None, *, pad=0, stride=1, upsample=False):
+    """Weight / bias gradient of one convolution from its NCHW input(s) and NCHW output gradient: (dW [O,I,KH,KW], db [O])."""
+    dev = x0.device
+    bsz, c0, hs, ws = x0.shape
+    c1 = 0 if x1 is None else x1.shape[1]
+    cout = dy.shape[1]
+    x0n, x1n, dyn = _nhwc(x0.float()), _nhwc(None if x1 is None else x1.float()), _nhwc(dy.float())
+    dw = torch.full((cout, c0 + c1, ks, ks), float("nan"), device=dev, dtype=torch.float32)
+    db = torch.full((cout,), float("nan"), device=dev, dtype=torch.float32)
+    B.check(B.lib().fc_debug_conv_wgrad(B.ptr(x0n), c0, B.ptr(x1n), c1, B.ptr(dyn), cout, bsz, hs, ws, ks, pad, stride, int(upsample),
+                                        B.ptr(dw), B.ptr(db), B.current_stream(dev)))
+    return dw, db

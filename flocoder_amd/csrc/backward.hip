@@ -1,0 +1,657 @@
+// Backward kernels of the flow training step (train_flow.py:350-397): everything except the convolution gradients
+// (conv_wgrad.hip; data gradients reuse the forward implicit-GEMM kernel on flipped weights).  All HBM-bound or tiny:
+//   * GroupNorm / FiLM / SiLU backward as a per-(sample, channel) reduction plus one elementwise pass, recomputing the
+//     normalised activation from the raw convolution output and the forward's (mean, M2) partials -- nothing but the raw
+//     tensors the forward keeps anyway is stored;
+//   * LinearAttention / Attention backward (unet.py:99-150);
+//   * the conditioning MLPs (dense layers with <= 256 rows);
+//   * loss, gradient norm, Adam + EMA on flat parameter vectors (reference: torch.optim.Adam, clip_grad_norm_, EMA.update).
+// Every reduction runs in a fixed order (no atomics): a step is bit-reproducible.
+#include <cmath>
+
+#include "common.h"
+#include "stats_dev.h"
+
+namespace fc {
+
+constexpr int DH = 32;
+
+static inline int grid_1d(size_t total, int cap = 4096) {
+    const size_t g = (total + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > (size_t)cap ? cap : g));
+}
+
+// ===================================================================================================
+// GroupNorm (+FiLM, +SiLU) backward.   Forward: u = (gamma*xhat + beta)*(sc+1) + sh,  y = act(u),  xhat = (h - mean)*rstd.
+// Pass 1: s1[b][c] = sum_hw du, s2[b][c] = sum_hw du*xhat with du = dy*act'(u).             grid (ceil(C/32), B)
+__global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const GnBwdArgs a) {
+    __shared__ float r1[8][32], r2[8][32];
+    const int b = blockIdx.y, lane = threadIdx.x & 31, row = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + lane;
+    const bool valid = c < a.C;
+    float s1 = 0.f, s2 = 0.f;
+    if (valid) {
+        const int cpg = a.C / a.xf.G;
+        float mean, rstd;
+        combine_partials(a.xf, b, c / cpg, &mean, &rstd);
+        float A = rstd * a.xf.gamma[c], Bv = a.xf.beta[c] - mean * A;
+        if (a.xf.ss) {
+            const float sc = a.xf.ss[(size_t)b * a.xf.ss_stride + c] + 1.0f;
+            const float sh = a.xf.ss[(size_t)b * a.xf.ss_stride + a.C + c];
+            A *= sc;
+            Bv = Bv * sc + sh;
+        }
+        const bool act = a.xf.mode == 2;
+        const float* hp = a.h + (size_t)b * a.HW * a.C + c;
+        const float* dp = a.dy + (size_t)b * a.HW * a.C + c;
+        for (int p = row; p < a.HW; p += 8) {
+            const float hv = hp[(size_t)p * a.C];
+            float du = dp[(size_t)p * a.C];
+            if (act) du *= silu_grad_e(A * hv + Bv);
+            s1 += du;
+            s2 += du * ((hv - mean) * rstd);
+        }
+    }
+    r1[row][lane] = s1; r2[row][lane] = s2;
+    __syncthreads();
+    if (row == 0 && valid) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { t1 += r1[r][lane]; t2 += r2[r][lane]; }
+        a.s12[((size_t)b * a.C + c) * 2] = t1;
+        a.s12[((size_t)b * a.C + c) * 2 + 1] = t2;
+    }
+}
+
+// Pass 2: dh = rstd * (gamma' du - P1/n - xhat P2/n),  gamma' = gamma (sc+1),  P1 = sum_{c in g} gamma' s1,  P2 = sum gamma' s2.
+// grid (bps, B); dynamic LDS: [G][4] (mean, rstd, k1, k2) | A[C] | Bv[C] | ga[C]
+__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const GnBwdArgs a, int bps) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* gt = sm;
+    float* A = gt + 4 * a.xf.G;
+    float* Bv = A + a.C;
+    float* ga = Bv + a.C;
+    const int b = blockIdx.y, tid = threadIdx.x, cpg = a.C / a.xf.G;
+    for (int g = tid; g < a.xf.G; g += 256) combine_partials(a.xf, b, g, &gt[4 * g], &gt[4 * g + 1]);
+    __syncthreads();
+    for (int c = tid; c < a.C; c += 256) {
+        const int g = c / cpg;
+        const float mean = gt[4 * g], rstd = gt[4 * g + 1];
+        float gam = a.xf.gamma[c];
+        float s = rstd * gam, t = a.xf.beta[c] - mean * s;
+        if (a.xf.ss) {
+            const float sc = a.xf.ss[(size_t)b * a.xf.ss_stride + c] + 1.0f;
+            const float sh = a.xf.ss[(size_t)b * a.xf.ss_stride + a.C + c];
+            s *= sc; t = t * sc + sh; gam *= sc;
+        }
+        A[c] = s; Bv[c] = t; ga[c] = gam * rstd;
+    }
+    __syncthreads();
+    for (int g = tid; g < a.xf.G; g += 256) {
+        float p1 = 0.f, p2 = 0.f;
+        const float rstd = gt[4 * g + 1];
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            const float gp = ga[c] / rstd;     // gamma'
+            p1 += gp * a.s12[((size_t)b * a.C + c) * 2];
+            p2 += gp * a.s12[((size_t)b * a.C + c) * 2 + 1];
+        }
+        const float inv_n = 1.0f / ((float)a.HW * (float)cpg);
+        gt[4 * g + 2] = rstd * p1 * inv_n;
+        gt[4 * g + 3] = rstd * p2 * inv_n;
+    }
+    __syncthreads();
+    const int per = a.HW * a.C / bps;
+    const size_t base = (size_t)b * a.HW * a.C + (size_t)blockIdx.x * per;
+    const bool act = a.xf.mode == 2;
+    for (int i = 4 * tid; i < per; i += 1024) {
+        const int c0 = (int)((blockIdx.x * (size_t)per + i) % a.C);
+        const float4 hv = *reinterpret_cast<const float4*>(a.h + base + i);
+        const float4 dv = *reinterpret_cast<const float4*>(a.dy + base + i);
+        const float hs[4] = {hv.x, hv.y, hv.z, hv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + j, g = c / cpg;
+            float du = ds[j];
+            if (act) du *= silu_grad_e(A[c] * hs[j] + Bv[c]);
+            const float xh = (hs[j] - gt[4 * g]) * gt[4 * g + 1];
+            o[j] = ga[c] * du - gt[4 * g + 2] - xh * gt[4 * g + 3];
+        }
+        float4* dst = reinterpret_cast<float4*>(a.dh + base + i);
+        if (a.accumulate) { const float4 p = *dst; o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w; }
+        *dst = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+int gn_bwd_launch(const GnBwdArgs& a, hipStream_t s) {
+    if (a.C & 3) return fail(FC_E_SHAPE, "gn_bwd: C must be a multiple of 4");
+    if (!a.xf.mode || !a.xf.stats || !a.s12 || !a.dh) return fail(FC_E_ARG, "gn_bwd: needs statistics and workspaces");
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(cdiv(a.C, 32), a.B), dim3(256), 0, s, a);
+    FC_HIP(hipGetLastError());
+    const int bps = finalize_blocks_per_sample(a.HW, a.C);
+    const size_t lds = (size_t)(4 * a.xf.G + 3 * a.C) * sizeof(float);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(bps, a.B), dim3(256), lds, s, a, bps);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+// Parameter gradients of one norm layer from its s12 table: dgamma[c] = sum_b (sc+1) s2, dbeta[c] = sum_b (sc+1) s1, and the
+// FiLM gradients dss[b][c] = gamma s2 + beta s1 (scale), dss[b][C + c] = s1 (shift).      grid (ceil(C/256))
+__global__ void __launch_bounds__(256) norm_param_grads_kernel(const float* s12, const float* gamma, const float* beta, const float* ss,
+                                                               int ss_stride, float* dgamma, float* dbeta, float* dss, int B, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float dg = 0.f, db = 0.f;
+    const float gm = gamma[c], bt = beta[c];
+    for (int b = 0; b < B; ++b) {
+        const float s1 = s12[((size_t)b * C + c) * 2], s2 = s12[((size_t)b * C + c) * 2 + 1];
+        float sc = 1.0f;
+        if (ss) {
+            sc = ss[(size_t)b * ss_stride + c] + 1.0f;
+            dss[(size_t)b * ss_stride + c] = gm * s2 + bt * s1;
+            dss[(size_t)b * ss_stride + C + c] = s1;
+        }
+        dg += sc * s2;
+        db += sc * s1;
+    }
+    dgamma[c] = dg;
+    dbeta[c] = db;
+}
+int norm_param_grads_launch(const float* s12, const float* gamma, const float* beta, const float* ss, int ss_stride, float* dgamma,
+                            float* dbeta, float* dss, int B, int C, hipStream_t s) {
+    hipLaunchKernelGGL(norm_param_grads_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, s12, gamma, beta, ss, ss_stride, dgamma, dbeta, dss, B, C);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+// ===================================================================================================
+// LinearAttention backward (unet.py:137-149).  With p = softmax_d(q_raw), q = p/sqrt(32), k = softmax_n(k_raw):
+//   ctx[d][e] = sum_n k[d][n] v[e][n],  out[e][n] = sum_d ctx[d][e] q[d][n]
+//   dctx[d][e] = sum_n q[d][n] dout[e][n];  dq[d][n] = sum_e ctx[d][e] dout[e][n];  dk[d][n] = sum_e dctx[d][e] v[e][n];
+//   dv[e][n] = sum_d dctx[d][e] k[d][n];   softmax_n backward needs sum_n k dk = sum_e dctx[d][e] ctx[d][e] =: rr[d].
+// Kernel 1, grid (B*heads): column statistics of k_raw, dctx and rr.
+__global__ void __launch_bounds__(256) linattn_bwd_ctx_kernel(const float* qkv, const float* dout, const float* ctx, float* dctx, float* kst,
+                                                              float* rr, int n, int heads) {
+    __shared__ float red[8][DH];
+    __shared__ float kmax[DH];
+    __shared__ float qs[64][DH + 1], ds[64][DH + 1];
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads, tid = threadIdx.x;
+    const int C3 = 3 * heads * DH, CO = heads * DH;
+    const float* qb = qkv + (size_t)b * n * C3 + h * DH;
+    const float* kb = qb + heads * DH;
+    const float* db = dout + (size_t)b * n * CO + h * DH;
+    {
+        const int d = tid & 31, grp = tid >> 5;
+        float m = -INFINITY;
+        for (int i = grp; i < n; i += 8) m = fmaxf(m, kb[(size_t)i * C3 + d]);
+        red[grp][d] = m;
+        __syncthreads();
+        if (tid < DH) {
+            float mm = red[0][tid];
+            for (int g = 1; g < 8; ++g) mm = fmaxf(mm, red[g][tid]);
+            kmax[tid] = mm;
+        }
+        __syncthreads();
+        float z = 0.f;
+        const float km = kmax[d];
+        for (int i = grp; i < n; i += 8) z += __expf(kb[(size_t)i * C3 + d] - km);
+        __syncthreads();
+        red[grp][d] = z;
+        __syncthreads();
+        if (tid < DH) {
+            float zz = 0.f;
+            for (int g = 0; g < 8; ++g) zz += red[g][tid];
+            kst[((size_t)blockIdx.x * DH + tid) * 2] = kmax[tid];
+            kst[((size_t)blockIdx.x * DH + tid) * 2 + 1] = 1.0f / zz;
+        }
+    }
+    const float scale = 0.17677669529663687f;
+    const int d = tid >> 3, e0 = (tid & 7) * 4;
+    const int r = tid >> 2, c8 = (tid & 3) * 8;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        __syncthreads();
+        {
+            float qv[8], dv[8];
+            const bool in = i0 + r < n;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                qv[j] = in ? qb[(size_t)(i0 + r) * C3 + c8 + j] : 0.f;
+                dv[j] = in ? db[(size_t)(i0 + r) * CO + c8 + j] : 0.f;
+            }
+            float m = qv[0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) m = fmaxf(m, qv[j]);
+            m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2));
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { qv[j] = __expf(qv[j] - m); sum += qv[j]; }
+            sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
+            const float f = in ? scale / sum : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { qs[r][c8 + j] = qv[j] * f; ds[r][c8 + j] = dv[j]; }
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int rr_ = 0; rr_ < 64; ++rr_) {
+            const float qd = qs[rr_][d];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += qd * ds[rr_][e0 + j];
+        }
+    }
+    const size_t o = ((size_t)blockIdx.x * DH + d) * DH + e0;
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dctx[o + j] = acc[j]; part += acc[j] * ctx[o + j]; }
+    part += __shfl_xor(part, 1); part += __shfl_xor(part, 2); part += __shfl_xor(part, 4);
+    if ((tid & 7) == 0) rr[(size_t)blockIdx.x * DH + d] = part;
+}
+
+// Kernel 2, grid (ceil(n/pix_per), B), one thread per (pixel, head): dqkv[b][n][3*heads*32].
+__global__ void __launch_bounds__(256) linattn_bwd_apply_kernel(const float* qkv, const float* dout, const float* ctx, const float* dctx,
+                                                                const float* kst, const float* rr, float* dqkv, int n, int heads, int pix_per) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // ctx[heads][32][32] | dctx[...] | kst[heads][32][2] | rr[heads][32]
+    float* cs = sm;
+    float* dcs = cs + heads * DH * DH;
+    float* ks = dcs + heads * DH * DH;
+    float* rs = ks + heads * DH * 2;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int C3 = 3 * heads * DH, CO = heads * DH;
+    for (int i = tid; i < heads * DH * DH; i += 256) { cs[i] = ctx[(size_t)b * heads * DH * DH + i]; dcs[i] = dctx[(size_t)b * heads * DH * DH + i]; }
+    for (int i = tid; i < heads * DH * 2; i += 256) ks[i] = kst[(size_t)b * heads * DH * 2 + i];
+    for (int i = tid; i < heads * DH; i += 256) rs[i] = rr[(size_t)b * heads * DH + i];
+    __syncthreads();
+    const float scale = 0.17677669529663687f;
+    for (int j = tid; j < pix_per * heads; j += 256) {
+        const int h = j % heads, pix = blockIdx.x * pix_per + j / heads;
+        if (pix >= n) continue;
+        const float* base = qkv + ((size_t)b * n + pix) * C3 + h * DH;
+        const float* dop = dout + ((size_t)b * n + pix) * CO + h * DH;
+        float* outp = dqkv + ((size_t)b * n + pix) * C3 + h * DH;
+        const float* ch = cs + h * DH * DH;
+        const float* dch = dcs + h * DH * DH;
+        float p[DH], g[DH];
+        // ---- q: p = softmax_d(q_raw); dq = ctx . dout; dq_raw = p (s dq - sum_d p s dq)
+#pragma unroll
+        for (int i = 0; i < DH; ++i) { p[i] = base[i]; g[i] = dop[i]; }
+        float m = p[0];
+#pragma unroll
+        for (int i = 1; i < DH; ++i) m = fmaxf(m, p[i]);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < DH; ++i) { p[i] = __expf(p[i] - m); sum += p[i]; }
+        const float inv = 1.0f / sum;
+        float dot = 0.f;
+        float dp[DH];
+#pragma unroll
+        for (int d = 0; d < DH; ++d) {
+            float acc = 0.f;
+#pragma unroll
+            for (int e = 0; e < DH; ++e) acc += ch[d * DH + e] * g[e];
+            p[d] *= inv;
+            dp[d] = acc * scale;
+            dot += p[d] * dp[d];
+        }
+#pragma unroll
+        for (int d = 0; d < DH; ++d) outp[d] = p[d] * (dp[d] - dot);
+        // ---- k, v: k = exp(k_raw - max) / Z; dk = dctx . v; dk_raw = k (dk - rr); dv = dctx^T . k
+        const float* kp = base + heads * DH;
+        const float* vp = kp + heads * DH;
+#pragma unroll
+        for (int i = 0; i < DH; ++i) { p[i] = __expf(kp[i] - ks[(h * DH + i) * 2]) * ks[(h * DH + i) * 2 + 1]; g[i] = vp[i]; }
+#pragma unroll
+        for (int d = 0; d < DH; ++d) {
+            float acc = 0.f;
+#pragma unroll
+            for (int e = 0; e < DH; ++e) acc += dch[d * DH + e] * g[e];
+            outp[heads * DH + d] = p[d] * (acc - rs[h * DH + d]);
+        }
+#pragma unroll
+        for (int e = 0; e < DH; ++e) {
+            float acc = 0.f;
+#pragma unroll
+            for (int d = 0; d < DH; ++d) acc += dch[d * DH + e] * p[d];
+            outp[2 * heads * DH + e] = acc;
+        }
+    }
+}
+
+int linattn_bwd_launch(const float* qkv, const float* dout, const float* ctx, float* dctx, float* kst, float* rr, float* dqkv, int B, int n,
+                       int heads, hipStream_t s) {
+    hipLaunchKernelGGL(linattn_bwd_ctx_kernel, dim3(B * heads), dim3(256), 0, s, qkv, dout, ctx, dctx, kst, rr, n, heads);
+    FC_HIP(hipGetLastError());
+    const int pix_per = 256 / heads > 0 ? 256 / heads : 1;
+    const size_t lds = (size_t)(2 * heads * DH * DH + 3 * heads * DH) * sizeof(float);
+    hipLaunchKernelGGL(linattn_bwd_apply_kernel, dim3(cdiv(n, pix_per), B), dim3(256), lds, s, qkv, dout, ctx, dctx, kst, rr, dqkv, n, heads, pix_per);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+// ===================================================================================================
+// Attention backward (unet.py:110-121), n <= 64 tokens.   grid (B*heads), 64 threads (one per token).
+__global__ void __launch_bounds__(64) attn_small_bwd_kernel(const float* qkv, const float* dout, float* dqkv, int n, int heads) {
+    __shared__ float Q[64][DH + 1], K[64][DH + 1], V[64][DH + 1], DO[64][DH + 1];
+    __shared__ float P[64][65], DS[64][65];
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads, i = threadIdx.x;
+    const int C3 = 3 * heads * DH, CO = heads * DH;
+    const float scale = 0.17677669529663687f;
+    if (i < n) {
+        const float* base = qkv + ((size_t)b * n + i) * C3 + h * DH;
+        const float* dop = dout + ((size_t)b * n + i) * CO + h * DH;
+        for (int d = 0; d < DH; ++d) { Q[i][d] = base[d]; K[i][d] = base[heads * DH + d]; V[i][d] = base[2 * heads * DH + d]; DO[i][d] = dop[d]; }
+    }
+    __syncthreads();
+    if (i < n) {
+        float m = -INFINITY;
+        for (int j = 0; j < n; ++j) {
+            float sdot = 0.f;
+            for (int d = 0; d < DH; ++d) sdot += (Q[i][d] * scale) * K[j][d];
+            P[i][j] = sdot;
+            m = fmaxf(m, sdot);
+        }
+        float sum = 0.f;
+        for (int j = 0; j < n; ++j) { const float e = __expf(P[i][j] - m); P[i][j] = e; sum += e; }
+        const float inv = 1.0f / sum;
+        float rd = 0.f;
+        for (int j = 0; j < n; ++j) {
+            const float pj = P[i][j] * inv;
+            float dpj = 0.f;
+            for (int d = 0; d < DH; ++d) dpj += DO[i][d] * V[j][d];
+            P[i][j] = pj;
+            DS[i][j] = dpj;
+            rd += pj * dpj;
+        }
+        for (int j = 0; j < n; ++j) DS[i][j] = P[i][j] * (DS[i][j] - rd);
+        float* outp = dqkv + ((size_t)b * n + i) * C3 + h * DH;
+        for (int d = 0; d < DH; ++d) {
+            float acc = 0.f;
+            for (int j = 0; j < n; ++j) acc += DS[i][j] * K[j][d];
+            outp[d] = acc * scale;
+        }
+    }
+    __syncthreads();
+    if (i < n) {
+        float* outp = dqkv + ((size_t)b * n + i) * C3 + h * DH;
+        for (int d = 0; d < DH; ++d) {
+            float ak = 0.f, av = 0.f;
+            for (int r = 0; r < n; ++r) { ak += DS[r][i] * Q[r][d]; av += P[r][i] * DO[r][d]; }
+            outp[heads * DH + d] = ak * scale;
+            outp[2 * heads * DH + d] = av;
+        }
+    }
+}
+int attn_small_bwd_launch(const float* qkv, const float* dout, float* dqkv, int B, int n, int heads, hipStream_t s) {
+    if (n > 64) return fail(FC_E_SHAPE, "attn_small_bwd: more than 64 tokens");
+    hipLaunchKernelGGL(attn_small_bwd_kernel, dim3(B * heads), dim3(64), 0, s, qkv, dout, dqkv, n, heads);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+// ===================================================================================================
+// Dense layers of the conditioning path (B <= a few hundred rows).  `xpre` is the layer input BEFORE its activation
+// in_act (0 none, 1 GELU(erf), 2 SiLU); weights are the reference's [O][I].
+__device__ __forceinline__ float act_apply(float x, int k) {
+    if (k == 1) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    if (k == 2) return x / (1.0f + expf(-x));
+    return x;
+}
+__device__ __forceinline__ float act_grad(float x, int k) {
+    if (k == 1) return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+    if (k == 2) { const float s = 1.0f / (1.0f + expf(-x)); return s * (1.0f + x * (1.0f - s)); }
+    return 1.0f;
+}
+__global__ void __launch_bounds__(256) dense_fwd_kernel(const float* xpre, int in_act, const float* w, const float* bias, float* y, int B, int I, int O) {
+    const size_t total = (size_t)B * O;
+    for (size_t t = blockIdx.x * 256ull + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        const int o = (int)(t % O), b = (int)(t / O);
+        float acc = bias ? bias[o] : 0.f;
+        for (int i = 0; i < I; ++i) acc += act_apply(xpre[(size_t)b * I + i], in_act) * w[(size_t)o * I + i];
+        y[t] = acc;
+    }
+}
+int dense_fwd_launch(const float* xpre, int in_act, const float* w, const float* bias, float* y, int B, int I, int O, hipStream_t s) {
+    hipLaunchKernelGGL(dense_fwd_kernel, dim3(grid_1d((size_t)B * O)), dim3(256), 0, s, xpre, in_act, w, bias, y, B, I, O);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+// dW[o][i] = sum_b dy[b][o] act(xpre[b][i]);  db[o] = sum_b dy[b][o]      (dy row stride ldy)
+__global__ void __launch_bounds__(256) dense_bwd_w_kernel(const float* dy, int ldy, const float* xpre, int in_act, float* dw, float* db, int B, int I, int O) {
+    const size_t total = (size_t)O * I;
+    for (size_t t = blockIdx.x * 256ull + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        const int i = (int)(t % I), o = (int)(t / I);
+        float acc = 0.f, bs = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float d = dy[(size_t)b * ldy + o];
+            acc += d * act_apply(xpre[(size_t)b * I + i], in_act);
+            bs += d;
+        }
+        dw[t] = acc;
+        if (i == 0 && db) db[o] = bs;
+    }
+}
+int dense_bwd_w_launch(const float* dy, int ldy, const float* xpre, int in_act, float* dw, float* db, int B, int I, int O, hipStream_t s) {
+    hipLaunchKernelGGL(dense_bwd_w_kernel, dim3(grid_1d((size_t)O * I)), dim3(256), 0, s, dy, ldy, xpre, in_act, dw, db, B, I, O);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+// dxpre[b][i] = act'(xpre[b][i]) * sum_o dy[b][o] W[o][i]     (w_t: weights stored [I][ldw] instead of [O][I])
+__global__ void __launch_bounds__(256) dense_bwd_x_kernel(const float* dy, int ldy, const float* w, int w_t, int ldw, const float* xpre, int in_act,
+                                                          float* dx, int accumulate, int B, int I, int O) {
+    const size_t total = (size_t)B * I;
+    for (size_t t = blockIdx.x * 256ull + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        const int i = (int)(t % I), b = (int)(t / I);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const float* dyb = dy + (size_t)b * ldy;
+        int o = 0;
+        if (w_t) {
+            const float* wr = w + (size_t)i * ldw;
+            for (; o + 4 <= O; o += 4) { a0 += dyb[o] * wr[o]; a1 += dyb[o + 1] * wr[o + 1]; a2 += dyb[o + 2] * wr[o + 2]; a3 += dyb[o + 3] * wr[o + 3]; }
+            for (; o < O; ++o) a0 += dyb[o] * wr[o];
+        } else {
+            for (; o + 4 <= O; o += 4) {
+                a0 += dyb[o] * w[(size_t)o * I + i]; a1 += dyb[o + 1] * w[(size_t)(o + 1) * I + i];
+                a2 += dyb[o + 2] * w[(size_t)(o + 2) * I + i]; a3 += dyb[o + 3] * w[(size_t)(o + 3) * I + i];
+            }
+            for (; o < O; ++o) a0 += dyb[o] * w[(size_t)o * I + i];
+        }
+        float v = (a0 + a1) + (a2 + a3);
+        if (xpre) v *= act_grad(xpre[t], in_act);
+        dx[t] = accumulate ? dx[t] + v : v;
+    }
+}
+int dense_bwd_x_launch(const float* dy, int ldy, const float* w, int w_t, int ldw, const float* xpre, int in_act, float* dx, int accumulate,
+                       int B, int I, int O, hipStream_t s) {
+    hipLaunchKernelGGL(dense_bwd_x_kernel, dim3(grid_1d((size_t)B * I)), dim3(256), 0, s, dy, ldy, w, w_t, ldw, xpre, in_act, dx, accumulate, B, I, O);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+// sinusoidal embedding rows (unet.py:24-29) and class-embedding gather / scatter
+__global__ void __launch_bounds__(256) sin_emb_kernel(const float* time, const float* freqs, float* e, int B, int dim) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= B * dim) return;
+    const int i = t % dim, b = t / dim, half = dim / 2;
+    const float arg = time[b] * freqs[i < half ? i : i - half];
+    e[t] = i < half ? sinf(arg) : cosf(arg);
+}
+int sin_emb_launch(const float* time, const float* freqs, float* e, int B, int dim, hipStream_t s) {
+    hipLaunchKernelGGL(sin_emb_kernel, dim3(cdiv(B * dim, 256)), dim3(256), 0, s, time, freqs, e, B, dim);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+__global__ void __launch_bounds__(256) gather_rows_kernel(const float* table, const int64_t* ids, float* out, int B, int D) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= B * D) return;
+    out[t] = table[(size_t)ids[t / D] * D + t % D];
+}
+int gather_rows_launch(const float* table, const int64_t* ids, float* out, int B, int D, hipStream_t s) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(B * D, 256)), dim3(256), 0, s, table, ids, out, B, D);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+// dtable[r][k] = sum over rows b with ids[b] == r of d[b][k], in batch order
+__global__ void __launch_bounds__(256) scatter_rows_kernel(const float* d, const int64_t* ids, float* dtable, int B, int D, int R) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= R * D) return;
+    const int k = t % D, r = t / D;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) if (ids[b] == r) acc += d[(size_t)b * D + k];
+    dtable[t] = acc;
+}
+int scatter_rows_launch(const float* d, const int64_t* ids, float* dtable, int B, int D, int R, hipStream_t s) {
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv(R * D, 256)), dim3(256), 0, s, d, ids, dtable, B, D, R);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+// ===================================================================================================
+// Elementwise helpers
+__global__ void __launch_bounds__(256) axpy_kernel(float* dst, const float* src, size_t n4) {
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 a = reinterpret_cast<float4*>(dst)[i];
+        const float4 b = reinterpret_cast<const float4*>(src)[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        reinterpret_cast<float4*>(dst)[i] = a;
+    }
+}
+int add_into_launch(float* dst, const float* src, size_t n, hipStream_t s) {
+    if (n & 3) return fail(FC_E_SHAPE, "add_into: length must be a multiple of 4");
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_1d(n / 4)), dim3(256), 0, s, dst, src, n / 4);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+// nearest x2 backward: dst[b][y][x][c] (+)= sum of the 2x2 block of src [B][2H][2W][C]
+__global__ void __launch_bounds__(256) sumpool2_kernel(const float* src, float* dst, int B, int H, int W, int C, int accumulate) {
+    const size_t total = (size_t)B * H * W * C;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H), b = (int)(r / H);
+        const float* p = src + (((size_t)b * 2 * H + 2 * y) * 2 * W + 2 * x) * C + c;
+        const float v = (p[0] + p[C]) + (p[(size_t)2 * W * C] + p[(size_t)2 * W * C + C]);
+        dst[i] = accumulate ? dst[i] + v : v;
+    }
+}
+int sumpool2_nhwc_launch(const float* src, float* dst, int B, int H, int W, int C, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(sumpool2_kernel, dim3(grid_1d((size_t)B * H * W * C)), dim3(256), 0, s, src, dst, B, H, W, C, accumulate);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+// space-to-depth backward: src [B][H][W][4C] (channel c*4 + i*2 + j) -> dst [B][2H][2W][C] (+)=
+__global__ void __launch_bounds__(256) depth_to_space_kernel(const float* src, float* dst, int B, int H, int W, int C, int accumulate) {
+    const size_t total = (size_t)B * 4 * H * W * C;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int X = (int)(r % (2 * W)); r /= 2 * W;
+        const int Y = (int)(r % (2 * H)), b = (int)(r / (2 * H));
+        const float v = src[(((size_t)b * H + (Y >> 1)) * W + (X >> 1)) * 4 * C + c * 4 + (Y & 1) * 2 + (X & 1)];
+        dst[i] = accumulate ? dst[i] + v : v;
+    }
+}
+int depth_to_space_launch(const float* src, float* dst, int B, int H, int W, int C, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(depth_to_space_kernel, dim3(grid_1d((size_t)B * 4 * H * W * C)), dim3(256), 0, s, src, dst, B, H, W, C, accumulate);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+// ===================================================================================================
+// Flow-matching step pieces (train_flow.py:350-358,392-397)
+// x = (1 - t) s + t g ; v* = g - s      with t per sample
+__global__ void __launch_bounds__(256) flow_interp_kernel(const float* src, const float* tgt, const float* t, float* x, float* v, size_t total, int per) {
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const float tt = t[i / per], s = src[i], g = tgt[i];
+        x[i] = (1.0f - tt) * s + tt * g;
+        v[i] = g - s;
+    }
+}
+int flow_interp_launch(const float* src, const float* tgt, const float* t, float* x, float* v, int B, int per, hipStream_t s) {
+    const size_t total = (size_t)B * per;
+    hipLaunchKernelGGL(flow_interp_kernel, dim3(grid_1d(total)), dim3(256), 0, s, src, tgt, t, x, v, total, per);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+constexpr int kRedBlocks = 256;
+// loss = mean((v - v*)^2) ; dv = 2 (v - v*) / n.    ws: kRedBlocks floats
+__global__ void __launch_bounds__(256) mse_partial_kernel(const float* v, const float* tgt, float* dv, float* ws, size_t n, float two_over_n) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float d = v[i] - tgt[i];
+        acc += d * d;
+        if (dv) dv[i] = d * two_over_n;
+    }
+    const float tot = block_sum(acc, red);
+    if (threadIdx.x == 0) ws[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(256) mse_final_kernel(const float* ws, float* loss, float inv_n) {
+    __shared__ float red[4];
+    const float tot = block_sum(ws[threadIdx.x], red);
+    if (threadIdx.x == 0) *loss = tot * inv_n;
+}
+int mse_loss_grad_launch(const float* v, const float* tgt, float* dv, float* loss, float* ws, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(kRedBlocks), dim3(256), 0, s, v, tgt, dv, ws, n, 2.0f / (float)n);
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, s, ws, loss, 1.0f / (float)n);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+// clip_grad_norm_: norm = sqrt(sum g^2) over the ranges given; coef = min(1, max_norm / (norm + 1e-6)).   out: {norm, coef}
+__global__ void __launch_bounds__(256) sumsq_partial_kernel(const float* g, size_t n0, const float* g2, size_t n1, float* ws) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n0; i += (size_t)gridDim.x * 256) acc += g[i] * g[i];
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n1; i += (size_t)gridDim.x * 256) acc += g2[i] * g2[i];
+    const float tot = block_sum(acc, red);
+    if (threadIdx.x == 0) ws[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(256) clip_final_kernel(const float* ws, float* out, float max_norm) {
+    __shared__ float red[4];
+    const float tot = block_sum(ws[threadIdx.x], red);
+    if (threadIdx.x == 0) {
+        const float norm = sqrtf(tot);
+        out[0] = norm;
+        out[1] = fminf(max_norm / (norm + 1e-6f), 1.0f);
+    }
+}
+int grad_clip_coef_launch(const float* g, size_t n0, const float* g2, size_t n1, float max_norm, float* out2, float* ws, hipStream_t s) {
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(kRedBlocks), dim3(256), 0, s, g, n0, g2, n1, ws);
+    hipLaunchKernelGGL(clip_final_kernel, dim3(1), dim3(256), 0, s, ws, out2, max_norm);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+// Adam as torch.optim.Adam computes it (no weight decay, no amsgrad), on g*coef, followed by the EMA recurrence of train_flow.py:46-54.
+__global__ void __launch_bounds__(256) adam_ema_kernel(float* p, const float* g, float* m, float* v, float* ema, size_t n, const float* coef_ptr,
+                                                       float lr_over_bc1, float b1, float b2, float inv_sqrt_bc2, float eps, float decay,
+                                                       float one_minus_decay, int do_adam) {
+    const float coef = coef_ptr ? *coef_ptr : 1.0f;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float pv = p[i];
+        if (do_adam) {
+            const float gv = g[i] * coef;
+            float mv = m[i], vv = v[i];
+            mv = mv + (gv - mv) * (1.0f - b1);                 // lerp_
+            vv = vv * b2 + (1.0f - b2) * gv * gv;              // mul_ + addcmul_
+            const float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
+            pv = pv - lr_over_bc1 * (mv / denom);
+            m[i] = mv; v[i] = vv; p[i] = pv;
+        }
+        if (ema) ema[i] = decay * ema[i] + one_minus_decay * pv;
+    }
+}
+int adam_ema_launch(float* p, const float* g, float* m, float* v, float* ema, size_t n, const float* coef_dev, float lr, float b1, float b2,
+                    float eps, int step, float ema_decay, int do_adam, hipStream_t s) {
+    if (!n) return FC_OK;
+    const double bc1 = 1.0 - std::pow((double)b1, step), bc2 = 1.0 - std::pow((double)b2, step);
+    const float lr_over_bc1 = do_adam ? (float)((double)lr / bc1) : 0.f;
+    const float inv_sqrt_bc2 = do_adam ? (float)(1.0 / std::sqrt(bc2)) : 0.f;
+    hipLaunchKernelGGL(adam_ema_kernel, dim3(grid_1d(n, 2048)), dim3(256), 0, s, p, g, m, v, ema, n, coef_dev, lr_over_bc1, b1, b2, inv_sqrt_bc2,
+                       eps, ema_decay, (float)(1.0 - (double)ema_decay), do_adam);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+}  // namespace fc

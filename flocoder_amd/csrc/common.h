@@ -166,6 +166,8 @@ int ode_rk4_final_launch(const float* sc, float* y, const float* k1, const float
 int pack_conv_launch(const float* oihw, float* dst /*[KK][I][O]*/, int O, int I, int KH, int KW, hipStream_t s);
 // same with zero padding of either channel count: dst [KK][Ipad][Opad]
 int pack_conv_pad_launch(const float* oihw, float* dst, int O, int I, int KK, int Opad, int Ipad, hipStream_t s);
+// operand of the data-gradient pass (forward kernel on dY): [taps flipped][O][nci] for input channels ci0..ci0+nci
+int pack_conv_dgrad_launch(const float* oihw, float* dst, int O, int I, int KS, int ci0, int nci, hipStream_t s);
 // [B][rows][cols] -> [B][cols][rows]
 int transpose_batched_launch(const float* src, float* dst, int B, int rows, int cols, hipStream_t s);
 // in place: x[r][:] = softmax(scale * x[r][:]) for `rows` rows of `cols` floats
@@ -173,6 +175,53 @@ int softmax_rows_launch(float* x, long rows, int cols, float scale, hipStream_t 
 int pack_s2d_conv_launch(const float* oi, float* dst /*[4][C][O]*/, int O, int C, hipStream_t s);  // Downsample: (c p1 p2) -> 2x2 s2
 int pack_transpose_launch(const float* src /*[R][Cc]*/, float* dst /*[Cc][R]*/, int R, int Cc, int dst_ld, int dst_col0,
                           hipStream_t s);
+
+// ---- training step (conv_wgrad.hip, backward.hip) ----------------------------------------------
+struct WgradArgs {          // dW[co][ci][ky][kx] (+ db[co]) of a convolution from its input and its output gradient
+    const float* x0 = nullptr; int C0 = 0;     // NHWC sources [B][Hs][Ws][C] (x1: second half of a channel concat)
+    const float* x1 = nullptr; int C1 = 0;
+    const float* dy = nullptr;                 // NHWC [B][H][W][Cout]
+    float* dw = nullptr;                       // [Cout][Cin][KS][KS]
+    float* db = nullptr;                       // [Cout] or null
+    float* ws = nullptr; size_t ws_floats = 0; // split-reduction workspace
+    int B = 0, H = 0, W = 0, Hs = 0, Ws = 0, Cin = 0, Cout = 0, KS = 1, pad = 0, stride = 1, ups = 0;
+};
+int conv_wgrad_init();
+size_t conv_wgrad_workspace(const WgradArgs& a);
+int conv_wgrad_launch(const WgradArgs& a, hipStream_t s);
+
+struct GnBwdArgs {          // backward of y = act((gamma xhat + beta)(sc+1) + sh); xf describes the forward (mode 1: no act, 2: SiLU)
+    const float* dy = nullptr;  // NHWC [B][HW][C]
+    const float* h = nullptr;   // raw normalised tensor (the convolution output)
+    SrcXform xf;
+    float* s12 = nullptr;       // [B][C][2]: per-channel sums of du and du*xhat (kept for norm_param_grads_launch)
+    float* dh = nullptr;        // NHWC [B][HW][C]
+    int accumulate = 0;         // dh += instead of dh =
+    int B = 0, HW = 0, C = 0;
+};
+int gn_bwd_launch(const GnBwdArgs& a, hipStream_t s);
+int norm_param_grads_launch(const float* s12, const float* gamma, const float* beta, const float* ss, int ss_stride, float* dgamma,
+                            float* dbeta, float* dss, int B, int C, hipStream_t s);
+int linattn_bwd_launch(const float* qkv, const float* dout, const float* ctx, float* dctx, float* kst, float* rr, float* dqkv, int B, int n,
+                       int heads, hipStream_t s);
+int attn_small_bwd_launch(const float* qkv, const float* dout, float* dqkv, int B, int n, int heads, hipStream_t s);
+// dense layers of the conditioning path; in_act: 0 none, 1 GELU(erf), 2 SiLU applied to `xpre` on the way in
+int dense_fwd_launch(const float* xpre, int in_act, const float* w, const float* bias, float* y, int B, int I, int O, hipStream_t s);
+int dense_bwd_w_launch(const float* dy, int ldy, const float* xpre, int in_act, float* dw, float* db, int B, int I, int O, hipStream_t s);
+int dense_bwd_x_launch(const float* dy, int ldy, const float* w, int w_t, int ldw, const float* xpre, int in_act, float* dx, int accumulate,
+                       int B, int I, int O, hipStream_t s);
+int sin_emb_launch(const float* time, const float* freqs, float* e, int B, int dim, hipStream_t s);
+int gather_rows_launch(const float* table, const int64_t* ids, float* out, int B, int D, hipStream_t s);
+int scatter_rows_launch(const float* d, const int64_t* ids, float* dtable, int B, int D, int R, hipStream_t s);
+int add_into_launch(float* dst, const float* src, size_t n, hipStream_t s);
+int sumpool2_nhwc_launch(const float* src, float* dst, int B, int H, int W, int C, int accumulate, hipStream_t s);
+int depth_to_space_launch(const float* src, float* dst, int B, int H, int W, int C, int accumulate, hipStream_t s);
+int flow_interp_launch(const float* src, const float* tgt, const float* t, float* x, float* v, int B, int per, hipStream_t s);
+int mse_loss_grad_launch(const float* v, const float* tgt, float* dv, float* loss, float* ws /*256*/, size_t n, hipStream_t s);
+int grad_clip_coef_launch(const float* g, size_t n0, const float* g2, size_t n1, float max_norm, float* out2 /*{norm, coef}*/, float* ws /*256*/,
+                          hipStream_t s);
+int adam_ema_launch(float* p, const float* g, float* m, float* v, float* ema, size_t n, const float* coef_dev, float lr, float b1, float b2,
+                    float eps, int step, float ema_decay, int do_adam, hipStream_t s);
 
 // ---- OT (ot.hip) ------------------------------------------------------------------------------
 int ot_launch(const float* src, const float* tgt, int B, int64_t D, float* dist, int64_t* perm, hipStream_t s);

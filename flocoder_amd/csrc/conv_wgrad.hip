@@ -1,0 +1,220 @@
+// Weight gradient of a convolution on the exact-fp32 matrix pipe:
+//     dW[co][ci][ky][kx] = sum over (b, y, x) of X[b][y*stride - pad + ky][x*stride - pad + kx][ci] * dY[b][y][x][co]
+// One GEMM per tap with M = ci, N = co and the output pixels as the reduction axis.  A workgroup owns a 32(ci) x 32(co) block
+// of every tap and walks a strided share of the pixel tiles (the forward kernel's tile geometry: TB samples x TH x TW pixels,
+// patch with halo staged once in LDS, taps as constant LDS offsets); its four waves split the taps (or, for 1x1, the pixels).
+// Partial sums of the `nsplit` workgroups that share a block go to a workspace and are added in a fixed order by a second
+// kernel -- no atomics, so gradients are bit-reproducible.  The result is written in the reference's own [O][I][KH][KW] layout
+// (for Downsample's space-to-depth conv that is exactly its [O][4*I][1][1] weight, unet.py:49-54), the bias gradient rides along.
+#include "common.h"
+
+namespace fc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgradDev {
+    WgradArgs a;
+    int BM, TWl, THl, TB, PH, PW, P;
+    int tiles_x, tiles_y, mtiles, nsplit, nci, nco;
+    int o_ys, o_pix;          // LDS offsets (floats)
+    size_t part_stride;       // floats per split in the workspace
+};
+
+constexpr int CS = 33;
+
+template <int KS>
+__global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradDev p) {
+    constexpr int KK = KS * KS, TPW = KS == 1 ? 1 : (KK + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;
+    float* ys = smem + p.o_ys;
+    int* pixbase = reinterpret_cast<int*>(smem + p.o_pix);
+    const WgradArgs& a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int split = blockIdx.x, cic = blockIdx.y % p.nci, coc = blockIdx.y / p.nci;
+    const int ci0 = cic * 32, co0 = coc * 32;
+    const int TW = 1 << p.TWl, TH = 1 << p.THl, BM = p.BM;
+    const int Hin = a.ups ? 2 * a.Hs : a.Hs, Win = a.ups ? 2 * a.Ws : a.Ws;
+    if (tid < BM) {
+        const int tw = tid & (TW - 1), th = (tid >> p.TWl) & (TH - 1), tb = tid >> (p.TWl + p.THl);
+        pixbase[tid] = (tb * p.PH * p.PW + th * a.stride * p.PW + tw * a.stride) * CS;
+    }
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;
+    const int phw = p.PH * p.PW;
+    for (int tile = split; tile < p.mtiles; tile += p.nsplit) {
+        const int txi = tile % p.tiles_x, tyi = (tile / p.tiles_x) % p.tiles_y, tbi = tile / (p.tiles_x * p.tiles_y);
+        const int b0 = tbi * p.TB, y0 = tyi * TH, x0 = txi * TW;
+        __syncthreads();
+        for (int idx = tid; idx < p.P * 8; idx += 256) {
+            const int pix = idx >> 3, q = idx & 7, c = ci0 + q * 4;
+            const int tb = pix / phw, rem = pix - tb * phw, py = rem / p.PW, px = rem - py * p.PW;
+            const int iy = y0 * a.stride - a.pad + py, ix = x0 * a.stride - a.pad + px, b = b0 + tb;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b < a.B && c < a.Cin && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
+                const int sy = a.ups ? iy >> 1 : iy, sx = a.ups ? ix >> 1 : ix;
+                const size_t pixoff = ((size_t)b * a.Hs + sy) * a.Ws + sx;
+                const float* src = c < a.C0 ? a.x0 + pixoff * a.C0 + c : a.x1 + pixoff * a.C1 + (c - a.C0);
+                v = *reinterpret_cast<const float4*>(src);
+            }
+            float* d = xs + pix * CS + q * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        for (int idx = tid; idx < BM * 8; idx += 256) {
+            const int m = idx >> 3, q = idx & 7, co = co0 + q * 4;
+            const int tw = m & (TW - 1), th = (m >> p.TWl) & (TH - 1), tb = m >> (p.TWl + p.THl);
+            const int b = b0 + tb;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b < a.B && co < a.Cout) v = *reinterpret_cast<const float4*>(a.dy + (((size_t)b * a.H + y0 + th) * a.W + x0 + tw) * a.Cout + co);
+            float* d = ys + m * CS + q * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+        if (a.db && cic == 0 && tid < 32)
+            for (int m = 0; m < BM; ++m) bsum += ys[m * CS + tid];
+        if (KS == 1) {
+            const int per = BM / 8;                      // k-steps (pixel pairs) per wave
+            for (int j = wave * per; j < (wave + 1) * per; ++j) {
+                const int pk = 2 * j + half;
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[pixbase[pk] + l31], ys[pk * CS + l31], acc[0], 0, 0, 0);
+            }
+        } else {
+            for (int j = 0; j < BM / 2; ++j) {
+                const int pk = 2 * j + half, pb = pixbase[pk];
+                const float bv = ys[pk * CS + l31];
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) {
+                    const int tap = wave + 4 * t;
+                    if (tap < KK) {
+                        const int ky = tap / KS, kx = tap % KS;
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[pb + (ky * p.PW + kx) * CS + l31], bv, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (KS == 1) {    // the four waves hold partial sums over different pixels of the same block
+        __syncthreads();
+        if (wave > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xs[((wave - 1) * 16 + r) * 64 + lane] = acc[0][r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            for (int w = 0; w < 3; ++w)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][r] += xs[(w * 16 + r) * 64 + lane];
+        }
+    }
+    float* dst = p.nsplit > 1 ? a.ws + (size_t)split * p.part_stride : a.dw;
+    const int co = co0 + l31;
+    if (co < a.Cout) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int tap = KS == 1 ? 0 : wave + 4 * t;
+            if (tap < KK && (KS != 1 || wave == 0)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (ci < a.Cin) dst[((size_t)co * a.Cin + ci) * KK + tap] = acc[t][r];
+                }
+            }
+        }
+    }
+    if (a.db && cic == 0 && tid < 32 && co0 + tid < a.Cout) {
+        float* bd = p.nsplit > 1 ? a.ws + (size_t)split * p.part_stride + (size_t)a.Cout * a.Cin * KK : a.db;
+        bd[co0 + tid] = bsum;
+    }
+}
+
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* ws, int nsplit, size_t stride, float* dw, size_t nw, float* db, int nb) {
+    const size_t total = nw + (db ? nb : 0);
+    for (size_t e = blockIdx.x * 256ull + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        float acc = 0.f;
+        for (int s = 0; s < nsplit; ++s) acc += ws[(size_t)s * stride + e];
+        if (e < nw) dw[e] = acc;
+        else db[e - nw] = acc;
+    }
+}
+
+static int wgrad_geometry(const WgradArgs& a, WgradDev* d) {
+    if (!is_pow2(a.H) || !is_pow2(a.W)) return fail(FC_E_SHAPE, "wgrad: H and W must be powers of two");
+    if ((a.C0 & 3) || (a.C1 & 3) || (a.Cout & 3) || a.C0 + a.C1 != a.Cin) return fail(FC_E_SHAPE, "wgrad: channel counts must be multiples of 4");
+    if (a.KS != 1 && a.KS != 2 && a.KS != 3 && a.KS != 5) return fail(FC_E_SHAPE, "wgrad: kernel size not instantiated");
+    WgradDev& p = *d;
+    p.a = a;
+    for (p.BM = 128;; p.BM = 32) {
+        const int TW = a.W < 16 ? a.W : 16;
+        int TH = p.BM / TW;
+        if (TH > a.H) TH = a.H;
+        p.TB = p.BM / (TH * TW);
+        p.TWl = ilog2(TW); p.THl = ilog2(TH);
+        p.PH = TH * a.stride + a.KS - a.stride;
+        p.PW = TW * a.stride + a.KS - a.stride;
+        p.P = p.TB * p.PH * p.PW;
+        p.tiles_x = a.W / TW; p.tiles_y = a.H / TH;
+        if (p.P <= 640 || p.BM == 32) break;
+    }
+    if (p.P > 1024) return fail(FC_E_SHAPE, "wgrad: patch does not fit in LDS");
+    p.mtiles = cdiv(a.B, p.TB) * p.tiles_x * p.tiles_y;
+    p.nci = cdiv(a.Cin, 32); p.nco = cdiv(a.Cout, 32);
+    int ns = cdiv(1024, p.nci * p.nco);
+    if (ns > 256) ns = 256;
+    if (ns > p.mtiles) ns = p.mtiles;
+    p.part_stride = ((size_t)a.Cout * a.Cin * a.KS * a.KS + a.Cout + 3) & ~(size_t)3;
+    if (ns > 1 && a.ws_floats) {
+        const size_t fit = a.ws_floats / p.part_stride;
+        if (fit < 2) ns = 1; else if ((size_t)ns > fit) ns = (int)fit;
+    }
+    p.nsplit = ns < 1 ? 1 : ns;
+    const int xs_floats = p.P * CS > 3 * 1024 ? p.P * CS : 3 * 1024;
+    p.o_ys = (xs_floats + 3) & ~3;
+    p.o_pix = (p.o_ys + p.BM * CS + 3) & ~3;
+    return FC_OK;
+}
+
+size_t conv_wgrad_workspace(const WgradArgs& a) {   // floats wanted for the preferred split
+    WgradArgs b = a;
+    b.ws_floats = 0;
+    WgradDev d;
+    if (wgrad_geometry(b, &d) != FC_OK) return 0;
+    return d.nsplit > 1 ? (size_t)d.nsplit * d.part_stride : 0;
+}
+
+int conv_wgrad_launch(const WgradArgs& a, hipStream_t s) {
+    WgradDev d;
+    FC_TRY(wgrad_geometry(a, &d));
+    if (d.nsplit > 1 && !a.ws) return fail(FC_E_ARG, "wgrad: workspace missing");
+    const size_t lds = (size_t)(d.o_pix + 128) * sizeof(float);
+    const dim3 grid(d.nsplit, d.nci * d.nco);
+    switch (a.KS) {
+        case 1: hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), lds, s, d); break;
+        case 2: hipLaunchKernelGGL(conv_wgrad_kernel<2>, grid, dim3(256), lds, s, d); break;
+        case 3: hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, dim3(256), lds, s, d); break;
+        default: hipLaunchKernelGGL(conv_wgrad_kernel<5>, grid, dim3(256), lds, s, d); break;
+    }
+    FC_HIP(hipGetLastError());
+    if (d.nsplit > 1) {
+        const size_t nw = (size_t)a.Cout * a.Cin * a.KS * a.KS;
+        const size_t total = nw + (a.db ? a.Cout : 0);
+        const int g = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g), dim3(256), 0, s, a.ws, d.nsplit, d.part_stride, a.dw, nw, a.db, a.Cout);
+        FC_HIP(hipGetLastError());
+    }
+    return FC_OK;
+}
+
+int conv_wgrad_init() {
+    // > 64 KB of dynamic LDS needs the attribute on gfx950 too
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return FC_OK;
+}
+
+}  // namespace fc

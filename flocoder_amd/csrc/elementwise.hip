@@ -1,36 +1,9 @@
 // HBM-bound helper kernels: GroupNorm finalisation with residual, the boundary 1x1 convolutions that
 // change layout (NCHW <-> NHWC), layout converters, bilinear resize, standalone GroupNorm statistics.
 #include "common.h"
+#include "stats_dev.h"
 
 namespace fc {
-
-__device__ __forceinline__ float silu_e(float z) { return z / (1.0f + __expf(-z)); }
-
-__device__ __forceinline__ float block_sum(float v, float* red /*[4]*/) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
-}
-
-// combine T equal-count (mean, M2) partials of group g of sample b
-__device__ __forceinline__ void combine_partials(const SrcXform& xf, int b, int g, float* mean_out, float* rstd_out) {
-    const float* sp = xf.stats + (size_t)(b * xf.G + g) * xf.T * 2;
-    float sm = 0.f;
-    for (int t = 0; t < xf.T; ++t) sm += sp[2 * t];
-    const float mean = sm / (float)xf.T;
-    float m2 = 0.f, dv = 0.f;
-    for (int t = 0; t < xf.T; ++t) {
-        const float d = sp[2 * t] - mean;
-        m2 += sp[2 * t + 1];
-        dv += d * d;
-    }
-    const float var = (m2 + xf.n_t * dv) / (xf.n_t * (float)xf.T);
-    *mean_out = mean;
-    *rstd_out = 1.0f / sqrtf(var + xf.eps);
-}
 
 // ---------------------------------------------------------------------------------------------------
 // y = act(GroupNorm(h) [FiLM]) + res ; optional GroupNorm(1) partials of y.   grid (bps, B)

@@ -47,6 +47,22 @@ __global__ void __launch_bounds__(256) pack_conv_pad_kernel(const float* src, fl
     }
 }
 
+// Data-gradient operand of a stride-1 convolution: the forward kernel run on dY with
+//     dst[(KS-1-ky)*KS + (KS-1-kx)][o][i - ci0] = src[o][i][ky][kx]   for i in [ci0, ci0 + nci)
+// ([taps][Cin' = O][Cout' = nci]) and padding KS-1-pad yields dX for input channels ci0..ci0+nci (a slice, so that the two
+// sources of a channel concatenation get their gradients from two launches).
+__global__ void __launch_bounds__(256) pack_conv_dgrad_kernel(const float* src, float* dst, int O, int I, int KS, int ci0, int nci) {
+    const int KK = KS * KS;
+    const size_t total = (size_t)O * nci * KK;
+    for (size_t t = blockIdx.x * 256ull + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        const int i = (int)(t % nci);
+        const size_t r = t / nci;
+        const int o = (int)(r % O), tap = (int)(r / O);
+        const int ky = KS - 1 - tap / KS, kx = KS - 1 - tap % KS;
+        dst[t] = src[((size_t)o * I + ci0 + i) * KK + ky * KS + kx];
+    }
+}
+
 // [B][R][Cc] -> [B][Cc][R] through a padded 32x32 LDS tile (coalesced on both sides).   grid (Cc/32, R/32, B), block (32, 8)
 __global__ void __launch_bounds__(256) transpose_batched_kernel(const float* src, float* dst, int R, int Cc) {
     __shared__ float tile[32][33];
@@ -68,6 +84,11 @@ int pack_conv_launch(const float* oihw, float* dst, int O, int I, int KH, int KW
 }
 int pack_conv_pad_launch(const float* oihw, float* dst, int O, int I, int KK, int Opad, int Ipad, hipStream_t s) {
     hipLaunchKernelGGL(pack_conv_pad_kernel, dim3(pgrid((size_t)Opad * Ipad * KK)), dim3(256), 0, s, oihw, dst, O, I, KK, Opad, Ipad);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+int pack_conv_dgrad_launch(const float* oihw, float* dst, int O, int I, int KS, int ci0, int nci, hipStream_t s) {
+    hipLaunchKernelGGL(pack_conv_dgrad_kernel, dim3(pgrid((size_t)O * nci * KS * KS)), dim3(256), 0, s, oihw, dst, O, I, KS, ci0, nci);
     FC_HIP(hipGetLastError());
     return FC_OK;
 }

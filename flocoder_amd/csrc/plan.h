@@ -31,8 +31,17 @@ struct FwdCtx {             // per-call inputs of one forward
     int mask_fuse = 0;                 // run mask_fusion_conv (mask present and not all ones)
     float* out = nullptr;              // NCHW [B][C][H][W]
     int B = 0;
+    const float* d_out = nullptr;      // backward only: NCHW gradient of `out`
+    float* grads = nullptr;            // backward only: flat parameter gradients, table layout
 };
 using Op = std::function<int(const FwdCtx&, hipStream_t)>;
+
+// What the backward pass needs to know about the forward's modules: the raw tensors and statistics each one left in the arena.
+struct ResRec { std::string p; Act x, skip, h1, h2, rb, out; Stat st1, st2; int cout = 0; };
+struct LinRec { std::string p; Act x, qkv, lao, yb, out; float* ctx = nullptr; Stat gn1, sty; };
+struct MidRec { Act x, qkv, ao, out; Stat gn1; };
+struct ConvRec { std::string name; Act x, out; int KS = 1, pad = 0, stride = 1, ups = 0; };
+struct TapeItem { int kind, idx; };   // 0 ResRec, 1 LinRec, 2 MidRec, 3 ConvRec -- in forward order
 
 struct Plan {                 // one launch plan + activation arena for up to maxB rows
     int maxB = 0, H = 0, W = 0;
@@ -43,6 +52,9 @@ struct Plan {                 // one launch plan + activation arena for up to ma
     double flops = 0.0;
     float *t_emb = nullptr, *ss = nullptr;
     std::map<std::string, Act> named;              // debug taps: block outputs by reference module name
+    std::vector<ResRec> res; std::vector<LinRec> lin; std::vector<MidRec> mid; std::vector<ConvRec> convs;
+    std::vector<TapeItem> tape;
+    Act x0, head;                                   // init_conv output, final_res_block output
     void release() {
         for (void* p : allocs) (void)hipFree(p);
         *this = Plan();

@@ -1,0 +1,41 @@
+// Device helpers shared by the HBM-bound kernels (elementwise.hip, backward.hip): SiLU, block reductions and the fixed-order
+// combination of GroupNorm (mean, M2) partials.
+#pragma once
+#include "common.h"
+
+namespace fc {
+
+__device__ __forceinline__ float silu_e(float z) { return z / (1.0f + __expf(-z)); }
+
+__device__ __forceinline__ float block_sum(float v, float* red /*[4]*/) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// combine T equal-count (mean, M2) partials of group g of sample b
+__device__ __forceinline__ void combine_partials(const SrcXform& xf, int b, int g, float* mean_out, float* rstd_out) {
+    const float* sp = xf.stats + (size_t)(b * xf.G + g) * xf.T * 2;
+    float sm = 0.f;
+    for (int t = 0; t < xf.T; ++t) sm += sp[2 * t];
+    const float mean = sm / (float)xf.T;
+    float m2 = 0.f, dv = 0.f;
+    for (int t = 0; t < xf.T; ++t) {
+        const float d = sp[2 * t] - mean;
+        m2 += sp[2 * t + 1];
+        dv += d * d;
+    }
+    const float var = (m2 + xf.n_t * dv) / (xf.n_t * (float)xf.T);
+    *mean_out = mean;
+    *rstd_out = 1.0f / sqrtf(var + xf.eps);
+}
+
+__device__ __forceinline__ float silu_grad_e(float z) {   // d/dz [z sigmoid(z)]
+    const float s = 1.0f / (1.0f + __expf(-z));
+    return s * (1.0f + z * (1.0f - s));
+}
+
+}  // namespace fc

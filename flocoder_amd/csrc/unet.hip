@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "plan.h"
+#include "unet_priv.h"
 
 namespace fc {
 
@@ -27,35 +28,6 @@ const char* last_error() { return g_err.c_str(); }
 }  // namespace fc
 
 using namespace fc;
-
-struct fc_unet : fc::ParamStore {
-    fc_unet_config cfg{};
-    int device = 0;
-    int td = 0, heads = 4;
-    std::vector<int> chans;  // [dim, dim*m0, dim*m1, ...]
-    int S = 0;                                    // total scale/shift width
-    std::unordered_map<std::string, int> ss_off;  // resblock prefix -> column offset
-    float* freqs = nullptr;
-
-    // plans: the batch can run as `nchains` independent row ranges on concurrent streams (no cross-sample op exists in the
-    // network; FLOCODER_AMD_CHAINS=2).  Off by default: half-batch launches lose more than the overlap wins on one GPU.
-    int maxB = 0, H = 0, W = 0, nchains = 1;
-    fc::Plan plan[2];
-    std::vector<void*> int_allocs;           // integrator state
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-
-    // integrator state (library-owned so captured graphs never see caller pointers)
-    hipStream_t stream = nullptr;
-    hipEvent_t ev_in = nullptr, ev_out = nullptr;
-    int* step = nullptr;
-    float *ts_dev = nullptr, *sc = nullptr, *tvec = nullptr;
-    int ts_cap = 0;
-    float *y = nullptr, *xs = nullptr, *k1 = nullptr, *k2 = nullptr, *k3 = nullptr, *v2 = nullptr, *mask_own = nullptr;
-    int64_t* ids_own = nullptr;
-    std::map<std::tuple<int, int, int, int, uint32_t, uint32_t, uint32_t, int>, hipGraphExec_t> graphs;
-
-};
 
 namespace fc {
 
@@ -184,6 +156,10 @@ struct Builder : PlanBuilder {
         }
         if (!err) push([f](const FwdCtx& c, hipStream_t s) { FinalizeArgs g = f; g.B = c.B; return finalize_launch(g, s); }, "finalize");
         pl->named[p] = out; pl->named[p + ".h1"] = h1; pl->named[p + ".h2"] = h2;
+        ResRec rec;
+        rec.p = p; rec.x = x; if (skip) rec.skip = *skip; rec.h1 = h1; rec.h2 = h2; rec.rb = rb; rec.out = out; rec.st1 = st1; rec.st2 = st2; rec.cout = cout;
+        pl->tape.push_back({0, (int)pl->res.size()});
+        pl->res.push_back(rec);
         return out;
     }
 
@@ -214,6 +190,10 @@ struct Builder : PlanBuilder {
         f.res = x.p; f.y = out.p; f.HW = n; f.C = x.C;
         if (!err) push([f](const FwdCtx& c, hipStream_t s) { FinalizeArgs g = f; g.B = c.B; return finalize_launch(g, s); }, "finalize");
         pl->named[p] = out; pl->named[p + ".qkv"] = qkv; pl->named[p + ".lao"] = lao; pl->named[p + ".y"] = yb;
+        LinRec rec;
+        rec.p = p; rec.x = x; rec.qkv = qkv; rec.lao = lao; rec.yb = yb; rec.out = out; rec.ctx = ctx; rec.gn1 = gn1; rec.sty = sty;
+        pl->tape.push_back({1, (int)pl->lin.size()});
+        pl->lin.push_back(rec);
         return out;
     }
 
@@ -237,6 +217,10 @@ struct Builder : PlanBuilder {
         o.add = x.p;
         conv(o, out, 0, nullptr);
         pl->named["mid_attn"] = out;
+        MidRec rec;
+        rec.x = x; rec.qkv = qkv; rec.ao = ao; rec.out = out; rec.gn1 = gn1;
+        pl->tape.push_back({2, (int)pl->mid.size()});
+        pl->mid.push_back(rec);
         return out;
     }
 
@@ -270,6 +254,8 @@ static void free_plan(fc_unet* u) {
     for (auto& kv : u->graphs) (void)hipGraphExecDestroy(kv.second);
     u->graphs.clear();
     for (Plan& pln : u->plan) pln.release();
+    u->bwd.release();                       // the backward plan points into the forward arena
+    u->dgrad_packs.clear();
     for (void* p : u->int_allocs) (void)hipFree(p);
     u->int_allocs.clear();
     u->maxB = 0;
@@ -315,6 +301,7 @@ static int build_plan(fc_unet* u, Plan* pl, int maxB, int H, int W) {
     // -- init_conv (unet.py:295) and mask fusion (unet.py:298-305) --
     Act x0 = b.act(dim, H, W);
     pl->named["init"] = x0;
+    pl->x0 = x0;
     Act mask_nhwc;
     {
         const float *w = u->P("init_conv.weight"), *bias = u->R("init_conv.bias");
@@ -377,12 +364,16 @@ static int build_plan(fc_unet* u, Plan* pl, int maxB, int H, int W) {
             a.KS = 3; a.pad = 1; a.w = u->P(p + ".3.weight"); a.bias = u->R(p + ".3.bias");
             Act o = b.act(cs[i + 1], x.H, x.W);
             b.conv(a, o, 0, nullptr);
+            pl->tape.push_back({3, (int)pl->convs.size()});
+            pl->convs.push_back({p + ".3", x, o, 3, 1, 1, 0});
             x = o;
             pl->named[p + ".3"] = o;
         } else {
             a.KS = 2; a.pad = 0; a.stride = 2; a.w = u->P(p + ".3.1.weight"); a.bias = u->R(p + ".3.1.bias");
             Act o = b.act(cs[i + 1], x.H / 2, x.W / 2);
             b.conv(a, o, 0, nullptr);
+            pl->tape.push_back({3, (int)pl->convs.size()});
+            pl->convs.push_back({p + ".3.1", x, o, 2, 0, 2, 0});
             x = o;
             pl->named[p + ".3"] = o;
         }
@@ -412,11 +403,15 @@ static int build_plan(fc_unet* u, Plan* pl, int maxB, int H, int W) {
             a.w = u->P(p + ".3.weight"); a.bias = u->R(p + ".3.bias");
             Act o = b.act(din, x.H, x.W);
             b.conv(a, o, 0, nullptr);
+            pl->tape.push_back({3, (int)pl->convs.size()});
+            pl->convs.push_back({p + ".3", x, o, 3, 1, 1, 0});
             x = o;
         } else {  // nn.Upsample(nearest x2) folded into the conv's loader (unet.py:42-46)
             a.ups = 1; a.w = u->P(p + ".3.1.weight"); a.bias = u->R(p + ".3.1.bias");
             Act o = b.act(din, x.H * 2, x.W * 2);
             b.conv(a, o, 0, nullptr);
+            pl->tape.push_back({3, (int)pl->convs.size()});
+            pl->convs.push_back({p + ".3.1", x, o, 3, 1, 1, 1});
             x = o;
         }
         pl->named[p + ".3"] = x;
@@ -425,6 +420,7 @@ static int build_plan(fc_unet* u, Plan* pl, int maxB, int H, int W) {
     // -- head (unet.py:369-372) --
     x = b.resblock("final_res_block", x, &x0, dim, false, nullptr);
     if (b.err) return b.err;
+    pl->head = x;
     {
         const float *xp = x.p, *w = u->P("final_conv.weight"), *bias = u->R("final_conv.bias");
         b.scope = "final_conv";
@@ -582,6 +578,7 @@ int fc_unet_load_params(fc_unet* u, const float* flat, int64_t numel, int on_dev
     if (!u || !flat) return fail(FC_E_ARG, "fc_unet_load_params: null argument");
     if (u->device < 0) return fail(FC_E_STATE, "unet: created with device < 0 (description only)");
     FC_HIP(hipSetDevice(u->device));
+    ++u->param_version;
     return u->load(flat, numel, on_device, static_cast<hipStream_t>(stream));
 }
 
@@ -764,7 +761,10 @@ int fc_unet_integrate(fc_unet* u, int method, float* x_dev, int B, int H, int W,
 int fc_unet_debug_tensor(const fc_unet* u, const char* name, const float** ptr, int* C, int* H, int* W) {
     if (!u || !name) return fail(FC_E_ARG, "fc_unet_debug_tensor: null argument");
     auto it = u->plan[0].named.find(name);   // chain 0 = the first rows of the batch
-    if (it == u->plan[0].named.end()) return fail(FC_E_ARG, std::string("fc_unet_debug_tensor: no tap named ") + name);
+    if (it == u->plan[0].named.end()) {
+        it = u->bwd.named.find(name);        // "grad:<tap>": gradient of that tap after fc_unet_backward
+        if (it == u->bwd.named.end()) return fail(FC_E_ARG, std::string("fc_unet_debug_tensor: no tap named ") + name);
+    }
     *ptr = it->second.p; *C = it->second.C; *H = it->second.H; *W = it->second.W;
     return FC_OK;
 }
@@ -813,6 +813,26 @@ int fc_debug_conv(const float* src0, int c0, const float* src1, int c1, const fl
     }
     (void)hipStreamSynchronize(s);
     (void)hipFree(wp);
+    return r;
+}
+
+int fc_debug_conv_wgrad(const float* src0, int c0, const float* src1, int c1, const float* dy, int cout, int batch, int hs, int ws, int ksize,
+                        int pad, int stride, int upsample, float* dw_out, float* db_out, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    FC_TRY(conv_wgrad_init());
+    WgradArgs a;
+    a.x0 = src0; a.C0 = c0; a.x1 = src1; a.C1 = src1 ? c1 : 0; a.Cin = a.C0 + a.C1; a.Cout = cout; a.dy = dy;
+    a.B = batch; a.Hs = hs; a.Ws = ws; a.KS = ksize; a.pad = pad; a.stride = stride; a.ups = upsample;
+    a.H = upsample ? hs * 2 : (hs + 2 * pad - ksize) / stride + 1;
+    a.W = upsample ? ws * 2 : (ws + 2 * pad - ksize) / stride + 1;
+    a.dw = dw_out; a.db = db_out;
+    const size_t need = conv_wgrad_workspace(a);
+    float* wsp = nullptr;
+    if (need) FC_HIP(hipMalloc(reinterpret_cast<void**>(&wsp), need * sizeof(float)));
+    a.ws = wsp; a.ws_floats = need;
+    const int r = conv_wgrad_launch(a, s);
+    (void)hipStreamSynchronize(s);
+    if (wsp) (void)hipFree(wsp);
     return r;
 }
 

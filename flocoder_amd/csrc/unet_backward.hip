@@ -1,0 +1,427 @@
+// Backward pass of the velocity U-Net for the flow training step (train_flow.py:358-371: loss.backward() through
+// Unet._forward, unet.py:289-372), as a second static launch plan over the arena the forward plan already keeps.
+//
+// The forward stores raw convolution outputs and GroupNorm (mean, M2) partials only; the backward recomputes normalised /
+// activated tensors where a weight gradient needs them (a finalize pass) and inside the GroupNorm-backward kernels.  Per module,
+// in reverse order of the forward tape:
+//   ResnetBlock      GN2+SiLU bwd | recompute a1 | wgrad conv2 | dgrad conv2 | GN1+FiLM+SiLU bwd | wgrad conv1 | dgrad conv1 (one
+//                    launch per concat source) | res_conv wgrad + dgrad, or the identity residual
+//   LinearAttention  GN bwd | wgrad/dgrad to_out | attention core bwd | recompute GN(x) | wgrad/dgrad to_qkv | GN bwd | residual
+//   Attention        wgrad/dgrad to_out | core bwd | recompute GN(x) | wgrad/dgrad to_qkv | GN bwd | residual
+//   Down/Upsample    wgrad (strided / nearest-x2 loader) | dgrad (+ depth-to-space / 2x2 sum)
+// then the conditioning path: FiLM projections, time MLP, class-embedding MLP.  Data gradients reuse the forward implicit-GEMM
+// kernel on flipped, transposed weights (re-packed whenever the parameters change); a tensor with several consumers gets its
+// gradient contributions through the kernels' accumulate paths in a fixed order.  Parameter gradients land in the caller's flat
+// vector in the parameter table's layout, each written exactly once.
+#include <memory>
+
+#include "plan.h"
+#include "unet_priv.h"
+
+using namespace fc;
+
+namespace fc {
+
+struct BwdBuilder : PlanBuilder {
+    fc_unet* u;
+    const Plan* fw;
+    struct Slot { Act g; bool written = false; };
+    std::map<const float*, Slot> gmap;
+    float *ws = nullptr, *s12 = nullptr, *dss = nullptr;
+    size_t ws_floats = 0;
+    BwdBuilder(fc_unet* u_, const Plan* fw_, Plan* pl_, int B_) : u(u_), fw(fw_) { pl = pl_; B = B_; }
+
+    int64_t off(const std::string& n) const { return u->params[u->pidx.at(n)].offset; }
+    Slot& slot(const Act& a) {
+        auto it = gmap.find(a.p);
+        if (it == gmap.end()) {
+            Slot s;
+            s.g.C = a.C; s.g.H = a.H; s.g.W = a.W;
+            s.g.p = dmalloc((size_t)B * a.H * a.W * a.C);
+            it = gmap.emplace(a.p, s).first;
+        }
+        return it->second;
+    }
+    const Act& grad_of(const Act& a) {
+        Slot& s = slot(a);
+        if (!s.written) err = fail(FC_E_STATE, "backward: gradient consumed before it was produced (" + scope + ")");
+        return s.g;
+    }
+
+    void wgrad(const std::string& wname, const std::string& bname, const Act& x, const Act* skip, const Act& dy, int KS, int pad, int stride, int ups) {
+        if (err) return;
+        WgradArgs a;
+        a.x0 = x.p; a.C0 = x.C;
+        if (skip && skip->p) { a.x1 = skip->p; a.C1 = skip->C; }
+        a.dy = dy.p; a.H = dy.H; a.W = dy.W; a.Hs = x.H; a.Ws = x.W; a.Cin = a.C0 + a.C1; a.Cout = dy.C;
+        a.KS = KS; a.pad = pad; a.stride = stride; a.ups = ups; a.B = B;
+        a.ws = ws; a.ws_floats = ws_floats;
+        const int64_t wo = off(wname), bo = bname.empty() ? -1 : off(bname);
+        push([a, wo, bo](const FwdCtx& c, hipStream_t s) {
+            WgradArgs b = a;
+            b.B = c.B; b.dw = c.grads + wo; b.db = bo >= 0 ? c.grads + bo : nullptr;
+            return conv_wgrad_launch(b, s);
+        }, "conv_wgrad", 2.0 * dy.H * dy.W * KS * KS * (double)a.Cin * a.Cout);
+    }
+
+    // d(target) (+)= conv_transpose(dy, W[:, ci0:ci0+target.C]) for a stride-1 convolution of kernel KS / padding pad
+    void dgrad(const std::string& wname, int O, int I, int KS, int pad, const Act& dy, int ci0, const Act& target, const float* plus = nullptr) {
+        if (err) return;
+        Slot& t = slot(target);
+        dgrad_to(wname, O, I, KS, pad, dy, ci0, t.g, t.written ? t.g.p : plus);
+        if (t.written && plus) err = fail(FC_E_STATE, "backward: dgrad with both an accumulate and an extra addend");
+        t.written = true;
+    }
+    void dgrad_to(const std::string& wname, int O, int I, int KS, int pad, const Act& dy, int ci0, const Act& out, const float* add) {
+        if (err) return;
+        const int nci = out.C;
+        float* wp = dmalloc((size_t)O * nci * KS * KS);
+        u->dgrad_packs.push_back({off(wname), wp, O, I, KS, ci0, nci});
+        ConvArgs a;
+        a.s0.p = dy.p; a.s0.C = O; a.Hs = dy.H; a.Ws = dy.W; a.KS = KS; a.pad = KS - 1 - pad;
+        a.w = wp; a.add = add;
+        conv(a, out, 0, nullptr);
+    }
+    void accumulate(const Act& target, const Act& src) {   // d(target) (+)= src
+        if (err) return;
+        Slot& t = slot(target);
+        float* dp = t.g.p; const float* sp = src.p;
+        const size_t per = (size_t)target.H * target.W * target.C;
+        if (t.written) push([=](const FwdCtx& c, hipStream_t s) { return add_into_launch(dp, sp, per * c.B, s); }, "add_into");
+        else push([=](const FwdCtx& c, hipStream_t s) -> int { FC_HIP(hipMemcpyAsync(dp, sp, per * c.B * sizeof(float), hipMemcpyDeviceToDevice, s)); return FC_OK; }, "copy");
+        t.written = true;
+    }
+    // GroupNorm(+FiLM)(+SiLU) backward of y = f(h): dh (+)= ..., parameter gradients of the norm, FiLM gradients into dss
+    void gn_bwd(const Act& dy, const Act& h, const SrcXform& xf, float* dh, bool acc, const std::string& norm, int ss_col) {
+        if (err) return;
+        GnBwdArgs g;
+        g.dy = dy.p; g.h = h.p; g.xf = xf; g.s12 = s12; g.dh = dh; g.accumulate = acc ? 1 : 0; g.HW = h.H * h.W; g.C = h.C;
+        push([g](const FwdCtx& c, hipStream_t s) { GnBwdArgs k = g; k.B = c.B; return gn_bwd_launch(k, s); }, "gn_bwd");
+        const float *gm = xf.gamma, *bt = xf.beta, *ssp = xf.ss;
+        const int S = u->S, C = h.C;
+        const int64_t go = off(norm + ".weight"), bo = off(norm + ".bias");
+        float *sp = s12, *dssp = ssp ? dss + ss_col : nullptr;
+        push([=](const FwdCtx& c, hipStream_t s) { return norm_param_grads_launch(sp, gm, bt, ssp, S, c.grads + go, c.grads + bo, dssp, c.B, C, s); }, "norm_param_grads");
+    }
+    void materialize(const Act& h, const SrcXform& xf, const Act& y) {   // y = act(gn(h))
+        if (err) return;
+        FinalizeArgs f;
+        f.h = h.p; f.xf = xf; f.y = y.p; f.HW = h.H * h.W; f.C = h.C;
+        push([f](const FwdCtx& c, hipStream_t s) { FinalizeArgs g = f; g.B = c.B; return finalize_launch(g, s); }, "finalize");
+    }
+
+    void resblock(const ResRec& r) {
+        scope = r.p;
+        const std::string& p = r.p;
+        const int cout = r.cout, cin = r.x.C + r.skip.C, H = r.x.H, W = r.x.W;
+        const Act g_out = grad_of(r.out);
+        if (err) return;
+        const SrcXform xf2 = xf_of(r.st2, 2, u->R(p + ".block2.norm.weight"), u->R(p + ".block2.norm.bias"));
+        const SrcXform xf1 = xf_of(r.st1, 2, u->R(p + ".block1.norm.weight"), u->R(p + ".block1.norm.bias"), fw->ss + u->ss_off.at(p), u->S);
+        Act dh2 = act(cout, H, W), a1 = act(cout, H, W), da1 = act(cout, H, W);
+        gn_bwd(g_out, r.h2, xf2, dh2.p, false, p + ".block2.norm", 0);
+        materialize(r.h1, xf1, a1);
+        wgrad(p + ".block2.proj.weight", p + ".block2.proj.bias", a1, nullptr, dh2, 3, 1, 1, 0);
+        dgrad_to(p + ".block2.proj.weight", cout, cout, 3, 1, dh2, 0, da1, nullptr);
+        release(a1);
+        Act dh1 = dh2;   // dh2 is dead once conv2's gradients are out
+        gn_bwd(da1, r.h1, xf1, dh1.p, false, p + ".block1.norm", u->ss_off.at(p));
+        release(da1);
+        const Act* sk = r.skip.p ? &r.skip : nullptr;
+        wgrad(p + ".block1.proj.weight", p + ".block1.proj.bias", r.x, sk, dh1, 3, 1, 1, 0);
+        const bool ident = cin == cout;
+        // identity residual: d(x) = dgrad(conv1) + d(out), folded into the dgrad epilogue when d(x) has no earlier contribution
+        const bool fold = ident && !slot(r.x).written;
+        dgrad(p + ".block1.proj.weight", cout, cin, 3, 1, dh1, 0, r.x, fold ? g_out.p : nullptr);
+        if (sk) dgrad(p + ".block1.proj.weight", cout, cin, 3, 1, dh1, r.x.C, r.skip);
+        release(dh1);
+        if (ident) {
+            if (!fold) accumulate(r.x, g_out);
+        } else {
+            wgrad(p + ".res_conv.weight", p + ".res_conv.bias", r.x, sk, g_out, 1, 0, 1, 0);
+            dgrad(p + ".res_conv.weight", cout, cin, 1, 0, g_out, 0, r.x);
+            if (sk) dgrad(p + ".res_conv.weight", cout, cin, 1, 0, g_out, r.x.C, r.skip);
+        }
+    }
+
+    // shared tail of both attention blocks: d(qkv) -> to_qkv gradients -> PreNorm GroupNorm(1) backward into d(x), plus the residual
+    void qkv_tail(const std::string& wq, const std::string& norm, const Act& x, const Stat& gn1, const Act& dqkv, const Act& g_out) {
+        const SrcXform xf = xf_of(gn1, 1, u->R(norm + ".weight"), u->R(norm + ".bias"));
+        Act xn = act(x.C, x.H, x.W), dxn = act(x.C, x.H, x.W);
+        materialize(x, xf, xn);
+        wgrad(wq, "", xn, nullptr, dqkv, 1, 0, 1, 0);
+        dgrad_to(wq, dqkv.C, x.C, 1, 0, dqkv, 0, dxn, nullptr);
+        release(xn);
+        Slot& t = slot(x);
+        gn_bwd(dxn, x, xf, t.g.p, t.written, norm, 0);
+        t.written = true;
+        release(dxn);
+        accumulate(x, g_out);
+    }
+
+    void linattn(const LinRec& r) {
+        scope = r.p;
+        const std::string& p = r.p;
+        const int hid = u->heads * 32, n = r.x.H * r.x.W, heads = u->heads, H = r.x.H, W = r.x.W;
+        const Act g_out = grad_of(r.out);
+        if (err) return;
+        Act dyb = act(r.x.C, H, W), dlao = act(hid, H, W), dqkv = act(3 * hid, H, W);
+        gn_bwd(g_out, r.yb, xf_of(r.sty, 1, u->R(p + ".fn.fn.to_out.1.weight"), u->R(p + ".fn.fn.to_out.1.bias")), dyb.p, false, p + ".fn.fn.to_out.1", 0);
+        wgrad(p + ".fn.fn.to_out.0.weight", p + ".fn.fn.to_out.0.bias", r.lao, nullptr, dyb, 1, 0, 1, 0);
+        dgrad_to(p + ".fn.fn.to_out.0.weight", r.x.C, hid, 1, 0, dyb, 0, dlao, nullptr);
+        release(dyb);
+        float* dctx = dmalloc((size_t)B * heads * 32 * 32);
+        float* kst = dmalloc((size_t)B * heads * 32 * 2);
+        float* rr = dmalloc((size_t)B * heads * 32);
+        const float *qp = r.qkv.p, *dl = dlao.p, *cx = r.ctx;
+        float* dq = dqkv.p;
+        if (!err) push([=](const FwdCtx& c, hipStream_t s) { return linattn_bwd_launch(qp, dl, cx, dctx, kst, rr, dq, c.B, n, heads, s); }, "linattn_bwd",
+                       2.0 * 4 * n * 32 * 32 * heads);
+        release(dlao);
+        qkv_tail(p + ".fn.fn.to_qkv.weight", p + ".fn.norm", r.x, r.gn1, dqkv, g_out);
+        release(dqkv);
+    }
+
+    void midattn(const MidRec& r) {
+        scope = "mid_attn";
+        const int hid = u->heads * 32, n = r.x.H * r.x.W, heads = u->heads, H = r.x.H, W = r.x.W;
+        const Act g_out = grad_of(r.out);
+        if (err) return;
+        Act dao = act(hid, H, W), dqkv = act(3 * hid, H, W);
+        wgrad("mid_attn.fn.fn.to_out.weight", "mid_attn.fn.fn.to_out.bias", r.ao, nullptr, g_out, 1, 0, 1, 0);
+        dgrad_to("mid_attn.fn.fn.to_out.weight", r.x.C, hid, 1, 0, g_out, 0, dao, nullptr);
+        const float *qp = r.qkv.p, *dp = dao.p;
+        float* dq = dqkv.p;
+        if (!err) push([=](const FwdCtx& c, hipStream_t s) { return attn_small_bwd_launch(qp, dp, dq, c.B, n, heads, s); }, "attn_small_bwd");
+        release(dao);
+        qkv_tail("mid_attn.fn.fn.to_qkv.weight", "mid_attn.fn.norm", r.x, r.gn1, dqkv, g_out);
+        release(dqkv);
+    }
+
+    void resample(const ConvRec& r) {
+        scope = r.name;
+        const Act g_out = grad_of(r.out);
+        if (err) return;
+        wgrad(r.name + ".weight", r.name + ".bias", r.x, nullptr, g_out, r.KS, r.pad, r.stride, r.ups);
+        if (r.stride == 2) {            // Downsample: 1x1 over the space-to-depth channels, then depth-to-space
+            Act t4 = act(4 * r.x.C, r.out.H, r.out.W);
+            dgrad_to(r.name + ".weight", r.out.C, 4 * r.x.C, 1, 0, g_out, 0, t4, nullptr);
+            Slot& t = slot(r.x);
+            const float* sp = t4.p; float* dp = t.g.p;
+            const int h = r.out.H, w = r.out.W, C = r.x.C, acc = t.written ? 1 : 0;
+            if (!err) push([=](const FwdCtx& c, hipStream_t s) { return depth_to_space_launch(sp, dp, c.B, h, w, C, acc, s); }, "depth_to_space");
+            t.written = true;
+            release(t4);
+        } else if (r.ups) {             // nearest x2: gradient at the fine resolution, summed over 2x2 blocks
+            Act fine = act(r.x.C, r.out.H, r.out.W);
+            dgrad_to(r.name + ".weight", r.out.C, r.x.C, r.KS, r.pad, g_out, 0, fine, nullptr);
+            Slot& t = slot(r.x);
+            const float* sp = fine.p; float* dp = t.g.p;
+            const int h = r.x.H, w = r.x.W, C = r.x.C, acc = t.written ? 1 : 0;
+            if (!err) push([=](const FwdCtx& c, hipStream_t s) { return sumpool2_nhwc_launch(sp, dp, c.B, h, w, C, acc, s); }, "sumpool2");
+            t.written = true;
+            release(fine);
+        } else {
+            dgrad(r.name + ".weight", r.out.C, r.x.C, r.KS, r.pad, g_out, 0, r.x);
+        }
+    }
+};
+
+static size_t max_wgrad_ws(const fc_unet* u, const Plan& fw, int B) {
+    size_t m = 0;
+    auto want = [&](int C0, int C1, int Cout, int H, int W, int Hs, int Ws, int KS, int pad, int stride, int ups) {
+        WgradArgs a;
+        a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1; a.Cout = Cout; a.H = H; a.W = W; a.Hs = Hs; a.Ws = Ws; a.KS = KS; a.pad = pad; a.stride = stride; a.ups = ups; a.B = B;
+        const size_t w = conv_wgrad_workspace(a);
+        if (w > m) m = w;
+    };
+    const int hid = u->heads * 32, ch = u->cfg.channels, dim = u->cfg.dim;
+    for (const ResRec& r : fw.res) {
+        want(r.cout, 0, r.cout, r.x.H, r.x.W, r.x.H, r.x.W, 3, 1, 1, 0);
+        want(r.x.C, r.skip.C, r.cout, r.x.H, r.x.W, r.x.H, r.x.W, 3, 1, 1, 0);
+        want(r.x.C, r.skip.C, r.cout, r.x.H, r.x.W, r.x.H, r.x.W, 1, 0, 1, 0);
+    }
+    for (const LinRec& r : fw.lin) { want(hid, 0, r.x.C, r.x.H, r.x.W, r.x.H, r.x.W, 1, 0, 1, 0); want(r.x.C, 0, 3 * hid, r.x.H, r.x.W, r.x.H, r.x.W, 1, 0, 1, 0); }
+    for (const MidRec& r : fw.mid) { want(hid, 0, r.x.C, r.x.H, r.x.W, r.x.H, r.x.W, 1, 0, 1, 0); want(r.x.C, 0, 3 * hid, r.x.H, r.x.W, r.x.H, r.x.W, 1, 0, 1, 0); }
+    for (const ConvRec& r : fw.convs) want(r.x.C, 0, r.out.C, r.out.H, r.out.W, r.x.H, r.x.W, r.KS, r.pad, r.stride, r.ups);
+    want(dim, 0, ch, fw.H, fw.W, fw.H, fw.W, 1, 0, 1, 0);
+    want(ch, 0, dim, fw.H, fw.W, fw.H, fw.W, 1, 0, 1, 0);
+    return m;
+}
+
+int build_backward(fc_unet* u) {
+    const fc_unet_config& c = u->cfg;
+    const Plan& fw = u->plan[0];
+    u->bwd.release();
+    u->dgrad_packs.clear();
+    u->dgrad_version = ~0ull;
+    if (c.mask_cond) return fail(FC_E_STATE, "unet: the backward pass of the mask-conditioning branches is not built");
+    if (u->nchains != 1) return fail(FC_E_STATE, "unet: training needs a single-chain plan (unset FLOCODER_AMD_CHAINS)");
+    FC_TRY(conv_wgrad_init());
+    const int B = fw.maxB, H = fw.H, W = fw.W, HW = H * W, dim = c.dim, ch = c.channels, td = u->td, S = u->S, ncls = c.n_classes;
+    BwdBuilder b(u, &fw, &u->bwd, B);
+    int maxC = 3 * u->heads * 32;
+    for (int cc : u->chans) if (cc > maxC) maxC = cc;
+    b.ws_floats = max_wgrad_ws(u, fw, B);
+    b.ws = b.dmalloc(b.ws_floats ? b.ws_floats : 4);
+    b.s12 = b.dmalloc((size_t)B * maxC * 2);
+    b.dss = b.dmalloc((size_t)B * S);
+    float* redws = b.dmalloc(256);
+    (void)redws;
+    if (b.err) return b.err;
+    if (ncls > 0) {
+        u->class_lo = b.off("class_cond_mlp.0.weight");
+        const Param& last = u->params[u->pidx.at("class_cond_mlp.3.bias")];
+        u->class_hi = last.offset + ((last.numel + 3) & ~3ll);
+    }
+
+    // -- head: d(out) NCHW -> NHWC, final_conv (unet.py:372) --
+    b.scope = "final_conv";
+    Act dv = b.act(ch, H, W);
+    {
+        float* dvp = dv.p;
+        b.push([=](const FwdCtx& cx, hipStream_t s) { return nchw_to_nhwc_launch(cx.d_out, dvp, cx.B, ch, HW, ch, cx.B, s); }, "nchw_to_nhwc");
+    }
+    b.wgrad("final_conv.weight", "final_conv.bias", fw.head, nullptr, dv, 1, 0, 1, 0);
+    b.dgrad("final_conv.weight", ch, dim, 1, 0, dv, 0, fw.head);
+    // -- the tape in reverse --
+    for (int i = (int)fw.tape.size() - 1; i >= 0 && !b.err; --i) {
+        const TapeItem& t = fw.tape[i];
+        if (t.kind == 0) b.resblock(fw.res[t.idx]);
+        else if (t.kind == 1) b.linattn(fw.lin[t.idx]);
+        else if (t.kind == 2) b.midattn(fw.mid[t.idx]);
+        else b.resample(fw.convs[t.idx]);
+    }
+    if (b.err) return b.err;
+    // -- init_conv (unet.py:295): only its parameters need a gradient --
+    {
+        b.scope = "init_conv";
+        Act xin = b.act(ch, H, W);
+        float* xp = xin.p;
+        b.push([=](const FwdCtx& cx, hipStream_t s) { return nchw_to_nhwc_launch(cx.x, xp, cx.B, ch, HW, ch, cx.B, s); }, "nchw_to_nhwc");
+        const Act g0 = b.grad_of(fw.x0);
+        b.wgrad("init_conv.weight", "init_conv.bias", xin, nullptr, g0, 1, 0, 1, 0);
+    }
+    if (b.err) return b.err;
+    // -- conditioning: every ResnetBlock.mlp (unet.py:79-82,90-92), then time_mlp / class_cond_mlp (unet.py:199-212,310-316) --
+    {
+        b.scope = "resblock.mlp";
+        const float* te = fw.t_emb;
+        float* dss = b.dss;
+        for (auto& kv : u->ss_off) {
+            const std::string& p = kv.first;
+            const int col = kv.second, rows = (int)u->params[u->pidx.at(p + ".mlp.1.bias")].numel;
+            const int64_t wo = b.off(p + ".mlp.1.weight"), bo = b.off(p + ".mlp.1.bias");
+            b.push([=](const FwdCtx& cx, hipStream_t s) { return dense_bwd_w_launch(dss + col, S, te, 2, cx.grads + wo, cx.grads + bo, cx.B, td, rows, s); }, "dense_bwd_w");
+        }
+        float* dT = b.dmalloc((size_t)B * td);
+        const float* wt = u->P("__ss_wt");
+        b.push([=](const FwdCtx& cx, hipStream_t s) { return dense_bwd_x_launch(dss, S, wt, 1, S, te, 2, dT, 0, cx.B, td, S, s); }, "dense_bwd_x");
+
+        b.scope = "time_mlp";
+        float *se = b.dmalloc((size_t)B * dim), *z1 = b.dmalloc((size_t)B * td), *dz1 = b.dmalloc((size_t)B * td);
+        const float *fr = u->freqs, *w1 = u->R("time_mlp.1.weight"), *b1 = u->R("time_mlp.1.bias"), *w3 = u->R("time_mlp.3.weight");
+        const int64_t o1w = b.off("time_mlp.1.weight"), o1b = b.off("time_mlp.1.bias"), o3w = b.off("time_mlp.3.weight"), o3b = b.off("time_mlp.3.bias");
+        b.push([=](const FwdCtx& cx, hipStream_t s) -> int {
+            FC_TRY(sin_emb_launch(cx.time, fr, se, cx.B, dim, s));
+            FC_TRY(dense_fwd_launch(se, 0, w1, b1, z1, cx.B, dim, td, s));
+            FC_TRY(dense_bwd_w_launch(dT, td, z1, 1, cx.grads + o3w, cx.grads + o3b, cx.B, td, td, s));
+            FC_TRY(dense_bwd_x_launch(dT, td, w3, 0, 0, z1, 1, dz1, 0, cx.B, td, td, s));
+            return dense_bwd_w_launch(dz1, td, se, 0, cx.grads + o1w, cx.grads + o1b, cx.B, dim, td, s);
+        }, "time_mlp_bwd");
+        if (ncls > 0) {
+            b.scope = "class_cond_mlp";
+            float *e = b.dmalloc((size_t)B * td), *cz1 = b.dmalloc((size_t)B * td), *dcz1 = b.dmalloc((size_t)B * td), *de = b.dmalloc((size_t)B * td);
+            const float *E = u->R("class_cond_mlp.0.weight"), *cw1 = u->R("class_cond_mlp.1.weight"), *cb1 = u->R("class_cond_mlp.1.bias"),
+                        *cw3 = u->R("class_cond_mlp.3.weight");
+            const int64_t oE = b.off("class_cond_mlp.0.weight"), c1w = b.off("class_cond_mlp.1.weight"), c1b = b.off("class_cond_mlp.1.bias"),
+                          c3w = b.off("class_cond_mlp.3.weight"), c3b = b.off("class_cond_mlp.3.bias");
+            b.push([=](const FwdCtx& cx, hipStream_t s) -> int {
+                if (!cx.ids) return FC_OK;    // no conditioning this step: these parameters get no gradient (left zero, the optimiser skips them)
+                FC_TRY(gather_rows_launch(E, cx.ids, e, cx.B, td, s));
+                FC_TRY(dense_fwd_launch(e, 0, cw1, cb1, cz1, cx.B, td, td, s));
+                FC_TRY(dense_bwd_w_launch(dT, td, cz1, 1, cx.grads + c3w, cx.grads + c3b, cx.B, td, td, s));
+                FC_TRY(dense_bwd_x_launch(dT, td, cw3, 0, 0, cz1, 1, dcz1, 0, cx.B, td, td, s));
+                FC_TRY(dense_bwd_w_launch(dcz1, td, e, 0, cx.grads + c1w, cx.grads + c1b, cx.B, td, td, s));
+                FC_TRY(dense_bwd_x_launch(dcz1, td, cw1, 0, 0, nullptr, 0, de, 0, cx.B, td, td, s));
+                return scatter_rows_launch(de, cx.ids, cx.grads + oE, cx.B, td, ncls, s);
+            }, "class_mlp_bwd");
+        }
+    }
+    if (b.err) return b.err;
+    for (auto& kv : fw.named) {
+        auto it = b.gmap.find(kv.second.p);
+        if (it != b.gmap.end()) u->bwd.named["grad:" + kv.first] = it->second.g;
+    }
+    u->bwd.maxB = B; u->bwd.H = H; u->bwd.W = W;
+    return FC_OK;
+}
+
+}  // namespace fc
+
+extern "C" {
+
+int fc_unet_train_reserve(fc_unet* u, int max_batch, int height, int width) {
+    FC_TRY(fc_unet_reserve(u, max_batch, height, width));
+    if (u->bwd.maxB == u->plan[0].maxB && u->bwd.H == height && u->bwd.W == width && u->bwd.maxB > 0) return FC_OK;
+    FC_HIP(hipSetDevice(u->device));
+    FC_HIP(hipDeviceSynchronize());
+    const int r = build_backward(u);
+    if (r != FC_OK) { u->bwd.release(); u->dgrad_packs.clear(); }
+    return r;
+}
+
+int fc_unet_backward(fc_unet* u, const float* x, const float* time, const int64_t* ids, const float* d_out, float* grads, int64_t numel,
+                     int B, int H, int W, void* stream) {
+    if (!u || !x || !time || !d_out || !grads || B < 1) return fail(FC_E_ARG, "fc_unet_backward: null argument");
+    if (u->bwd.maxB < B || u->bwd.H != H || u->bwd.W != W || u->plan[0].maxB < B) return fail(FC_E_STATE, "unet: no backward plan for this shape; call fc_unet_train_reserve");
+    if (numel != u->raw_numel) return fail(FC_E_ARG, "fc_unet_backward: gradient vector must have " + std::to_string(u->raw_numel) + " floats (padded table layout)");
+    if (!u->loaded) return fail(FC_E_STATE, "unet: weights not loaded");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    FC_HIP(hipSetDevice(u->device));
+    if (u->dgrad_version != u->param_version) {     // data-gradient operands follow the parameters
+        for (const auto& k : u->dgrad_packs) FC_TRY(pack_conv_dgrad_launch(u->raw + k.src, k.dst, k.O, k.I, k.KS, k.ci0, k.nci, s));
+        u->dgrad_version = u->param_version;
+    }
+    FC_HIP(hipMemsetAsync(grads, 0, (size_t)numel * sizeof(float), s));
+    FwdCtx c;
+    c.x = x; c.x_mod = B; c.time = time; c.ids = u->cfg.n_classes > 0 ? ids : nullptr; c.ids_mod = B; c.B = B;
+    c.d_out = d_out; c.grads = grads;
+    return run_plan(u->bwd, c, s);
+}
+
+int fc_unet_class_param_range(const fc_unet* u, int64_t* lo, int64_t* hi) {
+    if (!u || !lo || !hi) return fail(FC_E_ARG, "fc_unet_class_param_range: null argument");
+    *lo = u->class_lo; *hi = u->class_hi;
+    return FC_OK;
+}
+
+int fc_flow_interp(const float* source_dev, const float* target_dev, const float* t_dev, float* x_out_dev, float* v_out_dev, int batch,
+                   int64_t per_sample, void* stream) {
+    if (!source_dev || !target_dev || !t_dev || !x_out_dev || !v_out_dev || batch < 1) return fail(FC_E_ARG, "fc_flow_interp: null argument");
+    return flow_interp_launch(source_dev, target_dev, t_dev, x_out_dev, v_out_dev, batch, (int)per_sample, static_cast<hipStream_t>(stream));
+}
+
+int fc_mse_loss_grad(const float* v_dev, const float* target_dev, float* dv_out_dev, float* loss_out_dev, float* ws256_dev, int64_t numel,
+                     void* stream) {
+    if (!v_dev || !target_dev || !loss_out_dev || !ws256_dev || numel < 1) return fail(FC_E_ARG, "fc_mse_loss_grad: null argument");
+    return mse_loss_grad_launch(v_dev, target_dev, dv_out_dev, loss_out_dev, ws256_dev, (size_t)numel, static_cast<hipStream_t>(stream));
+}
+
+int fc_grad_clip_coef(const float* grads_dev, int64_t numel, const float* grads2_dev, int64_t numel2, float max_norm, float* norm_coef_out_dev,
+                      float* ws256_dev, void* stream) {
+    if (!grads_dev || !norm_coef_out_dev || !ws256_dev) return fail(FC_E_ARG, "fc_grad_clip_coef: null argument");
+    return grad_clip_coef_launch(grads_dev, (size_t)numel, grads2_dev, grads2_dev ? (size_t)numel2 : 0, max_norm, norm_coef_out_dev, ws256_dev,
+                                 static_cast<hipStream_t>(stream));
+}
+
+int fc_adam_ema_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, float* ema_dev, int64_t numel,
+                     const float* clip_coef_dev, float lr, float beta1, float beta2, float eps, int step, float ema_decay, int apply_adam,
+                     void* stream) {
+    if (!params_dev || numel < 0 || (apply_adam && (!grads_dev || !exp_avg_dev || !exp_avg_sq_dev || step < 1)))
+        return fail(FC_E_ARG, "fc_adam_ema_step: bad argument");
+    return adam_ema_launch(params_dev, grads_dev, exp_avg_dev, exp_avg_sq_dev, ema_dev, (size_t)numel, clip_coef_dev, lr, beta1, beta2, eps, step,
+                           ema_decay, apply_adam, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,43 @@
+// The velocity U-Net object behind the fc_unet_* entry points (unet.hip: parameters, forward plan, integrator;
+// unet_backward.hip: backward plan of the training step).
+#pragma once
+#include <map>
+#include <tuple>
+
+#include "plan.h"
+
+struct fc_unet : fc::ParamStore {
+    fc_unet_config cfg{};
+    int device = 0;
+    int td = 0, heads = 4;
+    std::vector<int> chans;  // [dim, dim*m0, dim*m1, ...]
+    int S = 0;                                    // total scale/shift width
+    std::unordered_map<std::string, int> ss_off;  // resblock prefix -> column offset
+    float* freqs = nullptr;
+
+    // plans: the batch can run as `nchains` independent row ranges on concurrent streams (no cross-sample op exists in the
+    // network; FLOCODER_AMD_CHAINS=2).  Off by default: half-batch launches lose more than the overlap wins on one GPU.
+    int maxB = 0, H = 0, W = 0, nchains = 1;
+    fc::Plan plan[2];
+    std::vector<void*> int_allocs;           // integrator state
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+
+    // integrator state (library-owned so captured graphs never see caller pointers)
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    int* step = nullptr;
+    float *ts_dev = nullptr, *sc = nullptr, *tvec = nullptr;
+    int ts_cap = 0;
+    float *y = nullptr, *xs = nullptr, *k1 = nullptr, *k2 = nullptr, *k3 = nullptr, *v2 = nullptr, *mask_own = nullptr;
+    int64_t* ids_own = nullptr;
+    std::map<std::tuple<int, int, int, int, uint32_t, uint32_t, uint32_t, int>, hipGraphExec_t> graphs;
+
+    // training (unet_backward.hip): backward launch plan over the forward arena, data-gradient weight operands
+    fc::Plan bwd;
+    struct DgradPack { int64_t src; float* dst; int O, I, KS, ci0, nci; };
+    std::vector<DgradPack> dgrad_packs;
+    uint64_t param_version = 0, dgrad_version = ~0ull;
+    int64_t class_lo = 0, class_hi = 0;       // [lo, hi) of class_cond_mlp.* in the flat table
+
+};

@@ -70,3 +70,19 @@ def gather_samples(local: torch.Tensor, n_total: int) -> torch.Tensor | None:
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad)
     return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(out, sizes)], dim=0)
+
+
+def average_gradients(flat: torch.Tensor, group=None, bucket_bytes: int = 64 << 20) -> int:
+    """Data-parallel training (BASELINE config 4): all-reduce(sum) the flat gradient vector in place and divide by the world
+    size -- DDP's gradient averaging on the library's one contiguous vector (39.7 MB at dim=32, so one or two buckets; on xGMI a
+    ring all-reduce is per-link bound and large buckets are the right shape).  Returns the number of collectives issued."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0
+    world = dist.get_world_size(group)
+    per = max(1, bucket_bytes // 4)
+    n = 0
+    for lo in range(0, flat.numel(), per):
+        dist.all_reduce(flat[lo:lo + per], op=dist.ReduceOp.SUM, group=group)
+        n += 1
+    flat.div_(world)
+    return n

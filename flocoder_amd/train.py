@@ -1,0 +1,222 @@
+"""Flow training step: host-side mirror of the step in ``train_flow.py`` (reference train_flow.py:33-71 EMA, :90-182 batch_to_data,
+:338-397 the step) over the gfx950 library.
+
+Two ways in:
+
+* ``FlowTrainer.step(source, target, cond)`` -- the whole step on the device through the C ABI: interpolation (``fc_flow_interp``),
+  U-Net forward + backward (``fc_unet_forward`` / ``fc_unet_backward``), MSE loss and its gradient (``fc_mse_loss_grad``),
+  gradient-norm clipping (``fc_grad_clip_coef``), Adam and the EMA in one pass over flat vectors (``fc_adam_ema_step``).  No host
+  synchronisation inside a step; data-parallel ranks add one all-reduce of the flat gradient vector (RCCL).
+* the reference's own loop shape -- ``loss_fn(model(x, t*999, cond), v).backward(); clip_grad_norm_; optimizer.step(); ema.update()`` --
+  works unchanged too: ``Unet.forward`` joins autograd through the same native backward, ``EMA`` below mirrors the reference class
+  (kept on the device instead of round-tripping through host memory every step, train_flow.py:52-54).
+
+There is no CPU path.
+"""
+from __future__ import annotations
+
+import random
+from typing import Dict, Optional
+
+import torch
+
+from . import _binding as B
+from .dist import average_gradients
+from .inpainting import mask_blending
+from .ot import compute_ot_pairing
+from .sampling import warp_time
+
+
+class EMA:
+    """train_flow.py:33-71 with the shadow weights resident on the device (same recurrence, same eval()/train() swap)."""
+
+    def __init__(self, model, decay=0.99, device=None):
+        self.model, self.decay = model, decay
+        self.device = device if device is not None else 'cuda'
+        self.shadow: Dict[str, torch.Tensor] = {}
+        self.backup: Dict[str, Optional[torch.Tensor]] = {}
+        for name, param in model.named_parameters():
+            if param.requires_grad:
+                self.shadow[name] = param.data.clone()
+
+    def update(self):
+        with torch.no_grad():
+            for name, param in self.model.named_parameters():
+                if param.requires_grad:
+                    assert name in self.shadow
+                    self.shadow[name] = self.decay * self.shadow[name] + (1.0 - self.decay) * param.data
+
+    def eval(self):
+        for name, param in self.model.named_parameters():
+            if param.requires_grad:
+                self.backup[name] = param.data.clone()
+                param.data.copy_(self.shadow[name])
+
+    def train(self):
+        for name, param in self.model.named_parameters():
+            if param.requires_grad:
+                param.data.copy_(self.backup[name])
+                self.backup[name] = None
+
+
+def batch_to_data(batch, device, pre_encoded=True, mask_encoder=None, epoch=None, curriculum_epochs=10, extend_epochs=20,
+                  blank_latents=None):
+    """train_flow.py:90-182: unpack a (latents | dict, class) batch, draw the source noise, encode / blend the inpainting mask and
+    re-index the TARGET by the greedy OT pairing.  The on-the-fly mask augmentation is a no-op upstream (p_ones = p_zeros = 0,
+    train_flow.py:129-133) and is therefore absent.  Returns (source, target, class_cond, mask, mask_pixels)."""
+    source, mask, mask_pixels = None, None, None
+    if not pre_encoded:
+        raise NotImplementedError("batch_to_data: only pre-encoded latents are supported (pre_encoded=True is hard-wired upstream, train_flow.py:213)")
+    data, class_cond = batch
+    if isinstance(data, dict):
+        target = data['target_latents'].to(device)
+        class_cond = class_cond.to(device)
+        if mask_encoder is not None:
+            mask_pixels = data['mask_pixels'].float()
+            if len(mask_pixels.shape) < 4:
+                mask_pixels = mask_pixels.unsqueeze(1)
+            mask = mask_pixels.to(device)
+            source = data['source_latents'].to(device)
+    else:
+        target, class_cond = data.to(device), class_cond.to(device)
+    noise = torch.randn_like(target)
+    if mask is None:
+        source = noise
+    elif mask_pixels is not None and mask_encoder is not None:
+        mask = mask_encoder(mask_pixels.to(device))
+        source = mask_blending(source, mask, noise)
+    else:
+        raise AssertionError("Unintended edge case in batch_to_data (train_flow.py:149)")
+    ot_indices = compute_ot_pairing(source, target)
+    target = target[ot_indices]
+    return source, target, class_cond, mask, mask_pixels
+
+
+class FlowTrainer:
+    """One object per rank.  Owns the flat parameter / gradient / Adam / EMA vectors (library table layout); the model's
+    parameters become views into the flat parameter vector, so ``model.state_dict()`` always shows the trained weights."""
+
+    def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 1.0, ema_decay: float = 0.999,
+                 t_eps: float = 1e-3, t_scale: float = 999.0, device=None, process_group=None, distributed: Optional[bool] = None):
+        device = torch.device(device) if device is not None else next(model.parameters()).device
+        if device.type != "cuda":
+            raise RuntimeError("flocoder_amd.FlowTrainer runs on MI355X (gfx950) only; there is no CPU path")
+        if model._cfg.mask_cond:
+            raise NotImplementedError("FlowTrainer: the backward pass of the mask-conditioning branches is not built")
+        self.model, self.device = model, device
+        self.lr, self.betas, self.eps, self.max_norm, self.ema_decay = lr, betas, eps, max_norm, ema_decay
+        self.t_eps, self.t_scale = t_eps, t_scale
+        n = model._flat_numel
+        z = lambda: torch.zeros(n, dtype=torch.float32, device=device)
+        self.params, self.grads, self.exp_avg, self.exp_avg_sq = z(), z(), z(), z()
+        model.to(device)
+        model.adopt_flat(self.params)
+        self.ema = self.params.clone()
+        self._lo, self._hi = model.class_param_range()
+        self.step_main, self.step_class = 0, 0
+        self._scal = torch.zeros(4, dtype=torch.float32, device=device)      # loss | grad norm | clip coefficient
+        self._ws = torch.zeros(256, dtype=torch.float32, device=device)
+        self.pg = process_group
+        dist = torch.distributed
+        self.distributed = (dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1) if distributed is None else distributed
+        model.train()
+        model.sync_flat()
+
+    # ---- pieces, each one library call -----------------------------------------------------------------------------
+    def interpolate(self, source, target, t):
+        x, v = torch.empty_like(target), torch.empty_like(target)
+        B.check(B.lib().fc_flow_interp(B.ptr(source), B.ptr(target), B.ptr(t), B.ptr(x), B.ptr(v), target.shape[0], target[0].numel(),
+                                       B.current_stream(self.device)))
+        return x, v
+
+    def loss_and_grads(self, x, t, cls, v_target):
+        """forward -> loss -> backward; leaves the gradients in ``self.grads`` and returns (loss 0-d tensor, v_model)."""
+        m, lib, st = self.model, B.lib(), B.current_stream(self.device)
+        time = (t * self.t_scale).contiguous()
+        v = m._forward_native(x, time, cls, None, train=True)
+        dv = torch.empty_like(v)
+        B.check(lib.fc_mse_loss_grad(B.ptr(v), B.ptr(v_target), B.ptr(dv), self._scal.data_ptr(), self._ws.data_ptr(), v.numel(), st))
+        m.backward_native(x, time, cls, dv, self.grads)
+        return self._scal[0], v
+
+    def optimizer_step(self, has_class_grads: bool):
+        """clip_grad_norm_ -> Adam -> EMA (train_flow.py:392-397).  Parameters without a gradient (class_cond_mlp.* in a step
+        without conditioning) are skipped by Adam, step count included, exactly as torch.optim skips ``p.grad is None``."""
+        lib, st = B.lib(), B.current_stream(self.device)
+        n, lo, hi = self.params.numel(), self._lo, self._hi
+        P, G, M, V, E = (t.data_ptr() for t in (self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.ema))
+        coef = self._scal.data_ptr() + 8
+        B.check(lib.fc_grad_clip_coef(G, n, None, 0, self.max_norm, self._scal.data_ptr() + 4, self._ws.data_ptr(), st))
+        b1, b2 = self.betas
+        self.step_main += 1
+
+        def run(a, b, step, adam):
+            if b > a:
+                B.check(lib.fc_adam_ema_step(P + 4 * a, G + 4 * a, M + 4 * a, V + 4 * a, E + 4 * a, b - a, coef, self.lr, b1, b2, self.eps,
+                                             max(step, 1), self.ema_decay, int(adam), st))
+        if hi > lo:
+            if has_class_grads:
+                self.step_class += 1
+            run(0, lo, self.step_main, True)
+            run(lo, hi, self.step_class, has_class_grads)
+            run(hi, n, self.step_main, True)
+        else:
+            run(0, n, self.step_main, True)
+        self.model.sync_flat()
+
+    # ---- the step -------------------------------------------------------------------------------------------------
+    def step(self, source, target, cond=None, u: Optional[torch.Tensor] = None):
+        """train_flow.py:346-397 for one batch: returns the loss as a 0-d device tensor (no host sync)."""
+        dev = self.device
+        source = source.to(dev, torch.float32).contiguous()
+        target = target.to(dev, torch.float32).contiguous()
+        bsz = target.shape[0]
+        if u is None:
+            u = torch.rand(bsz, device=dev)
+        t = warp_time(u.to(dev, torch.float32) * (1 - self.t_eps) + self.t_eps).contiguous()
+        cls = cond.get('class_cond') if isinstance(cond, dict) else None
+        if isinstance(cond, dict) and cond.get('mask_cond') is not None:
+            raise NotImplementedError("FlowTrainer: mask-conditioned training is not built")
+        if cls is not None and not self.model.class_condition:
+            cls = None
+        if cls is not None:
+            cls = cls.to(dev, torch.int64).contiguous()
+        x, v_target = self.interpolate(source, target, t)
+        loss, _ = self.loss_and_grads(x, t, cls, v_target)
+        loss = loss.clone()
+        if self.distributed:                                     # DDP semantics: average the gradients over ranks
+            average_gradients(self.grads, self.pg)
+        self.optimizer_step(has_class_grads=cls is not None)
+        return loss
+
+    def train_batch(self, batch, epoch=None, cfg_drop: float = 0.1, mask_encoder=None, blank_latents=None):
+        """batch_to_data + the 10 % conditioning drop of train_flow.py:338-345 + step."""
+        source, target, class_cond, mask_cond, _ = batch_to_data(batch, self.device, True, mask_encoder, epoch=epoch, blank_latents=blank_latents)
+        cond = {'class_cond': class_cond, 'mask_cond': mask_cond}
+        if random.random() < cfg_drop:
+            cond = None
+            source = torch.randn_like(source)
+        return self.step(source, target, cond)
+
+    # ---- state ----------------------------------------------------------------------------------------------------
+    @property
+    def grad_norm(self):
+        return self._scal[1]
+
+    def ema_state_dict(self) -> Dict[str, torch.Tensor]:
+        return {k: v.clone() for k, v in self.model.grad_views(self.ema).items()}
+
+    def swap_ema(self):
+        """EMA.eval() / EMA.train() (train_flow.py:56-71): exchange the live and the averaged weights."""
+        tmp = self.params.clone()
+        self.params.copy_(self.ema)
+        self.ema.copy_(tmp)
+        self.model.sync_flat()
+
+    def state_dict(self):
+        return {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "ema": self.ema.clone(),
+                "step_main": self.step_main, "step_class": self.step_class}
+
+    def load_state_dict(self, sd):
+        self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"]); self.ema.copy_(sd["ema"])
+        self.step_main, self.step_class = int(sd["step_main"]), int(sd["step_class"])

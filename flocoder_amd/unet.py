@@ -54,6 +54,29 @@ class _Node(nn.Module):
     """Parameter container; attribute names reproduce the reference's module tree."""
 
 
+class _UnetFunction(torch.autograd.Function):
+    """Autograd bridge: forward and backward both run in the library; parameters receive ``.grad`` as torch expects."""
+
+    @staticmethod
+    def forward(ctx, model, x, time, cls, *params):
+        ctx.model, ctx.cls = model, cls
+        ctx.save_for_backward(x, time)
+        return model._forward_native(x, time, cls, None, train=True)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, time = ctx.saved_tensors
+        model = ctx.model
+        flat = model.backward_native(x, time, ctx.cls, d_out)
+        grads = []
+        for name, shape, off in model._table:
+            if ctx.cls is None and name.startswith("class_cond_mlp."):
+                grads.append(None)                                # unused this step: p.grad stays None, as in the reference
+            else:
+                grads.append(flat[off:off + math.prod(shape)].view(shape).clone())
+        return (None, None, None, None, *grads)
+
+
 class Unet(nn.Module):
     def __init__(self, dim, dim_mults=(1, 2, 4, 8), channels=3, resnet_block_groups=4, n_classes=10, mask_cond=False,
                  use_checkpoint=False):
@@ -188,8 +211,6 @@ class Unet(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("flocoder_amd.Unet runs on MI355X (gfx950) only; there is no CPU path "
                                "(the CPU restatement under oracle/ is test infrastructure).")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
-            raise NotImplementedError("flocoder_amd.Unet: backward kernels are not built yet; call under torch.no_grad() / .eval()")
         dev = x.device
         bsz, ch, h, w = x.shape
         if ch != self.channels:
@@ -203,20 +224,67 @@ class Unet(nn.Module):
             cls = None                                            # hasattr(self,'class_cond_mlp') is False, unet.py:315
         if cls is not None:
             cls = cls.to(device=dev, dtype=torch.int64).contiguous()
-        ones = 0
         if mask is not None and not self._cfg.mask_cond:
             mask = None                                           # hasattr(self,'mask_fusion_conv') is False, unet.py:298
         if mask is not None:
             mask = mask.to(device=dev, dtype=torch.float32).contiguous()
             if mask.shape != x.shape:
                 raise ValueError("mask_cond must have the shape of x (unet.py:302)")
+        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
+            # loss.backward() support (train_flow.py:358-371): gradients come from the library's backward plan
+            if mask is not None:
+                raise NotImplementedError("flocoder_amd.Unet: the backward pass of the mask-conditioning branches is not built")
+            params = [self.get_parameter(n) for n, _, _ in self._table]
+            return _UnetFunction.apply(self, x, time, cls, *params)
+        return self._forward_native(x, time, cls, mask, train=False)
+
+    def _forward_native(self, x, time, cls, mask, train: bool) -> torch.Tensor:
+        dev = x.device
+        bsz, _, h, w = x.shape
+        ones = 0
+        if mask is not None:
             ones = int(torch.allclose(mask, torch.ones_like(mask)))   # unet.py:301 (one host sync, as upstream)
         hnd = self._native(dev)
-        B.check(B.lib().fc_unet_reserve(hnd, bsz, h, w))
+        B.check((B.lib().fc_unet_train_reserve if train else B.lib().fc_unet_reserve)(hnd, bsz, h, w))
         out = torch.empty_like(x)
         B.check(B.lib().fc_unet_forward(hnd, B.ptr(x), B.ptr(time), B.ptr(cls), B.ptr(mask), ones, B.ptr(out), bsz, h, w,
                                         B.current_stream(dev)))
         return out
+
+    def backward_native(self, x, time, cls, d_out, grads: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Parameter gradients of the LAST training forward (same x / time / class ids) for d(out) = ``d_out``: a flat fp32
+        vector in the library's table layout (``grad_views`` splits it).  train_flow.py:371 loss.backward()."""
+        dev = x.device
+        bsz, _, h, w = x.shape
+        if grads is None:
+            grads = torch.empty(self._flat_numel, dtype=torch.float32, device=dev)
+        B.check(B.lib().fc_unet_backward(self._native(dev), B.ptr(x), B.ptr(time), B.ptr(cls), B.ptr(d_out.contiguous()), B.ptr(grads),
+                                         grads.numel(), bsz, h, w, B.current_stream(dev)))
+        return grads
+
+    def grad_views(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        return {name: flat[off:off + math.prod(shape)].view(shape) for name, shape, off in self._table}
+
+    def class_param_range(self) -> Tuple[int, int]:
+        """[lo, hi) of class_cond_mlp.* inside the flat table (these get no gradient when a step runs without conditioning)."""
+        names = [(off, off + (math.prod(shape) + 3) // 4 * 4) for name, shape, off in self._table if name.startswith("class_cond_mlp.")]
+        return (min(a for a, _ in names), max(b for _, b in names)) if names else (0, 0)
+
+    def adopt_flat(self, flat: torch.Tensor) -> None:
+        """Make every parameter a view into ``flat`` (table layout) so that an optimiser working on the flat vector updates the
+        module in place; ``sync_flat`` then hands the new values to the library without a gather."""
+        with torch.no_grad():
+            for name, shape, off in self._table:
+                p = self.get_parameter(name)
+                flat[off:off + math.prod(shape)].copy_(p.detach().reshape(-1))
+                p.data = flat[off:off + math.prod(shape)].view(shape)
+        self._flat = flat
+
+    def sync_flat(self) -> None:
+        flat = self._flat
+        hnd = self._native(flat.device) if self._handle is None else self._handle
+        B.check(B.lib().fc_unet_load_params(hnd, flat.data_ptr(), flat.numel(), 1, B.current_stream(flat.device)))
+        self._synced_version = self._version()
 
     # ------------------------------------------------------------------ integrators (used by flocoder_amd.sampling)
     def integrate(self, method: str, x: torch.Tensor, ts: torch.Tensor, *, dt_euler: float = 0.0, t_scale: float = 999.0,

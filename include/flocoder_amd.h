@@ -137,6 +137,37 @@ int fc_debug_conv(const float* src0_nhwc, int c0, const float* src1_nhwc, int c1
                   float* ms_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Flow training step  (replaces train_flow.py:346-397: interpolation, loss.backward() through flocoder/unet.py,
+ * clip_grad_norm_, torch.optim.Adam.step, EMA.update :46-54).  All vectors are caller-owned device memory.
+ * ---------------------------------------------------------------------------------------------- */
+/* Forward plan (fc_unet_reserve) plus the backward plan over the same arena.  Not available with mask_cond. */
+int fc_unet_train_reserve(fc_unet* u, int max_batch, int height, int width);
+/* Gradients of all parameters for the LAST fc_unet_forward(x, time, ids) on this handle (same arguments again), given d(out):
+ * grads_flat_dev[numel] in the parameter table's layout (fc_unet_param_info offsets; padding stays zero).  With ids == NULL
+ * the class_cond_mlp.* range receives no gradient (zeros); an optimiser must skip it as torch skips p.grad is None. */
+int fc_unet_backward(fc_unet* u, const float* x_dev, const float* time_dev, const int64_t* class_ids_dev, const float* d_out_dev,
+                     float* grads_flat_dev, int64_t numel, int batch, int height, int width, void* stream);
+/* [lo, hi) of class_cond_mlp.* inside the flat table (0,0 without classes). */
+int fc_unet_class_param_range(const fc_unet* u, int64_t* lo, int64_t* hi);
+/* x = (1-t) source + t target ; v* = target - source   (train_flow.py:350-353), t per sample. */
+int fc_flow_interp(const float* source_dev, const float* target_dev, const float* t_dev, float* x_out_dev, float* v_out_dev, int batch,
+                   int64_t per_sample, void* stream);
+/* loss = mean((v - v*)^2) (train_flow.py:359) and, when dv_out_dev != NULL, its gradient 2 (v - v*) / numel.  ws: 256 floats. */
+int fc_mse_loss_grad(const float* v_dev, const float* target_dev, float* dv_out_dev, float* loss_out_dev, float* ws256_dev, int64_t numel,
+                     void* stream);
+/* clip_grad_norm_ (train_flow.py:392): out[0] = 2-norm over both ranges, out[1] = min(1, max_norm / (norm + 1e-6)). */
+int fc_grad_clip_coef(const float* grads_dev, int64_t numel, const float* grads2_dev, int64_t numel2, float max_norm, float* norm_coef_out_dev,
+                      float* ws256_dev, void* stream);
+/* One torch.optim.Adam step (no weight decay / amsgrad) on grads * (*clip_coef_dev), bias corrections for step count `step`
+ * (1-based), followed by ema = decay ema + (1 - decay) p.  apply_adam == 0: EMA only (parameters without a gradient). */
+int fc_adam_ema_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, float* ema_dev, int64_t numel,
+                     const float* clip_coef_dev, float lr, float beta1, float beta2, float eps, int step, float ema_decay, int apply_adam,
+                     void* stream);
+/* test hook: weight / bias gradient of one convolution (NHWC operands, dw in [O][I][KH][KW]) */
+int fc_debug_conv_wgrad(const float* src0, int c0, const float* src1, int c1, const float* dy, int cout, int batch, int hs, int ws, int ksize,
+                        int pad, int stride, int upsample, float* dw_out, float* db_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * SD-VAE codec  (replaces flocoder/codecs.py:631-663 SD_VAE_Wrapper -> diffusers AutoencoderKL, sd-vae-ft-mse config)
  * ---------------------------------------------------------------------------------------------- */
 typedef struct fc_vae fc_vae;

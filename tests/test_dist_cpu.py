@@ -65,3 +65,31 @@ def test_broadcast_and_gather_world2_gloo():
     assert was0 and not was1                             # ... and rank 1 did not before
     assert span0 == (0, 4) and span1 == (4, 7)
     assert full0 == full1 == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0]   # gather restores global sample order
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from flocoder_amd import dist as fdist
+    fdist.init(backend="gloo")
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)          # rank r holds (r+1) * base
+    n = fdist.average_gradients(g, bucket_bytes=1024)                 # 256-float buckets -> 4 collectives
+    q.put((rank, n, g.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_averaging_world2_gloo():
+    """The training step's only collective (flocoder_amd.train.FlowTrainer.step): bucketed all-reduce + divide == DDP averaging."""
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = (torch.arange(1000, dtype=torch.float32) * 1.5).tolist()
+    assert res[0][1] == res[1][1] == 4
+    assert res[0][2] == want and res[1][2] == want
