@@ -49,6 +49,21 @@ def synthetic_inputs(rank, world, device):
     return noise[lo:hi].to(device).contiguous(), ids[lo:hi].to(device)
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
+    tools/pmc_forward.py, summarised by tools/pmc_summary.py with the guide's gfx950 correction).  A process cannot collect
+    hardware counters on itself, so the figure comes from the newest profiles/*pmc_traffic.json; null when there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        return d["per_kernel"][kernel]["traffic_bytes_per_launch"], os.path.basename(files[-1])
+    except (KeyError, ValueError, OSError):
+        return None, None
+
+
 def roofline(model, batch):
     rows = model.profile_ops(batch, repeats=20)
     by = {}
@@ -59,9 +74,11 @@ def roofline(model, batch):
     total_ms = sum(v["ms"] for v in by.values())
     rows_timed = rows[0]["rows"]
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    traffic, traffic_src = pmc_traffic(name)
     return {
         "bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+        "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (avg over the kernel's launch sites)",
+        "traffic_source": traffic_src,
         "launches_per_forward": dom["launches"], "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
         "flops_per_launch_avg": dom["flops"] / dom["launches"], "share_of_forward_time": round(dom["ms"] / total_ms, 3),
         "forward_sum_of_kernels_ms": round(total_ms, 4),
