@@ -141,6 +141,23 @@ int ss_launch(const float* t, const float* wt, const float* bias, float* ss, int
 int linattn_ctx_launch(const float* qkv, float* ctx /*[B][heads][32][32]*/, int B, int n, int heads, hipStream_t s);
 int linattn_apply_launch(const float* qkv, const float* ctx, float* out /*[B][n][heads*32]*/, int B, int n, int heads,
                          hipStream_t s);
+// The whole Residual(PreNorm(LinearAttention)) body up to to_out.0 in two launches, nothing but x in and y out (linattn_fused.hip)
+struct LaArgs {
+    const float* x = nullptr;      // NHWC [B][n][C], raw (the PreNorm's GroupNorm(1) is applied on load)
+    SrcXform xf;                   // mode 1, G = 1: statistics / gamma / beta of fn.norm
+    const float* wqkv = nullptr;   // packed [C][3*128]
+    const float* wout = nullptr;   // packed [128][C]
+    const float* bout = nullptr;   // [C]
+    float* ctx = nullptr;          // [B][4][32][32] scratch
+    float* y = nullptr;            // NHWC [B][n][C]: to_out.0 output (before to_out.1's GroupNorm)
+    float* stats_out = nullptr;    // GroupNorm(1) partials of y: [B][1][T][2], T = linattn_fused_tiles(n), n_t = linattn_fused_nt(n, C)
+    int B = 0, n = 0, C = 0, heads = 4;
+};
+int linattn_fused_init();
+bool linattn_fused_supported(int n, int C, int heads);
+int linattn_fused_tiles(int n);
+float linattn_fused_nt(int n, int C);
+int linattn_fused_launch(const LaArgs& a, hipStream_t s);
 // SpatialNonLocalAttention (codecs.py:337-383) for a handful of channels: x NHWC [B][n][C] -> x + out_proj(softmax(rope(q) rope(k)^T) v)
 int rope_attn_launch(const float* x, const float* wq, const float* bq, const float* wk, const float* bk, const float* wv, const float* bv,
                      const float* wo, const float* bo, float* out, int B, int n, int C, int Cr, hipStream_t s);

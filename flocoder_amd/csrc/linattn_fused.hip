@@ -1,0 +1,604 @@
+// Residual(PreNorm(LinearAttention)) (unet.py:125-161) without ever materialising q, k, v or the attention output:
+//
+//   la_ctx    grid (heads, B): k, v = GroupNorm(x) . Wk, Wv on the matrix pipe, 32 positions at a time per wave, fed straight into
+//             an ONLINE softmax over the positions (running column maximum, rescaled accumulators) and the 32x32 context
+//             ctx[d][e] = sum_n softmax_n(k)[d][n] v[e][n], itself an MFMA over the positions.  The four waves' partial
+//             (max, sum, context) triples are merged at the end.  Traffic: x once per head, the context out.
+//   la_apply  grid (ceil(n/128), B): q = GroupNorm(x) . Wq, softmax over the head dimension by lane shuffles, out = q . ctx,
+//             y = out . Wout + b, all per 32-row tile per wave with the operands handed between the three GEMMs through a
+//             4 KB LDS tile; epilogue writes y and the GroupNorm(1) partial of the tile for to_out.1.
+//
+// At the 32x32 level this replaces a 100 MB qkv round trip (to_qkv 32->384 over 65536 pixels) and two 33 MB passes by one
+// read of x per kernel.  fp32 MFMA throughout (exact products), so results match the unfused kernels to summation order.
+#include <cstdlib>
+
+#include "common.h"
+#include "stats_dev.h"
+
+namespace fc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define FC_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+constexpr int LDH = 32, LHEADS = 4, LHID = LHEADS * LDH, LC3 = 3 * LHID, PS = 33;
+
+__device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// stage rows [r0, r0+32) x channels [c0, c0+cl) of GroupNorm(x[b]) into a wave-private tile xw[32][XS]; rows >= n are zero
+__device__ __forceinline__ void stage_x(const LaArgs& a, const float* Ab, const float* Bb, float* xw, int XS, int b, int r0, int c0, int cl, int lane) {
+    const int q4 = cl >> 2;
+    for (int idx = lane; idx < 32 * q4; idx += 64) {
+        const int row = idx / q4, q = idx - row * q4, nn = r0 + row, c = c0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (nn < a.n) {
+            v = *reinterpret_cast<const float4*>(a.x + ((size_t)b * a.n + nn) * a.C + c);
+            v.x = Ab[c] * v.x + Bb[c]; v.y = Ab[c + 1] * v.y + Bb[c + 1]; v.z = Ab[c + 2] * v.z + Bb[c + 2]; v.w = Ab[c + 3] * v.w + Bb[c + 3];
+        }
+        float* d = xw + row * XS + 4 * q;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+}
+
+__global__ void __launch_bounds__(256) la_ctx_kernel(const LaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int C = a.C, CC = C < 64 ? C : 64, XS = CC + 1;
+    float* Ab = sm;
+    float* Bb = Ab + C;
+    float* Wl = Bb + C;                 // [C][64]: k columns | v columns of this head
+    float* xt = Wl + C * 64;            // [4][32][XS]
+    float* Et = xt + 4 * 32 * XS;       // [4][32][PS]
+    float* Vt = Et + 4 * 32 * PS;       // [4][32][PS]
+    float* sct = Vt + 4 * 32 * PS;      // [4][32]
+    float* mz = sct + 128;              // [4][2][32]
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    float mean, rstd;
+    combine_partials(a.xf, b, 0, &mean, &rstd);
+    for (int c = tid; c < C; c += 256) {
+        const float s = rstd * a.xf.gamma[c];
+        Ab[c] = s;
+        Bb[c] = a.xf.beta[c] - mean * s;
+    }
+    for (int i = tid; i < C * 64; i += 256) {
+        const int c = i >> 6, j = i & 63;
+        Wl[i] = a.wqkv[(size_t)c * LC3 + (j < 32 ? LHID + h * LDH + j : 2 * LHID + h * LDH + (j - 32))];
+    }
+    float* xw = xt + wave * 32 * XS;
+    float* Ew = Et + wave * 32 * PS;
+    float* Vw = Vt + wave * 32 * PS;
+    float* scw = sct + wave * 32;
+    const int nblk = (a.n + 31) >> 5, iters = (nblk + 3) >> 2;
+    f32x16 cacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cacc[r] = 0.f;
+    float m_run = -INFINITY, z_run = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        const int rb = it * 4 + wave, r0 = rb * 32;
+        const bool active = rb < nblk;
+        f32x16 ak, av;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ak[r] = 0.f; av[r] = 0.f; }
+        for (int c0 = 0; c0 < C; c0 += CC) {
+            const int cl = C - c0 < CC ? C - c0 : CC;
+            __syncthreads();
+            if (active) stage_x(a, Ab, Bb, xw, XS, b, r0, c0, cl, lane);
+            __syncthreads();
+            if (active) {
+                for (int s = 0; s < (cl >> 1); ++s) {
+                    const float xa = xw[l31 * XS + 2 * s + half];
+                    const float* wr = Wl + (c0 + 2 * s + half) * 64 + l31;
+                    ak = FC_MFMA(xa, wr[0], ak);
+                    av = FC_MFMA(xa, wr[32], av);
+                }
+            }
+        }
+        if (active) {
+            float bm = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) if (r0 + acc_row(r, half) < a.n) bm = fmaxf(bm, ak[r]);
+            bm = fmaxf(bm, __shfl_xor(bm, 32));
+            const float m_new = fmaxf(m_run, bm);
+            const float sc = __expf(m_run - m_new);
+            float zs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = acc_row(r, half);
+                const float e = (r0 + row < a.n) ? __expf(ak[r] - m_new) : 0.f;
+                zs += e;
+                Ew[row * PS + l31] = e;
+                Vw[row * PS + l31] = av[r];
+            }
+            zs += __shfl_xor(zs, 32);
+            z_run = z_run * sc + zs;
+            m_run = m_new;
+            if (half == 0) scw[l31] = sc;
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cacc[r] *= scw[acc_row(r, half)];
+#pragma unroll 4
+            for (int s = 0; s < 16; ++s) cacc = FC_MFMA(Ew[(2 * s + half) * PS + l31], Vw[(2 * s + half) * PS + l31], cacc);
+        }
+    }
+    // merge the four waves' (max, sum, context)
+    __syncthreads();
+    if (half == 0) { mz[(wave * 2) * 32 + l31] = m_run; mz[(wave * 2 + 1) * 32 + l31] = z_run; }
+    __syncthreads();
+    if (tid < 128) {
+        const int w = tid >> 5, d = tid & 31;
+        float M = mz[d];
+        for (int k = 1; k < 4; ++k) M = fmaxf(M, mz[(k * 2) * 32 + d]);
+        float Z = 0.f;
+        for (int k = 0; k < 4; ++k) Z += mz[(k * 2 + 1) * 32 + d] * __expf(mz[(k * 2) * 32 + d] - M);
+        sct[w * 32 + d] = __expf(mz[(w * 2) * 32 + d] - M) / Z;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int d = acc_row(r, half);
+        Et[(wave * 32 + d) * PS + l31] = cacc[r] * sct[wave * 32 + d];
+    }
+    __syncthreads();
+    for (int i = tid; i < LDH * LDH; i += 256) {
+        const int d = i >> 5, e = i & 31;
+        a.ctx[((size_t)(b * LHEADS + h) * LDH + d) * LDH + e] = (Et[d * PS + e] + Et[(32 + d) * PS + e]) + (Et[(64 + d) * PS + e] + Et[(96 + d) * PS + e]);
+    }
+}
+
+template <int CT>   // CT = ceil(C / 32) output-channel tiles of to_out
+__global__ void __launch_bounds__(256) la_apply_kernel(const LaArgs a, int T, float n_t) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int C = a.C, CC = C < 64 ? C : 64, XS = CC + 1, WO = CT * 32;
+    const int wc_floats = CC * LHID > 32 * WO ? CC * LHID : 32 * WO;
+    float* Ab = sm;
+    float* Bb = Ab + C;
+    float* Wc = Bb + C;                   // [CC][128] (Wq chunk), later [32][WO] (one head's rows of Wout)
+    float* xt = Wc + wc_floats;           // [4][32][XS]
+    float* Pt = xt + 4 * 32 * XS;         // [4][32][PS]
+    float* ctxl = Pt + 4 * 32 * PS;       // [4][32][PS]
+    __shared__ float red[4];
+    const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int r0 = tile * 128 + wave * 32;
+    float mean, rstd;
+    combine_partials(a.xf, b, 0, &mean, &rstd);
+    for (int c = tid; c < C; c += 256) {
+        const float s = rstd * a.xf.gamma[c];
+        Ab[c] = s;
+        Bb[c] = a.xf.beta[c] - mean * s;
+    }
+    for (int i = tid; i < LHEADS * LDH * LDH; i += 256) ctxl[(i >> 5) * PS + (i & 31)] = a.ctx[(size_t)b * LHEADS * LDH * LDH + i];
+    float* xw = xt + wave * 32 * XS;
+    float* Pw = Pt + wave * 32 * PS;
+    f32x16 q[LHEADS];
+#pragma unroll
+    for (int hh = 0; hh < LHEADS; ++hh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) q[hh][r] = 0.f;
+    for (int c0 = 0; c0 < C; c0 += CC) {
+        const int cl = C - c0 < CC ? C - c0 : CC;
+        __syncthreads();
+        for (int i = tid; i < cl * (LHID / 4); i += 256) {
+            const int cc = i / (LHID / 4), j = (i - cc * (LHID / 4)) * 4;
+            *reinterpret_cast<float4*>(Wc + cc * LHID + j) = *reinterpret_cast<const float4*>(a.wqkv + (size_t)(c0 + cc) * LC3 + j);
+        }
+        stage_x(a, Ab, Bb, xw, XS, b, r0, c0, cl, lane);
+        __syncthreads();
+        for (int s = 0; s < (cl >> 1); ++s) {
+            const float xa = xw[l31 * XS + 2 * s + half];
+            const float* wr = Wc + (2 * s + half) * LHID + l31;
+#pragma unroll
+            for (int hh = 0; hh < LHEADS; ++hh) q[hh] = FC_MFMA(xa, wr[hh * 32], q[hh]);
+        }
+    }
+    // softmax over the 32 head channels of every (row, head): a row's channels sit in the 32 lanes of one half-wave
+    const float scale = 0.17677669529663687f;
+#pragma unroll
+    for (int hh = 0; hh < LHEADS; ++hh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = q[hh][r];
+            float m = v;
+            m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
+            m = fmaxf(m, __shfl_xor(m, 8)); m = fmaxf(m, __shfl_xor(m, 16));
+            const float e = __expf(v - m);
+            float s = e;
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8); s += __shfl_xor(s, 16);
+            q[hh][r] = e * (scale / s);
+        }
+    f32x16 y[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[ct][r] = 0.f;
+#pragma unroll
+    for (int hh = 0; hh < LHEADS; ++hh) {
+        __syncthreads();
+        for (int i = tid; i < 32 * WO; i += 256) {
+            const int k = i / WO, c = i - k * WO;
+            Wc[i] = c < C ? a.wout[(size_t)(hh * LDH + k) * C + c] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Pw[acc_row(r, half) * PS + l31] = q[hh][r];
+        __syncthreads();
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) o = FC_MFMA(Pw[l31 * PS + 2 * s + half], ctxl[(hh * LDH + 2 * s + half) * PS + l31], o);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Pw[acc_row(r, half) * PS + l31] = o[r];
+        __syncthreads();
+#pragma unroll 2
+        for (int s = 0; s < 16; ++s) {
+            const float oa = Pw[l31 * PS + 2 * s + half];
+            const float* wr = Wc + (2 * s + half) * WO + l31;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) y[ct] = FC_MFMA(oa, wr[ct * 32], y[ct]);
+        }
+    }
+    float S = 0.f, Q = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int c = ct * 32 + l31;
+        const float bias = (c < C && a.bout) ? a.bout[c] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nn = r0 + acc_row(r, half);
+            if (nn < a.n && c < C) {
+                const float v = y[ct][r] + bias;
+                a.y[((size_t)b * a.n + nn) * C + c] = v;
+                S += v;
+                Q += v * v;
+            }
+        }
+    }
+    const float St = block_sum(S, red);
+    const float Qt = block_sum(Q, red);
+    if (tid == 0) {
+        const float mt = St / n_t;
+        float* d = a.stats_out + ((size_t)b * T + tile) * 2;
+        d[0] = mt;
+        d[1] = Qt - St * mt;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Fast path, C <= 64 and C % 8 == 0 (every n >= 256 level of the dim 16 / 32 models): the K loop is a single chunk, so all
+// weights stay in LDS for the life of the workgroup, the next 32-row tile of x travels HBM -> registers while the current one
+// is on the matrix pipe, and every LDS tile is private to its wave -- no workgroup barrier inside the loops (a wave's LDS
+// operations execute in order).
+template <int NQ>   // NQ = C / 8 float4 loads per lane per 32-row tile
+__device__ __forceinline__ void fetch_x(const LaArgs& a, int b, int r0, int lane, float4 (&pre)[NQ]) {
+    constexpr int q4 = NQ * 2;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int idx = lane + 64 * j, row = idx / q4, q = idx - row * q4, nn = r0 + row;
+        pre[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (nn < a.n) pre[j] = *reinterpret_cast<const float4*>(a.x + ((size_t)b * a.n + nn) * (NQ * 8) + 4 * q);
+    }
+}
+template <int NQ>
+__device__ __forceinline__ void store_x(const LaArgs& a, const float* Ab, const float* Bb, float* xw, int XS, int r0, int lane, const float4 (&pre)[NQ]) {
+    constexpr int q4 = NQ * 2;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int idx = lane + 64 * j, row = idx / q4, q = idx - row * q4, c = 4 * q;
+        float4 v = pre[j];
+        if (r0 + row < a.n) { v.x = Ab[c] * v.x + Bb[c]; v.y = Ab[c + 1] * v.y + Bb[c + 1]; v.z = Ab[c + 2] * v.z + Bb[c + 2]; v.w = Ab[c + 3] * v.w + Bb[c + 3]; }
+        float* d = xw + row * XS + c;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+}
+
+template <int NQ>
+__global__ void __launch_bounds__(256) la_ctx_fast_kernel(const LaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int C = NQ * 8, XS = C + 1;
+    float* Ab = sm;
+    float* Bb = Ab + C;
+    float* Wl = Bb + C;                 // [C][64]
+    float* xt = Wl + C * 64;            // [4][32][XS]
+    float* Et = xt + 4 * 32 * XS;       // [4][32][PS]
+    float* Vt = Et + 4 * 32 * PS;
+    float* sct = Vt + 4 * 32 * PS;      // [4][32]
+    float* mz = sct + 128;              // [4][2][32]
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int nblk = (a.n + 31) >> 5;
+    float4 pre[NQ];
+    if (wave < nblk) fetch_x<NQ>(a, b, wave * 32, lane, pre);
+    float mean, rstd;
+    combine_partials(a.xf, b, 0, &mean, &rstd);
+    for (int c = tid; c < C; c += 256) {
+        const float s = rstd * a.xf.gamma[c];
+        Ab[c] = s;
+        Bb[c] = a.xf.beta[c] - mean * s;
+    }
+    for (int i = tid; i < C * 64; i += 256) {
+        const int c = i >> 6, j = i & 63;
+        Wl[i] = a.wqkv[(size_t)c * LC3 + (j < 32 ? LHID + h * LDH + j : 2 * LHID + h * LDH + (j - 32))];
+    }
+    __syncthreads();
+    float* xw = xt + wave * 32 * XS;
+    float* Ew = Et + wave * 32 * PS;
+    float* Vw = Vt + wave * 32 * PS;
+    float* scw = sct + wave * 32;
+    f32x16 cacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cacc[r] = 0.f;
+    float m_run = -INFINITY, z_run = 0.f;
+    for (int rb = wave; rb < nblk; rb += 4) {
+        const int r0 = rb * 32;
+        store_x<NQ>(a, Ab, Bb, xw, XS, r0, lane, pre);
+        __builtin_amdgcn_wave_barrier();
+        if (rb + 4 < nblk) fetch_x<NQ>(a, b, r0 + 128, lane, pre);
+        f32x16 ak, av;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ak[r] = 0.f; av[r] = 0.f; }
+#pragma unroll 4
+        for (int s = 0; s < (C >> 1); ++s) {
+            const float xa = xw[l31 * XS + 2 * s + half];
+            const float* wr = Wl + (2 * s + half) * 64 + l31;
+            ak = FC_MFMA(xa, wr[0], ak);
+            av = FC_MFMA(xa, wr[32], av);
+        }
+        float bm = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) if (r0 + acc_row(r, half) < a.n) bm = fmaxf(bm, ak[r]);
+        bm = fmaxf(bm, __shfl_xor(bm, 32));
+        const float m_new = fmaxf(m_run, bm);
+        const float sc = __expf(m_run - m_new);
+        float zs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, half);
+            const float e = (r0 + row < a.n) ? __expf(ak[r] - m_new) : 0.f;
+            zs += e;
+            Ew[row * PS + l31] = e;
+            Vw[row * PS + l31] = av[r];
+        }
+        zs += __shfl_xor(zs, 32);
+        z_run = z_run * sc + zs;
+        m_run = m_new;
+        if (half == 0) scw[l31] = sc;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cacc[r] *= scw[acc_row(r, half)];
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) cacc = FC_MFMA(Ew[(2 * s + half) * PS + l31], Vw[(2 * s + half) * PS + l31], cacc);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    if (half == 0) { mz[(wave * 2) * 32 + l31] = m_run; mz[(wave * 2 + 1) * 32 + l31] = z_run; }
+    __syncthreads();
+    if (tid < 128) {
+        const int w = tid >> 5, d = tid & 31;
+        float M = mz[d];
+        for (int k = 1; k < 4; ++k) M = fmaxf(M, mz[(k * 2) * 32 + d]);
+        float Z = 0.f;
+        for (int k = 0; k < 4; ++k) Z += mz[(k * 2 + 1) * 32 + d] * __expf(mz[(k * 2) * 32 + d] - M);
+        sct[w * 32 + d] = __expf(mz[(w * 2) * 32 + d] - M) / Z;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int d = acc_row(r, half);
+        Et[(wave * 32 + d) * PS + l31] = cacc[r] * sct[wave * 32 + d];
+    }
+    __syncthreads();
+    for (int i = tid; i < LDH * LDH; i += 256) {
+        const int d = i >> 5, e = i & 31;
+        a.ctx[((size_t)(b * LHEADS + h) * LDH + d) * LDH + e] = (Et[d * PS + e] + Et[(32 + d) * PS + e]) + (Et[(64 + d) * PS + e] + Et[(96 + d) * PS + e]);
+    }
+}
+
+template <int NQ, int CT>
+__global__ void __launch_bounds__(256) la_apply_fast_kernel(const LaArgs a, int T, float n_t) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int C = NQ * 8, XS = C + 1 > PS ? C + 1 : PS, WO = CT * 32;
+    float* Ab = sm;
+    float* Bb = Ab + C;
+    float* Wq = Bb + C;                    // [C][128]
+    float* Wo = Wq + C * LHID;             // [128][WO]
+    float* ctxl = Wo + LHID * WO;          // [4][32][PS]
+    float* xt = ctxl + LHEADS * LDH * PS;  // [4][32][XS]: x tile, then the P / out tile of the head in flight
+    __shared__ float red[4];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int ntiles = (a.n + 127) >> 7;
+    float4 pre[NQ];
+    fetch_x<NQ>(a, b, blockIdx.x * 128 + wave * 32, lane, pre);
+    float mean, rstd;
+    combine_partials(a.xf, b, 0, &mean, &rstd);
+    for (int c = tid; c < C; c += 256) {
+        const float s = rstd * a.xf.gamma[c];
+        Ab[c] = s;
+        Bb[c] = a.xf.beta[c] - mean * s;
+    }
+    for (int i = tid; i < C * (LHID / 4); i += 256) {
+        const int cc = i / (LHID / 4), j = (i - cc * (LHID / 4)) * 4;
+        *reinterpret_cast<float4*>(Wq + cc * LHID + j) = *reinterpret_cast<const float4*>(a.wqkv + (size_t)cc * LC3 + j);
+    }
+    for (int i = tid; i < LHID * WO; i += 256) {
+        const int k = i / WO, c = i - k * WO;
+        Wo[i] = c < C ? a.wout[(size_t)k * C + c] : 0.f;
+    }
+    for (int i = tid; i < LHEADS * LDH * LDH; i += 256) ctxl[(i >> 5) * PS + (i & 31)] = a.ctx[(size_t)b * LHEADS * LDH * LDH + i];
+    __syncthreads();
+    float* xw = xt + wave * 32 * XS;
+    const float scale = 0.17677669529663687f;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int r0 = tile * 128 + wave * 32;
+        store_x<NQ>(a, Ab, Bb, xw, XS, r0, lane, pre);
+        __builtin_amdgcn_wave_barrier();
+        if (tile + (int)gridDim.x < ntiles) fetch_x<NQ>(a, b, r0 + 128 * gridDim.x, lane, pre);
+        f32x16 q[LHEADS];
+#pragma unroll
+        for (int hh = 0; hh < LHEADS; ++hh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) q[hh][r] = 0.f;
+#pragma unroll 2
+        for (int s = 0; s < (C >> 1); ++s) {
+            const float xa = xw[l31 * XS + 2 * s + half];
+            const float* wr = Wq + (2 * s + half) * LHID + l31;
+#pragma unroll
+            for (int hh = 0; hh < LHEADS; ++hh) q[hh] = FC_MFMA(xa, wr[hh * 32], q[hh]);
+        }
+        f32x16 y[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[ct][r] = 0.f;
+        float* Pw = xw;                     // the x tile is dead: its buffer carries P, then out, of each head (row stride XS >= 33)
+#pragma unroll
+        for (int hh = 0; hh < LHEADS; ++hh) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Pw[acc_row(r, half) * XS + l31] = q[hh][r];
+            __builtin_amdgcn_wave_barrier();
+            {   // softmax over the head's 32 channels: lane (row l31, half) owns 16 of them
+                float v[16];
+                float* pr = Pw + l31 * XS + half * 16;
+                float m = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { v[j] = pr[j]; m = fmaxf(m, v[j]); }
+                m = fmaxf(m, __shfl_xor(m, 32));
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { v[j] = __expf(v[j] - m); sum += v[j]; }
+                sum += __shfl_xor(sum, 32);
+                const float f = scale / sum;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) pr[j] = v[j] * f;
+            }
+            __builtin_amdgcn_wave_barrier();
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll 4
+            for (int s = 0; s < 16; ++s) o = FC_MFMA(Pw[l31 * XS + 2 * s + half], ctxl[(hh * LDH + 2 * s + half) * PS + l31], o);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Pw[acc_row(r, half) * XS + l31] = o[r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 2
+            for (int s = 0; s < 16; ++s) {
+                const float oa = Pw[l31 * XS + 2 * s + half];
+                const float* wr = Wo + (hh * LDH + 2 * s + half) * WO + l31;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) y[ct] = FC_MFMA(oa, wr[ct * 32], y[ct]);
+            }
+        }
+        float S = 0.f, Q = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int c = ct * 32 + l31;
+            const float bias = (c < C && a.bout) ? a.bout[c] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nn = r0 + acc_row(r, half);
+                if (nn < a.n && c < C) {
+                    const float v = y[ct][r] + bias;
+                    a.y[((size_t)b * a.n + nn) * C + c] = v;
+                    S += v;
+                    Q += v * v;
+                }
+            }
+        }
+        const float St = block_sum(S, red);
+        const float Qt = block_sum(Q, red);
+        if (tid == 0) {
+            const float mt = St / n_t;
+            float* d = a.stats_out + ((size_t)b * T + tile) * 2;
+            d[0] = mt;
+            d[1] = Qt - St * mt;
+        }
+    }
+}
+
+static size_t la_ctx_fast_lds(int C) { return (size_t)(2 * C + C * 64 + 4 * 32 * (C + 1) + 2 * 4 * 32 * PS + 128 + 256) * sizeof(float); }
+static size_t la_apply_fast_lds(int C, int CT) {
+    const int XS = C + 1 > PS ? C + 1 : PS;
+    return (size_t)(2 * C + C * LHID + LHID * CT * 32 + LHEADS * LDH * PS + 4 * 32 * XS) * sizeof(float);
+}
+template <int NQ>
+static int launch_fast(const LaArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(la_ctx_fast_kernel<NQ>, dim3(LHEADS, a.B), dim3(256), la_ctx_fast_lds(a.C), s, a);
+    FC_HIP(hipGetLastError());
+    const int T = linattn_fused_tiles(a.n);
+    const float n_t = linattn_fused_nt(a.n, a.C);
+    const int tiles = cdiv(a.n, 128);
+    int gx = tiles;                                   // two tiles per workgroup once that still leaves >= 256 workgroups
+    if (tiles >= 2 && (tiles / 2) * a.B >= 256) gx = tiles / 2;
+    const dim3 grid(gx, a.B);
+    if (a.C <= 32) hipLaunchKernelGGL((la_apply_fast_kernel<NQ, 1>), grid, dim3(256), la_apply_fast_lds(a.C, 1), s, a, T, n_t);
+    else hipLaunchKernelGGL((la_apply_fast_kernel<NQ, 2>), grid, dim3(256), la_apply_fast_lds(a.C, 2), s, a, T, n_t);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+template <int NQ>
+static int init_fast() {
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_ctx_fast_kernel<NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_apply_fast_kernel<NQ, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_apply_fast_kernel<NQ, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    return FC_OK;
+}
+
+static size_t la_ctx_lds(int C) {
+    const int CC = C < 64 ? C : 64;
+    return (size_t)(2 * C + C * 64 + 4 * 32 * (CC + 1) + 2 * 4 * 32 * PS + 128 + 256) * sizeof(float);
+}
+static size_t la_apply_lds(int C, int CT) {
+    const int CC = C < 64 ? C : 64, WO = CT * 32;
+    const int wc = CC * LHID > 32 * WO ? CC * LHID : 32 * WO;
+    return (size_t)(2 * C + wc + 4 * 32 * (CC + 1) + 2 * 4 * 32 * PS) * sizeof(float);
+}
+
+int linattn_fused_tiles(int n) { return n >= 128 ? n / 128 : 1; }
+float linattn_fused_nt(int n, int C) { return (float)((n >= 128 ? 128 : n) * C); }
+
+int linattn_fused_init() {
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_ctx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_apply_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_apply_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_apply_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_apply_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    FC_TRY(init_fast<1>()); FC_TRY(init_fast<2>()); FC_TRY(init_fast<4>()); FC_TRY(init_fast<8>());
+    return FC_OK;
+}
+
+bool linattn_fused_supported(int n, int C, int heads) {
+    if (heads != LHEADS || (C & 3) || C > 256 || n < 1) return false;
+    if (n >= 128 && (n & 127)) return false;
+    return la_ctx_lds(C) <= 160 * 1024;
+}
+
+int linattn_fused_launch(const LaArgs& a, hipStream_t s) {
+    if (!linattn_fused_supported(a.n, a.C, a.heads)) return fail(FC_E_SHAPE, "linattn_fused: unsupported shape");
+    if (a.xf.mode != 1 || a.xf.G != 1 || !a.xf.stats) return fail(FC_E_ARG, "linattn_fused: needs GroupNorm(1) statistics of x");
+    static const bool no_fast = std::getenv("FLOCODER_AMD_LINATTN_GENERAL") != nullptr;
+    if (!no_fast && a.C <= 64 && (a.C & 7) == 0 && (a.C == 8 || a.C == 16 || a.C == 32 || a.C == 64)) {
+        switch (a.C) {
+            case 8: return launch_fast<1>(a, s);
+            case 16: return launch_fast<2>(a, s);
+            case 32: return launch_fast<4>(a, s);
+            default: return launch_fast<8>(a, s);
+        }
+    }
+    hipLaunchKernelGGL(la_ctx_kernel, dim3(LHEADS, a.B), dim3(256), la_ctx_lds(a.C), s, a);
+    FC_HIP(hipGetLastError());
+    const int T = linattn_fused_tiles(a.n);
+    const float n_t = linattn_fused_nt(a.n, a.C);
+    const int CT = a.C <= 32 ? 1 : a.C <= 64 ? 2 : a.C <= 128 ? 4 : 8;
+    const dim3 grid(cdiv(a.n, 128), a.B);
+    const size_t lds = la_apply_lds(a.C, CT);
+    switch (CT) {
+        case 1: hipLaunchKernelGGL(la_apply_kernel<1>, grid, dim3(256), lds, s, a, T, n_t); break;
+        case 2: hipLaunchKernelGGL(la_apply_kernel<2>, grid, dim3(256), lds, s, a, T, n_t); break;
+        case 4: hipLaunchKernelGGL(la_apply_kernel<4>, grid, dim3(256), lds, s, a, T, n_t); break;
+        default: hipLaunchKernelGGL(la_apply_kernel<8>, grid, dim3(256), lds, s, a, T, n_t); break;
+    }
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+}  // namespace fc

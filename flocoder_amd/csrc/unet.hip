@@ -168,6 +168,10 @@ struct Builder : PlanBuilder {
     Act linattn(const std::string& p, const Act& x, const Stat& gn1) {
         scope = p;
         const int hid = u->heads * 32, n = x.H * x.W, heads = u->heads;
+        static const bool no_fuse = [] { const char* e = std::getenv("FLOCODER_AMD_LINATTN"); return e && std::string(e) == "unfused"; }();
+        // measured (tools/op_table.py, B=64): fused 110 vs 201 us at n=1024, 43 vs 65 us at n=256; at n <= 64 the per-workgroup weight
+        // loads dominate and the unfused chain wins (37 vs 67 us at n=16, C=256)
+        if (!u->keep_all && !no_fuse && n >= 256 && linattn_fused_supported(n, x.C, heads)) return linattn_fused(p, x, gn1);
         Act qkv = act(3 * hid, x.H, x.W), lao = act(hid, x.H, x.W), yb = act(x.C, x.H, x.W), out = act(x.C, x.H, x.W);
         float* ctx = dmalloc((size_t)B * heads * 32 * 32);
         ConvArgs a;
@@ -194,6 +198,25 @@ struct Builder : PlanBuilder {
         rec.p = p; rec.x = x; rec.qkv = qkv; rec.lao = lao; rec.yb = yb; rec.out = out; rec.ctx = ctx; rec.gn1 = gn1; rec.sty = sty;
         pl->tape.push_back({1, (int)pl->lin.size()});
         pl->lin.push_back(rec);
+        return out;
+    }
+
+    // the same module on the fused kernels (linattn_fused.hip): x -> context -> y in two launches, q/k/v never stored
+    Act linattn_fused(const std::string& p, const Act& x, const Stat& gn1) {
+        const int n = x.H * x.W, heads = u->heads, hid = heads * 32;
+        Act yb = act(x.C, x.H, x.W), out = act(x.C, x.H, x.W);
+        Stat sty = stat(1, linattn_fused_tiles(n), linattn_fused_nt(n, x.C));
+        LaArgs a;
+        a.x = x.p; a.xf = xf_of(gn1, 1, u->R(p + ".fn.norm.weight"), u->R(p + ".fn.norm.bias"));
+        a.wqkv = u->P(p + ".fn.fn.to_qkv.weight"); a.wout = u->P(p + ".fn.fn.to_out.0.weight"); a.bout = u->R(p + ".fn.fn.to_out.0.bias");
+        a.ctx = dmalloc((size_t)B * heads * 32 * 32); a.y = yb.p; a.stats_out = sty.p; a.n = n; a.C = x.C; a.heads = heads;
+        const double fl = 2.0 * n * (double)x.C * 3 * hid + 2.0 * 2 * n * 32 * 32 * heads + 2.0 * n * (double)hid * x.C;
+        if (!err) push([a](const FwdCtx& c, hipStream_t s) { LaArgs b = a; b.B = c.B; return linattn_fused_launch(b, s); }, "linattn_fused", fl);
+        FinalizeArgs f;
+        f.h = yb.p; f.xf = xf_of(sty, 1, u->R(p + ".fn.fn.to_out.1.weight"), u->R(p + ".fn.fn.to_out.1.bias"));
+        f.res = x.p; f.y = out.p; f.HW = n; f.C = x.C;
+        if (!err) push([f](const FwdCtx& c, hipStream_t s) { FinalizeArgs g = f; g.B = c.B; return finalize_launch(g, s); }, "finalize");
+        pl->named[p] = out; pl->named[p + ".y"] = yb;
         return out;
     }
 
@@ -524,6 +547,7 @@ int fc_unet_create(const fc_unet_config* cfg, int device, fc_unet** out) {
     FC_TRY(fc_check_device(device));
     FC_HIP(hipSetDevice(device));
     FC_TRY(conv_init());
+    FC_TRY(linattn_fused_init());
     FC_TRY(u->alloc_device());
     const int half = cfg->dim / 2;
     std::vector<float> fr(half);

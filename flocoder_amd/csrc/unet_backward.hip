@@ -362,6 +362,15 @@ int build_backward(fc_unet* u) {
 extern "C" {
 
 int fc_unet_train_reserve(fc_unet* u, int max_batch, int height, int width) {
+    if (!u) return fail(FC_E_ARG, "fc_unet_train_reserve: null handle");
+    if (!u->keep_all && u->device >= 0) {   // from now on this object's plans keep q/k/v and the attention output for the backward
+        u->keep_all = true;
+        if (u->maxB > 0) {                  // an inference plan exists: rebuild it in keep-everything form
+            const int mb = u->maxB > max_batch ? u->maxB : max_batch;
+            u->maxB = 0;
+            FC_TRY(fc_unet_reserve(u, mb, height, width));
+        }
+    }
     FC_TRY(fc_unet_reserve(u, max_batch, height, width));
     if (u->bwd.maxB == u->plan[0].maxB && u->bwd.H == height && u->bwd.W == width && u->bwd.maxB > 0) return FC_OK;
     FC_HIP(hipSetDevice(u->device));

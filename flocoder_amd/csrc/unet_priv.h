@@ -33,6 +33,8 @@ struct fc_unet : fc::ParamStore {
     int64_t* ids_own = nullptr;
     std::map<std::tuple<int, int, int, int, uint32_t, uint32_t, uint32_t, int>, hipGraphExec_t> graphs;
 
+    bool keep_all = false;   // plans keep every intermediate (q/k/v, attention output) for the backward: set by fc_unet_train_reserve
+
     // training (unet_backward.hip): backward launch plan over the forward arena, data-gradient weight operands
     fc::Plan bwd;
     struct DgradPack { int64_t src; float* dst; int O, I, KS, ci0, nci; };
