@@ -106,6 +106,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
     float* partQ = partS + (BM / 16) * BN;        // [BM/16][BN]
     if (a.stats_out) __syncthreads();             // patch/wl (aliased by part*) are dead for every wave
 
+    // Statistics first, stores last: a workgroup barrier waits for every outstanding global store (s_waitcnt vmcnt(0)), so a
+    // barrier AFTER the output stores would park the whole workgroup for the store round trip (measured: 6 K of a 66 K-cycle
+    // kernel, profiles/r01_c_stamps.txt).  With the stores as the last thing a wave does, they drain while the next workgroup starts.
     if (owner) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -114,25 +117,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                 const int ncol = (wn * NT + nt) * 32 + l31, n = n0 + ncol;
                 const bool nok = n < Cout;
                 const float bias = (a.bias && nok) ? a.bias[n] : 0.f;
-                const float rbias = (has_res && a.res_b && nok) ? a.res_b[n] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mt][nt][r] += bias;
-                size_t off[16];
-                bool ok[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const int tw = m & (TW - 1), th = (m >> p.TWl) & (TH - 1), tb = m >> (p.TWl + p.THl);
-                    const int b = b0 + tb;
-                    ok[r] = nok && b < a.B;
-                    off[r] = ((size_t)(b * a.H + y0 + th) * a.W + x0 + tw) * Cout + n;
-                }
                 if (a.stats_post) {   // statistics of the FINAL value (activation and residual included): pre-norm resnets (SD-VAE)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
+                        const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        const int tw = m & (TW - 1), th = (m >> p.TWl) & (TH - 1), tb = m >> (p.TWl + p.THl);
+                        const int b = b0 + tb;
                         float v = acc[mt][nt][r];
                         if (a.out_act) v = silu_f(v);
-                        if (a.add && ok[r]) v += a.add[off[r]];
+                        if (a.add && nok && b < a.B) v += a.add[((size_t)(b * a.H + y0 + th) * a.W + x0 + tw) * Cout + n];
                         acc[mt][nt][r] = v;
                     }
                 }
@@ -149,18 +144,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                             partS[hb * BN + ncol] = s;
                             partQ[hb * BN + ncol] = q;
                         }
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (ok[r]) {
-                        float v = acc[mt][nt][r];
-                        if (!a.stats_post) {
-                            if (a.out_act) v = silu_f(v);
-                            if (a.add) v += a.add[off[r]];
-                        }
-                        a.out[off[r]] = v;
-                        if (has_res) a.res_out[off[r]] = accr[mt][nt][r] + rbias;
                     }
                 }
             }
@@ -194,6 +177,33 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                 d[1] = q - s * mean;
             }
         }
+    }
+
+    if (owner) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int ncol = (wn * NT + nt) * 32 + l31, n = n0 + ncol;
+                const bool nok = n < Cout;
+                const float rbias = (has_res && a.res_b && nok) ? a.res_b[n] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int tw = m & (TW - 1), th = (m >> p.TWl) & (TH - 1), tb = m >> (p.TWl + p.THl);
+                    const int b = b0 + tb;
+                    if (nok && b < a.B) {
+                        const size_t off = ((size_t)(b * a.H + y0 + th) * a.W + x0 + tw) * Cout + n;
+                        float v = acc[mt][nt][r];
+                        if (!a.stats_post) {
+                            if (a.out_act) v = silu_f(v);
+                            if (a.add) v += a.add[off];
+                        }
+                        a.out[off] = v;
+                        if (has_res) a.res_out[off] = accr[mt][nt][r] + rbias;
+                    }
+                }
+            }
     }
     conv_stamp(p, 8);
 }

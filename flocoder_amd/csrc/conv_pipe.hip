@@ -99,8 +99,11 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvDev p) {
     const int nchunks = p.nchunks;
     conv_stamp(p, 0);
 
-    // ---- GroupNorm tables: moments per (sample, group), then the folded affine per (sample, channel) -- all 512 threads ----
-    if (p.any_xf) {
+    // ---- GroupNorm tables: moments per (sample, group), then the folded affine per (sample, channel) -- all 512 threads.
+    // Run by the consumers at once and by the loaders AFTER they have put the first weight slabs in flight (two dependent
+    // global round trips that the slab transfer overlaps); both sides meet in the same two barriers.
+    auto gn_tables = [&]() {
+      if (p.any_xf) {
         const int G0 = a.s0.xf.mode ? a.s0.xf.G : 0, G1 = a.s1.xf.mode ? a.s1.xf.G : 0;
         for (int i = tid; i < p.TB * (G0 + G1); i += 512) {
             const bool first = i < p.TB * G0;
@@ -140,7 +143,8 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvDev p) {
             aff[i] = make_float2(A, Bv);
         }
         __syncthreads();
-    }
+      }
+    };
 
     f32x16 acc[MT][NT], accr[MT][NT];
 #pragma unroll
@@ -235,6 +239,7 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvDev p) {
         unsigned long long dbg_mem = 0, dbg_store = 0, dbg_bar = 0, dbg_issue = 0, dbg_dma = 0;   // diagnostics: cycles per loader phase
         dma_weights(0);
         if (nwb == 3 && nchunks > 1) dma_weights(1);
+        gn_tables();
         issue_patch(0);
         wait_vmcnt(0);
         store_patch(0);
@@ -274,6 +279,7 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvDev p) {
         const int kk0 = wk * KPW;
         unsigned long long dbg_cbar = 0;
         conv_stamp(p, 1);
+        gn_tables();
         __syncthreads();        // stage 0 ready
         conv_stamp(p, 4);
         for (int i = 0; i < nchunks; ++i) {

@@ -68,8 +68,8 @@ __global__ void __launch_bounds__(256) finalize_kernel(const FinalizeArgs a, int
         q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
     }
     if (a.stats_out) {
-        const float S = block_sum(s, red);
-        const float Q = block_sum(q, red);
+        const float S = block_sum_lds(s, red);    // LDS-only barriers: the output stores above stay in flight
+        const float Q = block_sum_lds(q, red);
         if (tid == 0) {
             const float mean = S / (float)per;
             float* d = a.stats_out + ((size_t)b * bps + blockIdx.x) * 2;

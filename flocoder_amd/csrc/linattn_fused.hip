@@ -237,6 +237,7 @@ __global__ void __launch_bounds__(256) la_apply_kernel(const LaArgs a, int T, fl
             for (int ct = 0; ct < CT; ++ct) y[ct] = FC_MFMA(oa, wr[ct * 32], y[ct]);
         }
     }
+    // statistics before the stores: a barrier after them would wait for the store round trip
     float S = 0.f, Q = 0.f;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
@@ -244,13 +245,9 @@ __global__ void __launch_bounds__(256) la_apply_kernel(const LaArgs a, int T, fl
         const float bias = (c < C && a.bout) ? a.bout[c] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int nn = r0 + acc_row(r, half);
-            if (nn < a.n && c < C) {
-                const float v = y[ct][r] + bias;
-                a.y[((size_t)b * a.n + nn) * C + c] = v;
-                S += v;
-                Q += v * v;
-            }
+            const float v = y[ct][r] + bias;
+            y[ct][r] = v;
+            if (r0 + acc_row(r, half) < a.n && c < C) { S += v; Q += v * v; }
         }
     }
     const float St = block_sum(S, red);
@@ -260,6 +257,15 @@ __global__ void __launch_bounds__(256) la_apply_kernel(const LaArgs a, int T, fl
         float* d = a.stats_out + ((size_t)b * T + tile) * 2;
         d[0] = mt;
         d[1] = Qt - St * mt;
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int c = ct * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nn = r0 + acc_row(r, half);
+            if (nn < a.n && c < C) a.y[((size_t)b * a.n + nn) * C + c] = y[ct][r];
+        }
     }
 }
 
@@ -495,13 +501,9 @@ __global__ void __launch_bounds__(256) la_apply_fast_kernel(const LaArgs a, int 
             const float bias = (c < C && a.bout) ? a.bout[c] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int nn = r0 + acc_row(r, half);
-                if (nn < a.n && c < C) {
-                    const float v = y[ct][r] + bias;
-                    a.y[((size_t)b * a.n + nn) * C + c] = v;
-                    S += v;
-                    Q += v * v;
-                }
+                const float v = y[ct][r] + bias;
+                y[ct][r] = v;
+                if (r0 + acc_row(r, half) < a.n && c < C) { S += v; Q += v * v; }
             }
         }
         const float St = block_sum(S, red);
@@ -511,6 +513,15 @@ __global__ void __launch_bounds__(256) la_apply_fast_kernel(const LaArgs a, int 
             float* d = a.stats_out + ((size_t)b * T + tile) * 2;
             d[0] = mt;
             d[1] = Qt - St * mt;
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int c = ct * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nn = r0 + acc_row(r, half);
+                if (nn < a.n && c < C) a.y[((size_t)b * a.n + nn) * C + c] = y[ct][r];
+            }
         }
     }
 }

@@ -16,6 +16,19 @@ __device__ __forceinline__ float block_sum(float v, float* red /*[4]*/) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global store
+// (s_waitcnt vmcnt(0)) -- a store round trip of idle time when the barrier only guards an LDS reduction that follows the stores.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ float block_sum_lds(float v, float* red /*[4]*/) {   // 256 threads
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    lds_barrier();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    lds_barrier();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
 // combine T equal-count (mean, M2) partials of group g of sample b
 __device__ __forceinline__ void combine_partials(const SrcXform& xf, int b, int g, float* mean_out, float* rstd_out) {
     const float* sp = xf.stats + (size_t)(b * xf.G + g) * xf.T * 2;
