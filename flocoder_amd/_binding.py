@@ -50,6 +50,8 @@ SIGNATURES = {
     "fc_debug_copy": (_i, [_vp, _vp, _i64, _vp]),
     "fc_debug_set_conv_stamps": (_i, [_vp]),
     "fc_debug_conv": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _pi, _pf, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _pf, _vp]),
+    "fc_debug_set_fused_tail": (_i, [_i]),
+    "fc_unet_fused_tail_errors": (_i, [_vp, C.POINTER(_i)]),
     "fc_unet_train_reserve": (_i, [_vp, _i, _i, _i]),
     "fc_unet_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "fc_unet_class_param_range": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),

@@ -60,6 +60,19 @@ struct ConvSrc {
     SrcXform xf;
 };
 
+// Fused tail of a Block (unet.py:66-72,96): instead of storing the raw convolution output, the workgroups of one sample (or
+// sample group) exchange their GroupNorm partials through `stats_out` and a per-group arrival counter, then finish
+// out = SiLU(GN(acc)) + res straight from the accumulators.  Needs every workgroup of the launch resident at once.
+struct ConvFin {
+    const float* gamma = nullptr;   // != nullptr switches the tail on
+    const float* beta = nullptr;
+    float eps = 1e-5f;
+    const float* res = nullptr;     // NHWC [B][H][W][Cout] residual or null
+    float* gn1_out = nullptr;       // optional GroupNorm(1) partials of the final value: [B][1][T1][2]
+    unsigned* sync = nullptr;       // one arrival counter per sample group (never reset: targets advance by the group size)
+    int* err = nullptr;             // set to 1 if a wait ever times out
+};
+
 struct ConvArgs {
     ConvSrc s0, s1;           // s1.C == 0: no channel concat
     const float* w = nullptr;  // packed [KS*KS][Cin][Cout]
@@ -79,6 +92,7 @@ struct ConvArgs {
     int Cin = 0, Cout = 0;
     int KS = 1, pad = 0, stride = 1, ups = 0;
     int w_batch_stride = 0;    // != 0: per-sample weights (w + b*stride), tiles then hold one sample
+    ConvFin fin;
 };
 
 // Tile configurations of the implicit-GEMM kernel (see conv_igemm.hip).
@@ -89,7 +103,11 @@ struct ConvGeom {  // filled by conv_plan(): what a consumer must know about `st
     int tile = 0, grid = 0, T = 0, pipe = 0;
     float n_t = 0.f;
     size_t lds = 0;
+    int T1 = 0;        // fused tail: slots / count of the GroupNorm(1) partials of the final value
+    float n_t1 = 0.f;
+    int groups = 0;    // fused tail: arrival counters needed (sample groups)
 };
+bool conv_fin_possible(const ConvArgs& a, int tile);   // the fused tail's residency / shape conditions hold for this launch
 int conv_init();
 unsigned long long* conv_stamp_buffer();
 void conv_set_stamp_buffer(unsigned long long* p);  // diagnostics: phase stamps of the pipelined kernel

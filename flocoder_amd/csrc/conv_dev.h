@@ -12,6 +12,7 @@ struct ConvDev {
     int TWl, THl, TB, PH, PW, P;
     int tiles_x, tiles_y, ntiles, nblocks;
     int cpg, cpgt, NPG, rps;     // output-stats geometry
+    int gsz, o_fin;              // fused tail: workgroups per sample group, LDS offset of the (mean, rstd) table
     int act0, act1, any_xf;
     int o_pixoff, o_pixtb, o_gstat, o_aff, o_patch, o_wl, o_wres, o_red, o_part;
     // pipelined kernel only
@@ -36,6 +37,8 @@ struct TileInfo { int BM, BN, CC, WK, MTNT, WMWN; };
 __device__ __forceinline__ int fastdiv(int x, unsigned magic) { return magic ? (int)__umulhi((unsigned)x, magic) : x; }
 
 __device__ __forceinline__ float silu_f(float z) { return z / (1.0f + __expf(-z)); }
+// workgroup barrier that orders LDS traffic only (no wait for outstanding global stores)
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // bijective XCD remap (cdna_hip_programming.md 5 "XCD swizzle must be bijective"): blocks that share an
 // XCD (bid % 8) get a contiguous run of tile ids, so n-tiles of one m-tile and neighbouring m-tiles hit
@@ -102,13 +105,71 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
 
     conv_stamp(p, 6);
     const bool owner = active && (wk == 0);
+    const bool fin = a.fin.gamma != nullptr;
     float* partS = smem + p.o_part;               // [BM/16][BN]
     float* partQ = partS + (BM / 16) * BN;        // [BM/16][BN]
     if (a.stats_out) __syncthreads();             // patch/wl (aliased by part*) are dead for every wave
 
+    // per-(16-row half-block, column) sums of the accumulators -> LDS
+    auto block_sums = [&]() {
+        if (owner) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int ncol = (wn * NT + nt) * 32 + l31;
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        float s = 0.f, q = 0.f;
+#pragma unroll
+                        for (int r = 8 * hh; r < 8 * hh + 8; ++r) { const float v = acc[mt][nt][r]; s += v; q += v * v; }
+                        s += __shfl_xor(s, 32);
+                        q += __shfl_xor(q, 32);
+                        if (half == 0) {
+                            const int hb = (wm * MT + mt) * 2 + hh;
+                            partS[hb * BN + ncol] = s;
+                            partQ[hb * BN + ncol] = q;
+                        }
+                    }
+                }
+        }
+    };
+    // thread i <-> (sample tb, column col) sums its column over the sample's 16-row half-blocks, then the cpgt columns of a
+    // group -- consecutive lanes of one wave, cpgt a power of two <= 64 -- meet by xor-shuffles; the group's first lane writes
+    // (mean_t, M2_t) of this tile's share of group g of sample b.
+    auto emit = [&](float* dst, int G, int cpg, int cpgt, int NPG, bool coherent) {
+        const int hb_per = p.rps >> 4;
+        const int ncols = min(BN, Cout - n0);
+        for (int i0 = 0; i0 < p.TB * BN; i0 += nthr) {
+            const int i = i0 + tid;
+            const bool live = i < p.TB * BN;
+            const int tb = live ? i / BN : 0, col = live ? i - tb * BN : 0;
+            float s = 0.f, q = 0.f;
+            if (live)
+                for (int h = 0; h < hb_per; ++h) { s += partS[(tb * hb_per + h) * BN + col]; q += partQ[(tb * hb_per + h) * BN + col]; }
+            for (int o = cpgt >> 1; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+            const int b = b0 + tb;
+            if (live && (col & (cpgt - 1)) == 0 && col < ncols && b < a.B) {
+                const int gl = col / cpgt;
+                const float n = (float)(p.rps * cpgt), mean = s / n;
+                const int g = n0 / cpg + (cpg >= BN ? 0 : gl);
+                const int nsub = (cpg >= BN) ? (n0 % cpg) / BN : 0;
+                const int msub = (p.TB > 1) ? 0 : ty * p.tiles_x + tx;
+                const int T = (p.TB > 1 ? 1 : p.tiles_x * p.tiles_y) * NPG;
+                float* d = dst + ((size_t)(b * G + g) * T + msub * NPG + nsub) * 2;
+                if (coherent) {   // read by other workgroups of this launch: device-scope stores that bypass the per-XCD L2
+                    __hip_atomic_store(d, mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(d + 1, q - s * mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    d[0] = mean;
+                    d[1] = q - s * mean;
+                }
+            }
+        }
+    };
+
     // Statistics first, stores last: a workgroup barrier waits for every outstanding global store (s_waitcnt vmcnt(0)), so a
-    // barrier AFTER the output stores would park the whole workgroup for the store round trip (measured: 6 K of a 66 K-cycle
-    // kernel, profiles/r01_c_stamps.txt).  With the stores as the last thing a wave does, they drain while the next workgroup starts.
+    // barrier AFTER the output stores would park the whole workgroup for the store round trip.
     if (owner) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -131,51 +192,87 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                         acc[mt][nt][r] = v;
                     }
                 }
-                if (a.stats_out) {
-#pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        float s = 0.f, q = 0.f;
-#pragma unroll
-                        for (int r = 8 * hh; r < 8 * hh + 8; ++r) { const float v = acc[mt][nt][r]; s += v; q += v * v; }
-                        s += __shfl_xor(s, 32);
-                        q += __shfl_xor(q, 32);
-                        if (half == 0) {
-                            const int hb = (wm * MT + mt) * 2 + hh;
-                            partS[hb * BN + ncol] = s;
-                            partQ[hb * BN + ncol] = q;
-                        }
-                    }
-                }
             }
     }
+    if (a.stats_out) block_sums();
 
     conv_stamp(p, 7);
     if (a.stats_out) {
         __syncthreads();
-        // thread i <-> (sample tb, column col) sums its column over the sample's 16-row half-blocks, then the cpgt columns of a
-        // group -- consecutive lanes of one wave, cpgt a power of two <= 64 -- meet by xor-shuffles; the group's first lane writes.
-        const int hb_per = p.rps >> 4;
-        const int ncols = min(BN, Cout - n0);
-        for (int i0 = 0; i0 < p.TB * BN; i0 += nthr) {
-            const int i = i0 + tid;
-            const bool live = i < p.TB * BN;
-            const int tb = live ? i / BN : 0, col = live ? i - tb * BN : 0;
-            float s = 0.f, q = 0.f;
-            if (live)
-                for (int h = 0; h < hb_per; ++h) { s += partS[(tb * hb_per + h) * BN + col]; q += partQ[(tb * hb_per + h) * BN + col]; }
-            for (int o = p.cpgt >> 1; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-            const int b = b0 + tb;
-            if (live && (col & (p.cpgt - 1)) == 0 && col < ncols && b < a.B) {
-                const int gl = col / p.cpgt;
-                const float n = (float)(p.rps * p.cpgt), mean = s / n;
-                const int g = n0 / p.cpg + (p.cpg >= BN ? 0 : gl);
-                const int nsub = (p.cpg >= BN) ? (n0 % p.cpg) / BN : 0;
-                const int msub = (p.TB > 1) ? 0 : ty * p.tiles_x + tx;
-                const int T = (p.TB > 1 ? 1 : p.tiles_x * p.tiles_y) * p.NPG;
-                float* d = a.stats_out + ((size_t)(b * a.Gout + g) * T + msub * p.NPG + nsub) * 2;
-                d[0] = mean;
-                d[1] = q - s * mean;
+        emit(a.stats_out, a.Gout, p.cpg, p.cpgt, p.NPG, fin);
+    }
+
+    if (fin) {
+        // ---- meet the other workgroups of this sample group: their partials complete the GroupNorm statistics ----
+        // The exchanged bytes (partials, counter) travel as device-scope relaxed atomics -- sc1 accesses that bypass the
+        // non-coherent per-XCD L2 -- ordered by vmcnt(0) + the workgroup barrier; no cache write-back / invalidate, which
+        // a release/acquire fence pair would cost every workgroup (measured: 120 us per launch instead of 25).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            unsigned* c = a.fin.sync + b0 / p.TB;
+            const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = (old / (unsigned)p.gsz + 1u) * (unsigned)p.gsz;
+            int spins = 0;
+            while ((int)(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 21)) { if (a.fin.err) *a.fin.err = 1; break; }   // bounded: a residency mistake must not hang the device
             }
+        }
+        __syncthreads();
+        // (mean, rstd) of the groups this tile's columns belong to, per sample of the tile
+        float* tab = smem + p.o_fin;
+        const int ngt = p.cpg >= BN ? 1 : BN / p.cpg;
+        const int Tst = (p.TB > 1 ? 1 : p.tiles_x * p.tiles_y) * p.NPG;
+        for (int i = tid; i < p.TB * ngt; i += nthr) {
+            const int tb = i / ngt, gl = i - tb * ngt, b = b0 + tb, g = n0 / p.cpg + gl;
+            float mean = 0.f, rstd = 0.f;
+            if (b < a.B && g < a.Gout) {
+                float* sp = a.stats_out + (size_t)(b * a.Gout + g) * Tst * 2;
+                const float nt_ = (float)(p.rps * p.cpgt);
+                float sm = 0.f;
+                for (int t = 0; t < Tst; ++t) sm += __hip_atomic_load(sp + 2 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mean = sm / (float)Tst;
+                float m2 = 0.f, dv = 0.f;
+                for (int t = 0; t < Tst; ++t) {
+                    const float d = __hip_atomic_load(sp + 2 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - mean;
+                    m2 += __hip_atomic_load(sp + 2 * t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    dv += d * d;
+                }
+                rstd = 1.0f / sqrtf((m2 + nt_ * dv) / (nt_ * (float)Tst) + a.fin.eps);
+            }
+            tab[2 * i] = mean;
+            tab[2 * i + 1] = rstd;
+        }
+        lds_only_barrier();
+        if (owner) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int ncol = (wn * NT + nt) * 32 + l31, n = n0 + ncol;
+                    const bool nok = n < Cout;
+                    const int gl = p.cpg >= BN ? 0 : ncol / p.cpg;
+                    const float gam = nok ? a.fin.gamma[n] : 0.f, bet = nok ? a.fin.beta[n] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        const int tw = m & (TW - 1), th = (m >> p.TWl) & (TH - 1), tb = m >> (p.TWl + p.THl);
+                        const int b = b0 + tb;
+                        const float mean = tab[2 * (tb * ngt + gl)], rstd = tab[2 * (tb * ngt + gl) + 1];
+                        const float A = rstd * gam;
+                        float v = silu_f(A * acc[mt][nt][r] + (bet - mean * A));
+                        if (a.fin.res && nok && b < a.B) v += a.fin.res[((size_t)(b * a.H + y0 + th) * a.W + x0 + tw) * Cout + n];
+                        acc[mt][nt][r] = (nok && b < a.B) ? v : 0.f;
+                    }
+                }
+        }
+        if (a.fin.gn1_out) {   // GroupNorm(1) partials of the final value for the PreNorm that follows (unet.py:156-160)
+            lds_only_barrier();                    // every reader of part* / tab is done
+            block_sums();
+            lds_only_barrier();
+            const int cpg1 = Cout, cpgt1 = Cout < BN ? Cout : BN, NPG1 = Cout >= BN ? Cout / BN : 1;
+            emit(a.fin.gn1_out, 1, cpg1, cpgt1, NPG1, false);
         }
     }
 
@@ -195,7 +292,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                     if (nok && b < a.B) {
                         const size_t off = ((size_t)(b * a.H + y0 + th) * a.W + x0 + tw) * Cout + n;
                         float v = acc[mt][nt][r];
-                        if (!a.stats_post) {
+                        if (!a.stats_post && !fin) {
                             if (a.out_act) v = silu_f(v);
                             if (a.add) v += a.add[off];
                         }

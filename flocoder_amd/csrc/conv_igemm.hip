@@ -254,6 +254,9 @@ static bool pipe_disabled() {
     return off;
 }
 
+static int g_cu_count = 0;
+static int conv_cu_count() { return g_cu_count > 0 ? g_cu_count : 256; }
+
 static int conv_geometry(const ConvArgs& a, int tile, bool pipe, ConvDev* d, ConvGeom* g) {
     if (tile < 0 || tile >= TILE_COUNT) return fail(FC_E_ARG, "conv: bad tile id");
     const TileInfo& t = pipe ? kTilesPipe[tile] : kTiles[tile];
@@ -319,13 +322,29 @@ static int conv_geometry(const ConvArgs& a, int tile, bool pipe, ConvDev* d, Con
         if (t.WK > 1) epi = t.WMWN * (t.WK - 1) * t.MTNT * (a.res_out ? 2 : 1) * 1024;
         p.o_part = o + epi;
         if (a.stats_out) epi += 2 * (t.BM / 16) * t.BN + 2 * TB * t.BN;
+        p.o_fin = o + epi;
+        if (a.fin.gamma) epi += 2 * TB * t.BN;
         o += main_sz > epi ? main_sz : epi;
         p.zeros16 = conv_zeros16();
         p.stamps = conv_stamp_buffer();
         g->tile = tile; g->grid = p.nblocks; g->lds = (size_t)o * sizeof(float);
         if (g->lds > 160 * 1024) return fail(FC_E_SHAPE, "conv: tile does not fit in LDS");
+        p.gsz = 1;
+        if (a.fin.gamma) {   // fused Block tail: shape conditions and, above all, residency of the whole grid
+            if (!a.stats_out || a.stats_post || a.out_act || a.add || a.res_out) return fail(FC_E_ARG, "conv: fused tail excludes act / add / res outputs");
+            if (a.Cout % t.BN && a.Cout > t.BN) return fail(FC_E_SHAPE, "conv: fused tail needs Cout to fill its column tiles");
+            p.gsz = p.tiles_x * p.tiles_y * p.ntiles;
+            g->groups = cdiv(a.B, TB);
+            const int cpgt1 = a.Cout < t.BN ? a.Cout : t.BN, NPG1 = a.Cout >= t.BN ? a.Cout / t.BN : 1;
+            g->T1 = (TB > 1 ? 1 : p.tiles_x * p.tiles_y) * NPG1;
+            g->n_t1 = (float)(p.rps * cpgt1);
+            // two 512-thread workgroups share a CU only when both fit in LDS (and the kernels stay under 128 VGPRs: NT = 1 tiles)
+            const int per_cu = (g->lds <= 80 * 1024 && t.MTNT == 1 && a.KS <= 3) ? 2 : 1;   // those instantiations stay <= 110 VGPRs
+            if (p.nblocks > conv_cu_count() * per_cu) return fail(FC_E_SHAPE, "conv: fused tail needs the whole grid resident");
+        }
         return FC_OK;
     }
+    if (a.fin.gamma) return fail(FC_E_SHAPE, "conv: fused tail is implemented in the pipelined kernel only");
     // LDS carve (in floats)
     int o = 0;
     p.o_pixoff = o; o += align4(p.P);
@@ -349,13 +368,23 @@ static int conv_geometry(const ConvArgs& a, int tile, bool pipe, ConvDev* d, Con
     return FC_OK;
 }
 
+bool conv_fin_possible(const ConvArgs& a, int tile) {
+    ConvDev d;
+    ConvGeom g;
+    ConvArgs b = a;
+    if (!b.fin.gamma) b.fin.gamma = reinterpret_cast<const float*>(16);   // geometry only
+    if (!b.stats_out) b.stats_out = reinterpret_cast<float*>(16);
+    if (pipe_disabled()) return false;
+    return conv_geometry(b, tile, true, &d, &g) == FC_OK;   // a refusal leaves its reason in fc_last_error, harmlessly
+}
+
 static int auto_tile(const ConvArgs& a) {
     const long M = (long)a.B * a.H * a.W;
     const int hw = a.H * a.W;
     auto blocks = [&](int t) { return (M / kTiles[t].BM) * cdiv(a.Cout, kTiles[t].BN); };
     auto ok = [&](int t) { return !(a.w_batch_stride && hw < kTiles[t].BM) && M >= kTiles[t].BM; };
     if (a.Cout >= 64 && ok(TILE_M128N64) && blocks(TILE_M128N64) >= 512) return TILE_M128N64;
-    if (ok(TILE_M128N32) && blocks(TILE_M128N32) >= 384) return TILE_M128N32;
+    if (ok(TILE_M128N32) && blocks(TILE_M128N32) >= 256) return TILE_M128N32;   // one full wave of workgroups: measured 20 vs 29 us on the 64-channel 16x16 layers (profiles/r01_c_conv_microbench.txt)
     if (a.Cout >= 64 && ok(TILE_M64N64K2) && blocks(TILE_M64N64K2) >= 384) return TILE_M64N64K2;
     if (ok(TILE_M64N32K2) && blocks(TILE_M64N32K2) >= 256) return TILE_M64N32K2;
     return TILE_M32N32K4;
@@ -401,6 +430,13 @@ int conv_init() {
     FC_TRY((allow_big_lds<1, 1, 4, 1, 1, 32>()));
     FC_TRY((allow_big_lds<2, 1, 2, 1, 2, 16>()));
     FC_TRY(conv_pipe_init());
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        FC_HIP(hipGetDevice(&dev));
+        FC_HIP(hipGetDeviceProperties(&prop, dev));
+        g_cu_count = prop.multiProcessorCount;
+    }
     done = true;
     return FC_OK;
 }

@@ -55,6 +55,7 @@ struct Plan {                 // one launch plan + activation arena for up to ma
     std::vector<ResRec> res; std::vector<LinRec> lin; std::vector<MidRec> mid; std::vector<ConvRec> convs;
     std::vector<TapeItem> tape;
     Act x0, head;                                   // init_conv output, final_res_block output
+    std::vector<int*> fin_err;                      // device flags of the fused Block tails (a timed-out wait sets one)
     void release() {
         for (void* p : allocs) (void)hipFree(p);
         *this = Plan();
@@ -219,6 +220,33 @@ struct PlanBuilder {
             float* sp = st->p; const float* xp = out.p; const int HW = out.H * out.W, C = out.C, G = want_G;
             push([=](const FwdCtx& c, hipStream_t s) { return gn_stats_launch(xp, sp, c.B, HW, C, G, s); }, "gn_stats");
         }
+    }
+
+    // A convolution whose epilogue finishes the Block: out = SiLU(GroupNorm(conv)) + res, the GroupNorm statistics exchanged between
+    // the workgroups of a sample through a counter (ConvFin).  Returns false, emitting nothing, when the launch cannot keep its whole
+    // grid resident or the shape is outside the fused tail's conditions -- the caller then emits conv + finalize.
+    bool conv_fin(ConvArgs a, const Act& out, int G, const float* gamma, const float* beta, const float* res, bool want_gn1, Stat* gn1) {
+        if (err) return false;
+        a.B = B; a.H = out.H; a.W = out.W; a.Cout = out.C; a.out = out.p;
+        a.Cin = a.s0.C + a.s1.C;
+        if ((out.H * out.W) % 16) return false;
+        a.Gout = G; a.stats_out = reinterpret_cast<float*>(16);
+        a.fin.gamma = gamma; a.fin.beta = beta; a.fin.res = res;
+        ConvGeom g;
+        if (conv_plan(a, TILE_AUTO, &g) != FC_OK || !g.pipe) return false;
+        Stat st = stat(G, g.T, g.n_t);
+        a.stats_out = st.p;
+        if (want_gn1) { *gn1 = stat(1, g.T1, g.n_t1); a.fin.gn1_out = gn1->p; }
+        unsigned* sync = reinterpret_cast<unsigned*>(dmalloc((size_t)g.groups + 1));
+        if (err) return false;
+        if (hipMemset(sync, 0, ((size_t)g.groups + 1) * sizeof(unsigned)) != hipSuccess) { err = fail(FC_E_HIP, "hipMemset failed"); return false; }
+        a.fin.sync = sync;
+        a.fin.err = reinterpret_cast<int*>(sync + g.groups);
+        pl->fin_err.push_back(a.fin.err);
+        const int tile = g.tile;
+        const double fl = 2.0 * out.H * out.W * a.KS * a.KS * (double)a.Cin * a.Cout;
+        push([a, tile](const FwdCtx& c, hipStream_t s) { ConvArgs b = a; b.B = c.B; return conv_launch(b, tile, s); }, std::string(kTileNames[tile]) + "+fin", fl);
+        return true;
     }
 
     // Single-head softmax attention over the h*w tokens of x with d = C (diffusers' VAE mid-block attention, VQGAN's AttnBlock):

@@ -119,6 +119,12 @@ static int declare_all(fc_unet* u) {
     return FC_OK;
 }
 
+static int g_fused_tail = -1;
+static bool fused_tail_enabled() {
+    if (g_fused_tail < 0) { const char* e = std::getenv("FLOCODER_AMD_FUSED_TAIL"); g_fused_tail = (e && std::string(e) == "1") ? 1 : 0; }
+    return g_fused_tail == 1;
+}
+
 // ------------------------------------------------------------------------------------------- plan builder
 struct Builder : PlanBuilder {
     fc_unet* u = nullptr;
@@ -145,16 +151,26 @@ struct Builder : PlanBuilder {
         b.s0.xf = xf_of(st1, 2, u->R(p + ".block1.norm.weight"), u->R(p + ".block1.norm.bias"), pl->ss + u->ss_off.at(p), u->S);
         b.Hs = x.H; b.Ws = x.W; b.KS = 3; b.pad = 1;
         b.w = u->P(p + ".block2.proj.weight"); b.bias = u->R(p + ".block2.proj.bias");
-        conv(b, h2, G, &st2);
-        FinalizeArgs f;
-        f.h = h2.p; f.xf = xf_of(st2, 2, u->R(p + ".block2.norm.weight"), u->R(p + ".block2.norm.bias"));
-        f.res = (cin != cout) ? rb.p : x.p; f.y = out.p; f.HW = x.H * x.W; f.C = cout;
-        if (want_gn1) {
-            const int bps = finalize_blocks_per_sample(f.HW, f.C);
-            *gn1 = stat(1, bps, (float)(f.HW * f.C / bps));
-            f.stats_out = gn1->p;
+        // inference plans close the Block inside conv2 (ConvFin) when the launch keeps its whole grid resident; training plans keep
+        // the raw h2 and its statistics for the backward
+        // Measured on one box, B=64 (profiles/README.md r01_g): 494 samples/s with the fused tails against 503 without -- the
+        // in-kernel meeting (four dependent memory round trips) costs what a launch boundary plus the finalize pass cost.  Off
+        // unless FLOCODER_AMD_FUSED_TAIL=1 / fc_debug_set_fused_tail(1).
+        const float* resp = (cin != cout) ? rb.p : x.p;
+        const bool fused = !u->keep_all && fused_tail_enabled() &&
+                           conv_fin(b, out, G, u->R(p + ".block2.norm.weight"), u->R(p + ".block2.norm.bias"), resp, want_gn1, gn1);
+        if (!fused) {
+            conv(b, h2, G, &st2);
+            FinalizeArgs f;
+            f.h = h2.p; f.xf = xf_of(st2, 2, u->R(p + ".block2.norm.weight"), u->R(p + ".block2.norm.bias"));
+            f.res = resp; f.y = out.p; f.HW = x.H * x.W; f.C = cout;
+            if (want_gn1) {
+                const int bps = finalize_blocks_per_sample(f.HW, f.C);
+                *gn1 = stat(1, bps, (float)(f.HW * f.C / bps));
+                f.stats_out = gn1->p;
+            }
+            if (!err) push([f](const FwdCtx& c, hipStream_t s) { FinalizeArgs g = f; g.B = c.B; return finalize_launch(g, s); }, "finalize");
         }
-        if (!err) push([f](const FwdCtx& c, hipStream_t s) { FinalizeArgs g = f; g.B = c.B; return finalize_launch(g, s); }, "finalize");
         pl->named[p] = out; pl->named[p + ".h1"] = h1; pl->named[p + ".h2"] = h2;
         ResRec rec;
         rec.p = p; rec.x = x; if (skip) rec.skip = *skip; rec.h1 = h1; rec.h2 = h2; rec.rb = rb; rec.out = out; rec.st1 = st1; rec.st2 = st2; rec.cout = cout;
@@ -692,6 +708,18 @@ int fc_unet_chains(const fc_unet* u, int* rows_per_chain) {
     return u->nchains;
 }
 
+int fc_unet_fused_tail_errors(const fc_unet* u, int* count) {
+    if (!u || !count) return fail(FC_E_ARG, "fc_unet_fused_tail_errors: null argument");
+    *count = 0;
+    for (const Plan& pl : u->plan)
+        for (int* f : pl.fin_err) {
+            int v = 0;
+            FC_HIP(hipMemcpy(&v, f, sizeof(int), hipMemcpyDeviceToHost));
+            *count += v != 0;
+        }
+    return FC_OK;
+}
+
 int fc_unet_plan_launches(const fc_unet* u) { return u ? (int)u->plan[0].ops.size() : 0; }
 double fc_unet_flops_per_sample(const fc_unet* u) { return u ? u->plan[0].flops : 0.0; }
 
@@ -790,6 +818,11 @@ int fc_unet_debug_tensor(const fc_unet* u, const char* name, const float** ptr, 
         if (it == u->bwd.named.end()) return fail(FC_E_ARG, std::string("fc_unet_debug_tensor: no tap named ") + name);
     }
     *ptr = it->second.p; *C = it->second.C; *H = it->second.H; *W = it->second.W;
+    return FC_OK;
+}
+
+int fc_debug_set_fused_tail(int on) {   // plans built from now on use (1) / do not use (0) the fused Block tails
+    fc::g_fused_tail = on ? 1 : 0;
     return FC_OK;
 }
 

@@ -193,6 +193,14 @@ class Unet(nn.Module):
         n = B.lib().fc_unet_chains(self._handle, C.byref(rows)) if self._handle else 0
         return n, rows.value
 
+    def fused_tail_errors(self) -> int:
+        """Timed-out waits of the fused Block tails since the plan was built (must be 0; synchronises)."""
+        if not self._handle:
+            return 0
+        n = C.c_int(0)
+        B.check(B.lib().fc_unet_fused_tail_errors(self._handle, C.byref(n)))
+        return n.value
+
     @property
     def launches_per_forward(self) -> int:
         return int(B.lib().fc_unet_plan_launches(self._handle)) if self._handle else 0

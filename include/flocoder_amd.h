@@ -107,6 +107,12 @@ int fc_unet_integrate(fc_unet* u, int method, float* x_dev, int batch, int heigh
  * each chain's plan holds (= the batch every kernel launch of that chain sees). */
 int fc_unet_chains(const fc_unet* u, int* rows_per_chain);
 int fc_unet_plan_launches(const fc_unet* u);
+/* Fused Block tails meet the workgroups of a sample at a device-side counter (bounded wait).  *count = launches whose wait ever
+ * timed out since the plan was built -- must be 0; anything else means the residency assumption broke and results are invalid.
+ * Synchronises. */
+int fc_unet_fused_tail_errors(const fc_unet* u, int* count);
+/* Experiment switch (default off): plans built after the call close each Block inside its second convolution. */
+int fc_debug_set_fused_tail(int on);
 double fc_unet_flops_per_sample(const fc_unet* u);
 /* Launch i of the plan: kernel family, the reference module it implements, its algorithmic FLOPs per sample. */
 int fc_unet_op_info(const fc_unet* u, int i, const char** kernel, const char** module, double* flops_per_sample);

@@ -149,3 +149,34 @@ def test_mask_cond_sampling_vs_oracle():
     ref, _ = fo.generate_latents_rk4(sd, src.clone(), 4, {"mask_cond": ones}, 3.0)
     lat, _ = S.generate_latents_rk4(model, (2, 4, 8, 8), 4, {"mask_cond": ones.to(DEV)}, 3.0, source=src.to(DEV))
     assert rel_l2(lat.cpu(), ref) < TRAJ_TOL
+
+
+def test_bench_batch_forward_with_fused_tails():
+    """The optional fused Block tails (FLOCODER_AMD_FUSED_TAIL=1: workgroups of a sample meet at a device counter and finish
+    SiLU(GN(.)) + res from their accumulators) at B=64, the launch sizes bench.py runs: no timed-out wait, same results."""
+    from flocoder_amd import _binding as B
+    from flocoder_amd.unet import Unet
+    B.check(B.lib().fc_debug_set_fused_tail(1))
+    try:
+        _fused_tail_body(Unet)
+    finally:
+        B.check(B.lib().fc_debug_set_fused_tail(0))
+
+
+def _fused_tail_body(Unet):
+    torch.manual_seed(0)
+    m = Unet(dim=32, dim_mults=(1, 2, 4, 8), channels=4, n_classes=102).eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(4)
+    x, t = torch.randn(64, 4, 32, 32, generator=g), torch.rand(64, generator=g) * 999
+    ids = torch.randint(0, 102, (64,), generator=g)
+    with torch.no_grad():
+        v = m(x.to(DEV), t.to(DEV), {"class_cond": ids.to(DEV)})
+        v2 = m(x.to(DEV), t.to(DEV), {"class_cond": ids.to(DEV)})
+    assert m.fused_tail_errors() == 0
+    assert torch.equal(v, v2)
+    assert any("+fin" in r["kernel"] for r in m.profile_ops(64, repeats=1))          # the fused path is the one that ran
+    ref = fo.unet_forward(sd, x[:8], t[:8], {"class_cond": ids[:8]})
+    assert rel_l2(v[:8].cpu(), ref) < FWD_TOL
+    assert m.fused_tail_errors() == 0
