@@ -128,6 +128,8 @@ struct FinalizeArgs {       // y = act(gn(h)) + res, optional GroupNorm(1) parti
 int finalize_blocks_per_sample(int HW, int C);
 int finalize_launch(const FinalizeArgs& a, hipStream_t s);
 int gn_stats_launch(const float* x_nhwc, float* stats /*[B][G][1][2]*/, int B, int HW, int C, int G, hipStream_t s);
+// [B][G][T][2] partials of n_t elements each -> [B][G][1][2] covering n_t*T elements
+int gn_fold_launch(const float* in, float* out, int B, int G, int T, float n_t, hipStream_t s);
 
 int init_conv_launch(const float* x_nchw, int x_batch_mod, const float* w /*[Cin][Cout]*/, const float* bias, float* out_nhwc,
                      int B, int Cin, int HW, int Cout, hipStream_t s);

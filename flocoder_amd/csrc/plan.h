@@ -215,6 +215,13 @@ struct PlanBuilder {
         double fl = 2.0 * out.H * out.W * a.KS * a.KS * (double)a.Cin * a.Cout;
         if (a.res_out) fl += 2.0 * out.H * out.W * (double)a.Cin * a.Cout;
         push([a, tile](const FwdCtx& c, hipStream_t s) { ConvArgs b = a; b.B = c.B; return conv_launch(b, tile, s); }, kTileNames[tile], fl);
+        if (fused && st->T > 16) {   // many tiles per sample (large images): fold the partials once instead of in every consumer workgroup
+            const Stat raw = *st;
+            *st = stat(want_G, 1, raw.n_t * (float)raw.T);
+            const float* ip = raw.p; float* op = st->p;
+            const int G = want_G, T = raw.T; const float nt = raw.n_t;
+            push([=](const FwdCtx& c, hipStream_t s) { return gn_fold_launch(ip, op, c.B, G, T, nt, s); }, "gn_fold");
+        }
         if (want_G > 0 && !fused) {
             *st = stat(want_G, 1, (float)(out.H * out.W * (out.C / want_G)));
             float* sp = st->p; const float* xp = out.p; const int HW = out.H * out.W, C = out.C, G = want_G;

@@ -360,4 +360,44 @@ int fc_vae_decode(fc_vae* v, const float* z_dev, float* x_out_dev, int batch, in
 double fc_vae_flops_per_sample(const fc_vae* v, int decode) { return v ? (decode ? v->dec.flops : v->enc.flops) : 0.0; }
 int fc_vae_plan_launches(const fc_vae* v, int decode) { return v ? (int)(decode ? v->dec.ops.size() : v->enc.ops.size()) : 0; }
 
+int fc_vae_op_info(const fc_vae* v, int decode, int i, const char** kernel, const char** module, double* flops_per_sample) {
+    if (!v) return fail(FC_E_ARG, "fc_vae_op_info: null handle");
+    const Plan& pl = decode ? v->dec : v->enc;
+    if (i < 0 || i >= (int)pl.ops.size()) return fail(FC_E_ARG, "fc_vae_op_info: index out of range");
+    if (kernel) *kernel = pl.op_kernel[i].c_str();
+    if (module) *module = pl.op_what[i].c_str();
+    if (flops_per_sample) *flops_per_sample = pl.op_flops[i];
+    return FC_OK;
+}
+
+// Measurement hook: every launch of the encode / decode plan timed alone (`repeats` back-to-back launches between two events).
+// in_dev / out_dev: valid input and output tensors for `batch` samples at the plan's shape.  Synchronises.
+int fc_vae_profile_ops(fc_vae* v, int decode, const float* in_dev, float* out_dev, int batch, int repeats, float* ms_out, int n_out, void* stream) {
+    if (!v || !in_dev || !out_dev || !ms_out || repeats < 1) return fail(FC_E_ARG, "fc_vae_profile_ops: bad argument");
+    const Plan& pl = decode ? v->dec : v->enc;
+    const int n = (int)pl.ops.size();
+    if (pl.maxB < batch || n == 0) return fail(FC_E_STATE, "vae: reserve the plan first");
+    if (n_out < n) return fail(FC_E_ARG, "fc_vae_profile_ops: output array too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    FwdCtx c;
+    c.x = in_dev; c.x_mod = batch; c.out = out_dev; c.B = batch;
+    FC_TRY(run_plan(pl, c, s));
+    std::vector<hipEvent_t> ev(2 * n);
+    for (auto& e : ev) FC_HIP(hipEventCreate(&e));
+    int rc = FC_OK;
+    for (int i = 0; i < n && rc == FC_OK; ++i) {
+        (void)hipEventRecord(ev[2 * i], s);
+        for (int r = 0; r < repeats && rc == FC_OK; ++r) rc = pl.ops[i](c, s);
+        (void)hipEventRecord(ev[2 * i + 1], s);
+    }
+    (void)hipStreamSynchronize(s);
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
+        ms_out[i] = ms / repeats;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
 }  // extern "C"

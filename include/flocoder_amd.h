@@ -194,6 +194,10 @@ int fc_vae_encode(fc_vae* v, const float* x_dev, float* mean_out_dev, int batch,
 int fc_vae_decode(fc_vae* v, const float* z_dev, float* x_out_dev, int batch, int lat_height, int lat_width, void* stream);
 double fc_vae_flops_per_sample(const fc_vae* v, int decode);
 int fc_vae_plan_launches(const fc_vae* v, int decode);
+/* Measurement only: launch i of the encode / decode plan, and every launch timed alone (see fc_unet_profile_ops). */
+int fc_vae_op_info(const fc_vae* v, int decode, int i, const char** kernel, const char** module, double* flops_per_sample);
+int fc_vae_profile_ops(fc_vae* v, int decode, const float* in_dev, float* out_dev, int batch, int repeats, float* ms_out, int n_out,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * VQVAE codec, encode / decode  (replaces flocoder/codecs.py:386-525 VQVAE.encode / VQVAE.decode with
