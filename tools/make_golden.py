@@ -88,6 +88,30 @@ UNET_CASES = [  # tag, dim, n_classes, mask_cond, B, seed
 ]
 
 
+def make_latent_tree(root):
+    """A tiny pre-encoded dataset in the reference's on-disk format (preencode_data.py:130-156), deterministic content:
+    cls/  numeric class directories whose path order differs from their numeric order, plus a non-numeric directory
+    sub/  non-numeric sub-directories (no classes)      flat/  files at the top      inp/  inpainting dicts with bool masks"""
+    def save(path, obj):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        torch.save(obj, path)
+    k = 0
+    for cname, count in (("0", 2), ("1", 1), ("2", 3), ("10", 2), ("11", 1), ("notes", 1)):
+        for i in range(count):
+            save(os.path.join(root, "cls", cname, f"sample_{k}_{i}_abcd.pt"), synth_input(f"g11.cls.{cname}.{i}", (4, 8, 8), 11))
+            k += 1
+    for sub, count in (("00", 2), ("01", 3)):
+        for i in range(count):
+            save(os.path.join(root, "sub", sub, f"sample_{sub}_{i}.pt"), synth_input(f"g11.sub.{sub}.{i}", (4, 8, 8), 11))
+    for i in range(3):
+        save(os.path.join(root, "flat", f"sample_{i}.pt"), synth_input(f"g11.flat.{i}", (4, 8, 8), 11))
+    for cname, count in (("0", 2), ("1", 2)):
+        for i in range(count):
+            save(os.path.join(root, "inp", cname, f"sample_{cname}_{i}.pt"),
+                 {"target_latents": synth_input(f"g11.inp.t.{cname}.{i}", (4, 8, 8), 11), "source_latents": synth_input(f"g11.inp.s.{cname}.{i}", (4, 8, 8), 11),
+                  "mask_pixels": synth_input(f"g11.inp.m.{cname}.{i}", (1, 20, 20), 11) > 0.2})
+
+
 @torch.no_grad()
 def main():
     torch.set_num_threads(8)
@@ -295,6 +319,29 @@ def main():
                   arrays[f"s{step}_param_{k}"] = p.data.clone()
     arrays["names"] = names
     npz("g10_train_step", **arrays)
+
+    # ---- G11: PreEncodedDataset (data.py:311-384) on a small tree in the on-disk format of preencode_data.py:130-156 ----
+    import tempfile
+    tvm = sys.modules["torchvision"]
+    tvm.datasets = _stand_in("torchvision.datasets")
+    spec = importlib.util.spec_from_file_location("flocoder.data", os.path.join(REF, "flocoder", "data.py"))
+    refdata = importlib.util.module_from_spec(spec)
+    refdata.__package__ = "flocoder"
+    spec.loader.exec_module(refdata)
+    g11 = {}
+    with tempfile.TemporaryDirectory() as td:
+        make_latent_tree(td)
+        with contextlib.redirect_stdout(io.StringIO()):
+            for tag, sub, kw in (("classes", "cls", {}), ("classes_off", "cls", {"n_classes": 0}), ("subdirs", "sub", {}), ("flat", "flat", {}),
+                                 ("inpaint", "inp", {})):
+                ds = refdata.PreEncodedDataset(os.path.join(td, sub), **kw)
+                g11[tag] = {"n_classes": ds.n_classes, "has_classes": bool(ds.has_classes), "len": len(ds),
+                            "labels": {os.path.relpath(str(f), os.path.join(td, sub)): int(l) for f, l in zip(ds.files, ds._labels)},
+                            "class_to_idx": {str(k): int(v) for k, v in getattr(ds, "class_to_idx", {}).items()}}
+            item, lab = refdata.PreEncodedDataset(os.path.join(td, "inp"))[0]
+        g11["inpaint"]["item_keys"] = sorted(item.keys())
+        g11["inpaint"]["mask_dtype"] = str(item["mask_pixels"].dtype)
+    npz("g11_latent_dataset", layout=g11)
 
 
 if __name__ == "__main__":
