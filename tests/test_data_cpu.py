@@ -94,3 +94,33 @@ def test_packed_loader_partitions_and_collates(tree, tmp_path):
     assert torch.equal(y, yr) and all(torch.equal(x[k], xr[k]) and x[k].dtype == xr[k].dtype for k in xr)
     assert isinstance(latent_loader(os.path.join(tree, "cls"), 4, num_workers=0), PackedLatentLoader)   # picks up <dir>.fcl
     assert isinstance(latent_loader(os.path.join(tree, "flat"), 2, num_workers=0), DataLoader)
+
+
+def test_preencode_pipeline_with_resize_codec(tmp_path):
+    """process_dataset (preencode_data.py:84-181) end to end with the CPU-capable SimpleResizeAE: reference directory layout when
+    unpacked, one memory-mappable shard per rank when packed, same latents either way."""
+    from flocoder_amd.codecs import SimpleResizeAE
+    from flocoder_amd.data import PackedLatentDataset, PreEncodedDataset
+    from flocoder_amd.preencode import merge_shards, process_dataset
+    codec = SimpleResizeAE(latent_shape=(4, 8, 8)).eval()
+    g = torch.Generator().manual_seed(0)
+    batches = [(torch.rand(5, 3, 32, 32, generator=g), torch.randint(0, 3, (5,), generator=g)) for _ in range(4)]
+    want = torch.cat([codec.encode(x) for x, _ in batches])
+    r = process_dataset(codec, batches, tmp_path / "files", "cpu", n_classes=3)
+    assert r["samples"] == 20 and r["bytes"] > 0
+    ds = PreEncodedDataset(str(tmp_path / "files"))
+    assert len(ds) == 20 and ds.n_classes == 3
+    assert all(p.parent.name in "012" and p.name.startswith("sample_") and p.suffix == ".pt" for p in ds.files)
+    key = lambda t: round(float(t.double().sum()), 5)
+    assert sorted(key(ds[i][0]) for i in range(20)) == sorted(key(t) for t in want)
+    labels = torch.cat([y for _, y in batches])
+    assert sorted((key(ds[i][0]), int(ds[i][1])) for i in range(20)) == sorted((key(t), int(l)) for t, l in zip(want, labels))
+    # packed, two ranks -> two shards -> merged file holding every sample once
+    shards = [process_dataset(codec, batches, tmp_path / "packed", "cpu", n_classes=3, packed=True, rank=r_, world=2) for r_ in range(2)]
+    assert [s["samples"] for s in shards] == [10, 10]
+    info = merge_shards([s["path"] for s in shards], str(tmp_path / "packed" / "latents.fcl"))
+    pk = PackedLatentDataset(str(tmp_path / "packed" / "latents.fcl"))
+    assert info["count"] == len(pk) == 20 and pk.n_classes == 3
+    assert sorted((key(pk[i][0]), int(pk[i][1])) for i in range(20)) == sorted((key(t), int(l)) for t, l in zip(want, labels))
+    r = process_dataset(codec, batches, tmp_path / "budget", "cpu", n_classes=0, max_batches=2)
+    assert r["samples"] == 10 and sorted(p.name for p in (tmp_path / "budget").iterdir()) == ["00", "01"]
