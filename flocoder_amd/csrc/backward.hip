@@ -164,6 +164,43 @@ int norm_param_grads_launch(const float* s12, const float* gamma, const float* b
     return FC_OK;
 }
 
+// The same for every norm layer of the network in one launch (a step has ~55 of them, each a few microseconds of work).
+// grid (ceil(maxC/64), njobs); 256 threads = 4 batch rows x 64 channels
+__global__ void __launch_bounds__(256) norm_param_grads_table_kernel(const NormJob* jobs, float* grads, float* dss_base, int ss_stride, int B) {
+    __shared__ float rg[4][64], rb[4][64];
+    const NormJob j = jobs[blockIdx.y];
+    const int lane = threadIdx.x & 63, row = threadIdx.x >> 6, c = blockIdx.x * 64 + lane;
+    if (blockIdx.x * 64 >= j.C) return;
+    float dg = 0.f, db = 0.f;
+    if (c < j.C) {
+        const float gm = j.gamma[c], bt = j.beta[c];
+        for (int b = row; b < B; b += 4) {
+            const float s1 = j.s12[((size_t)b * j.C + c) * 2], s2 = j.s12[((size_t)b * j.C + c) * 2 + 1];
+            float sc = 1.0f;
+            if (j.ss) {
+                sc = j.ss[(size_t)b * ss_stride + c] + 1.0f;
+                float* d = dss_base + (size_t)b * ss_stride + j.ss_col;
+                d[c] = gm * s2 + bt * s1;
+                d[j.C + c] = s1;
+            }
+            dg += sc * s2;
+            db += sc * s1;
+        }
+    }
+    rg[row][lane] = dg; rb[row][lane] = db;
+    __syncthreads();
+    if (row == 0 && c < j.C) {
+        grads[j.dgamma + c] = (rg[0][lane] + rg[1][lane]) + (rg[2][lane] + rg[3][lane]);
+        grads[j.dbeta + c] = (rb[0][lane] + rb[1][lane]) + (rb[2][lane] + rb[3][lane]);
+    }
+}
+int norm_param_grads_table_launch(const NormJob* jobs_dev, int njobs, int maxC, float* grads, float* dss, int ss_stride, int B, hipStream_t s) {
+    if (!njobs) return FC_OK;
+    hipLaunchKernelGGL(norm_param_grads_table_kernel, dim3(cdiv(maxC, 64), njobs), dim3(256), 0, s, jobs_dev, grads, dss, ss_stride, B);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
 // ===================================================================================================
 // LinearAttention backward (unet.py:137-149).  With p = softmax_d(q_raw), q = p/sqrt(32), k = softmax_n(k_raw):
 //   ctx[d][e] = sum_n k[d][n] v[e][n],  out[e][n] = sum_d ctx[d][e] q[d][n]

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 
 #include "../../include/flocoder_amd.h"
 
@@ -200,11 +201,21 @@ int ode_rk4_final_launch(const float* sc, float* y, const float* k1, const float
                          int cfg_on, float cfg, hipStream_t s);
 
 // ---- weight packing (pack.hip) ----------------------------------------------------------------
+struct PackJob { const float* src; float* dst; int kind, a, b, c, d, e; size_t total; };
+constexpr int kPackPerBlock = 4096;          // elements a workgroup of the table kernel moves
+struct PackTable {                            // device-resident job list + (job, block) map of one batched launch
+    PackJob* jobs = nullptr;
+    int2* blocks = nullptr;
+    int nblocks = 0;
+    void release();
+};
 int pack_conv_launch(const float* oihw, float* dst /*[KK][I][O]*/, int O, int I, int KH, int KW, hipStream_t s);
 // same with zero padding of either channel count: dst [KK][Ipad][Opad]
 int pack_conv_pad_launch(const float* oihw, float* dst, int O, int I, int KK, int Opad, int Ipad, hipStream_t s);
 // operand of the data-gradient pass (forward kernel on dY): [taps flipped][O][nci] for input channels ci0..ci0+nci
 int pack_conv_dgrad_launch(const float* oihw, float* dst, int O, int I, int KS, int ci0, int nci, hipStream_t s);
+int pack_table_build(std::vector<PackJob> jobs, PackTable* out);   // uploads; the table keeps raw device pointers of src / dst
+int pack_table_launch(const PackTable& t, hipStream_t s);
 // [B][rows][cols] -> [B][cols][rows]
 int transpose_batched_launch(const float* src, float* dst, int B, int rows, int cols, hipStream_t s);
 // in place: x[r][:] = softmax(scale * x[r][:]) for `rows` rows of `cols` floats
@@ -239,6 +250,8 @@ struct GnBwdArgs {          // backward of y = act((gamma xhat + beta)(sc+1) + s
 int gn_bwd_launch(const GnBwdArgs& a, hipStream_t s);
 int norm_param_grads_launch(const float* s12, const float* gamma, const float* beta, const float* ss, int ss_stride, float* dgamma,
                             float* dbeta, float* dss, int B, int C, hipStream_t s);
+struct NormJob { const float* s12; const float* gamma; const float* beta; const float* ss; int64_t dgamma, dbeta; int ss_col, C; };
+int norm_param_grads_table_launch(const NormJob* jobs_dev, int njobs, int maxC, float* grads, float* dss, int ss_stride, int B, hipStream_t s);
 int linattn_bwd_launch(const float* qkv, const float* dout, const float* ctx, float* dctx, float* kst, float* rr, float* dqkv, int B, int n,
                        int heads, hipStream_t s);
 int attn_small_bwd_launch(const float* qkv, const float* dout, float* dqkv, int B, int n, int heads, hipStream_t s);

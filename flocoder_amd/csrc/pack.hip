@@ -1,5 +1,7 @@
 // Weight re-layout from the reference's state_dict tensors to the kernels' operand layouts.  Runs once per
 // fc_unet_load_params (and once per optimiser step when training), HBM-bound and tiny.
+#include <vector>
+
 #include "common.h"
 
 namespace fc {
@@ -73,6 +75,74 @@ __global__ void __launch_bounds__(256) transpose_batched_kernel(const float* src
     __syncthreads();
     for (int j = threadIdx.y; j < 32; j += 8)
         if (c0 + j < Cc && r0 + threadIdx.x < R) dst[base + (size_t)(c0 + j) * R + r0 + threadIdx.x] = tile[threadIdx.x][j];
+}
+
+// ---- a whole table of re-layout jobs in ONE launch (a training step re-packs ~190 weight tensors: launch latency, not bytes) ----
+// kinds: 0 conv OIHW -> [KK][I][O] (a=O b=I c=KK) | 1 s2d (a=O b=C) | 2 transpose (a=R b=Cc c=ld d=col0) | 3 copy (a=n)
+//        4 conv with channel padding (a=O b=I c=KK d=Opad e=Ipad) | 5 data-gradient operand (a=O b=I c=KS d=ci0 e=nci)
+__global__ void __launch_bounds__(256) pack_table_kernel(const PackJob* jobs, const int2* blocks) {
+    const int2 bj = blocks[blockIdx.x];          // (job, block index inside the job)
+    const PackJob j = jobs[bj.x];
+    const float* src = j.src;
+    float* dst = j.dst;
+    const size_t lo = (size_t)bj.y * kPackPerBlock, hi = lo + kPackPerBlock < j.total ? lo + kPackPerBlock : j.total;
+    for (size_t t = lo + threadIdx.x; t < hi; t += 256) {
+        switch (j.kind) {
+            case 0: { const int o = (int)(t % j.a); const size_t r = t / j.a; const int ci = (int)(r % j.b), tap = (int)(r / j.b);
+                      dst[t] = src[((size_t)o * j.b + ci) * j.c + tap]; break; }
+            case 1: { const int o = (int)(t % j.a); const size_t r = t / j.a; const int c = (int)(r % j.b), tap = (int)(r / j.b);
+                      dst[t] = src[(size_t)o * 4 * j.b + c * 4 + tap]; break; }
+            case 2: { const int r = (int)(t % j.a), c = (int)(t / j.a);
+                      dst[(size_t)c * j.c + j.d + r] = src[(size_t)r * j.b + c]; break; }
+            case 3: dst[t] = src[t]; break;
+            case 4: { const int o = (int)(t % j.d); const size_t r = t / j.d; const int ci = (int)(r % j.e), tap = (int)(r / j.e);
+                      dst[t] = (o < j.a && ci < j.b) ? src[((size_t)o * j.b + ci) * j.c + tap] : 0.f; break; }
+            default: { const int KK = j.c * j.c; const int i = (int)(t % j.e); const size_t r = t / j.e; const int o = (int)(r % j.a), tap = (int)(r / j.a);
+                       const int ky = j.c - 1 - tap / j.c, kx = j.c - 1 - tap % j.c;
+                       dst[t] = src[((size_t)o * j.b + j.d + i) * KK + ky * j.c + kx]; break; }
+        }
+    }
+}
+
+size_t pack_job_total(const PackJob& j) {
+    switch (j.kind) {
+        case 0: return (size_t)j.a * j.b * j.c;
+        case 1: return (size_t)j.a * j.b * 4;
+        case 2: return (size_t)j.a * j.b;
+        case 3: return (size_t)j.a;
+        case 4: return (size_t)j.d * j.e * j.c;
+        default: return (size_t)j.a * j.e * j.c * j.c;
+    }
+}
+
+int pack_table_build(std::vector<PackJob> jobs, PackTable* out) {
+    out->release();
+    if (jobs.empty()) return FC_OK;
+    std::vector<int2> blocks;
+    for (size_t i = 0; i < jobs.size(); ++i) {
+        jobs[i].total = pack_job_total(jobs[i]);
+        const int nb = (int)((jobs[i].total + kPackPerBlock - 1) / kPackPerBlock);
+        for (int b = 0; b < nb; ++b) blocks.push_back(make_int2((int)i, b));
+    }
+    FC_HIP(hipMalloc(reinterpret_cast<void**>(&out->jobs), jobs.size() * sizeof(PackJob)));
+    FC_HIP(hipMalloc(reinterpret_cast<void**>(&out->blocks), blocks.size() * sizeof(int2)));
+    FC_HIP(hipMemcpy(out->jobs, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
+    FC_HIP(hipMemcpy(out->blocks, blocks.data(), blocks.size() * sizeof(int2), hipMemcpyHostToDevice));
+    out->nblocks = (int)blocks.size();
+    return FC_OK;
+}
+
+void PackTable::release() {
+    if (jobs) (void)hipFree(jobs);
+    if (blocks) (void)hipFree(blocks);
+    jobs = nullptr; blocks = nullptr; nblocks = 0;
+}
+
+int pack_table_launch(const PackTable& t, hipStream_t s) {
+    if (!t.nblocks) return FC_OK;
+    hipLaunchKernelGGL(pack_table_kernel, dim3(t.nblocks), dim3(256), 0, s, t.jobs, t.blocks);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
 }
 
 static int pgrid(size_t total) { size_t g = (total + 255) / 256; return (int)(g < 4096 ? (g ? g : 1) : 4096); }

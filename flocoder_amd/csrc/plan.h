@@ -77,6 +77,7 @@ struct ParamStore {
     float *raw = nullptr, *packed = nullptr;
     std::unordered_map<std::string, int64_t> pk;  // name -> offset into packed
     std::vector<PackOp> packops;
+    PackTable pack_table;                          // all of `packops` as one launch
     bool loaded = false;
 
     const float* R(const std::string& n) const { return raw + params[pidx.at(n)].offset; }
@@ -120,14 +121,18 @@ struct ParamStore {
         FC_HIP(hipMalloc(reinterpret_cast<void**>(&raw), (size_t)(raw_numel ? raw_numel : 4) * sizeof(float)));
         FC_HIP(hipMalloc(reinterpret_cast<void**>(&packed), (size_t)(packed_numel ? packed_numel : 4) * sizeof(float)));
         FC_HIP(hipMemset(raw, 0, (size_t)(raw_numel ? raw_numel : 4) * sizeof(float)));
-        return FC_OK;
+        std::vector<PackJob> jobs;
+        for (const PackOp& o : packops) jobs.push_back({raw + o.src, packed + o.dst, o.kind, o.a, o.b, o.kind == 0 ? o.c * o.d : o.c, o.d, o.e, 0});
+        return pack_table_build(jobs, &pack_table);
     }
     void free_device() {
+        pack_table.release();
         if (raw) (void)hipFree(raw);
         if (packed) (void)hipFree(packed);
         raw = packed = nullptr;
     }
     int run_pack(hipStream_t s) const {
+        if (pack_table.nblocks) return pack_table_launch(pack_table, s);
         for (const PackOp& o : packops) {
             const float* src = raw + o.src;
             float* dst = packed + o.dst;

@@ -295,6 +295,7 @@ static void free_plan(fc_unet* u) {
     for (Plan& pln : u->plan) pln.release();
     u->bwd.release();                       // the backward plan points into the forward arena
     u->dgrad_packs.clear();
+    u->dgrad_table.release();
     for (void* p : u->int_allocs) (void)hipFree(p);
     u->int_allocs.clear();
     u->maxB = 0;

@@ -95,14 +95,12 @@ struct BwdBuilder : PlanBuilder {
     void gn_bwd(const Act& dy, const Act& h, const SrcXform& xf, float* dh, bool acc, const std::string& norm, int ss_col) {
         if (err) return;
         GnBwdArgs g;
-        g.dy = dy.p; g.h = h.p; g.xf = xf; g.s12 = s12; g.dh = dh; g.accumulate = acc ? 1 : 0; g.HW = h.H * h.W; g.C = h.C;
+        float* s12l = dmalloc((size_t)B * h.C * 2);      // kept until the batched parameter-gradient launch at the end
+        g.dy = dy.p; g.h = h.p; g.xf = xf; g.s12 = s12l; g.dh = dh; g.accumulate = acc ? 1 : 0; g.HW = h.H * h.W; g.C = h.C;
         push([g](const FwdCtx& c, hipStream_t s) { GnBwdArgs k = g; k.B = c.B; return gn_bwd_launch(k, s); }, "gn_bwd");
-        const float *gm = xf.gamma, *bt = xf.beta, *ssp = xf.ss;
-        const int S = u->S, C = h.C;
-        const int64_t go = off(norm + ".weight"), bo = off(norm + ".bias");
-        float *sp = s12, *dssp = ssp ? dss + ss_col : nullptr;
-        push([=](const FwdCtx& c, hipStream_t s) { return norm_param_grads_launch(sp, gm, bt, ssp, S, c.grads + go, c.grads + bo, dssp, c.B, C, s); }, "norm_param_grads");
+        norm_jobs.push_back({s12l, xf.gamma, xf.beta, xf.ss, off(norm + ".weight"), off(norm + ".bias"), ss_col, h.C});
     }
+    std::vector<NormJob> norm_jobs;
     void materialize(const Act& h, const SrcXform& xf, const Act& y) {   // y = act(gn(h))
         if (err) return;
         FinalizeArgs f;
@@ -254,6 +252,7 @@ int build_backward(fc_unet* u) {
     const Plan& fw = u->plan[0];
     u->bwd.release();
     u->dgrad_packs.clear();
+    u->dgrad_table.release();
     u->dgrad_version = ~0ull;
     if (c.mask_cond) return fail(FC_E_STATE, "unet: the backward pass of the mask-conditioning branches is not built");
     if (u->nchains != 1) return fail(FC_E_STATE, "unet: training needs a single-chain plan (unset FLOCODER_AMD_CHAINS)");
@@ -303,6 +302,18 @@ int build_backward(fc_unet* u) {
         b.wgrad("init_conv.weight", "init_conv.bias", xin, nullptr, g0, 1, 0, 1, 0);
     }
     if (b.err) return b.err;
+    // -- parameter gradients of every norm layer and the FiLM gradients, one launch --
+    {
+        b.scope = "norms";
+        NormJob* jd = reinterpret_cast<NormJob*>(b.dmalloc((b.norm_jobs.size() * sizeof(NormJob) + 3) / 4 + 4));
+        if (b.err) return b.err;
+        FC_HIP(hipMemcpy(jd, b.norm_jobs.data(), b.norm_jobs.size() * sizeof(NormJob), hipMemcpyHostToDevice));
+        const int nj = (int)b.norm_jobs.size();
+        int mc = 0;
+        for (const NormJob& j : b.norm_jobs) if (j.C > mc) mc = j.C;
+        float* dssp = b.dss;
+        b.push([=](const FwdCtx& cx, hipStream_t s) { return norm_param_grads_table_launch(jd, nj, mc, cx.grads, dssp, S, cx.B, s); }, "norm_param_grads");
+    }
     // -- conditioning: every ResnetBlock.mlp (unet.py:79-82,90-92), then time_mlp / class_cond_mlp (unet.py:199-212,310-316) --
     {
         b.scope = "resblock.mlp";
@@ -354,7 +365,9 @@ int build_backward(fc_unet* u) {
         if (it != b.gmap.end()) u->bwd.named["grad:" + kv.first] = it->second.g;
     }
     u->bwd.maxB = B; u->bwd.H = H; u->bwd.W = W;
-    return FC_OK;
+    std::vector<PackJob> jobs;
+    for (const auto& k : u->dgrad_packs) jobs.push_back({u->raw + k.src, k.dst, 5, k.O, k.I, k.KS, k.ci0, k.nci, 0});
+    return pack_table_build(jobs, &u->dgrad_table);
 }
 
 }  // namespace fc
@@ -376,7 +389,7 @@ int fc_unet_train_reserve(fc_unet* u, int max_batch, int height, int width) {
     FC_HIP(hipSetDevice(u->device));
     FC_HIP(hipDeviceSynchronize());
     const int r = build_backward(u);
-    if (r != FC_OK) { u->bwd.release(); u->dgrad_packs.clear(); }
+    if (r != FC_OK) { u->bwd.release(); u->dgrad_packs.clear(); u->dgrad_table.release(); }
     return r;
 }
 
@@ -389,7 +402,7 @@ int fc_unet_backward(fc_unet* u, const float* x, const float* time, const int64_
     hipStream_t s = static_cast<hipStream_t>(stream);
     FC_HIP(hipSetDevice(u->device));
     if (u->dgrad_version != u->param_version) {     // data-gradient operands follow the parameters
-        for (const auto& k : u->dgrad_packs) FC_TRY(pack_conv_dgrad_launch(u->raw + k.src, k.dst, k.O, k.I, k.KS, k.ci0, k.nci, s));
+        FC_TRY(pack_table_launch(u->dgrad_table, s));
         u->dgrad_version = u->param_version;
     }
     FC_HIP(hipMemsetAsync(grads, 0, (size_t)numel * sizeof(float), s));

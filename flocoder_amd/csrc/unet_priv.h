@@ -39,6 +39,7 @@ struct fc_unet : fc::ParamStore {
     fc::Plan bwd;
     struct DgradPack { int64_t src; float* dst; int O, I, KS, ci0, nci; };
     std::vector<DgradPack> dgrad_packs;
+    fc::PackTable dgrad_table;                // all of them as one launch
     uint64_t param_version = 0, dgrad_version = ~0ull;
     int64_t class_lo = 0, class_hi = 0;       // [lo, hi) of class_cond_mlp.* in the flat table
 
