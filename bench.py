@@ -126,7 +126,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path to time (the CPU oracle is only the baseline leg)")
-    device = torch.device("cuda", local_rank)
+    # FLOCODER_AMD_SINGLE_GPU=1 (with FLOCODER_AMD_DIST_BACKEND=gloo): every rank on cuda:0, a rehearsal of the N>1 path on a 1-GPU box
+    device = torch.device("cuda", 0 if os.environ.get("FLOCODER_AMD_SINGLE_GPU") else local_rank)
     torch.cuda.set_device(device)
 
     model = build_model(device)

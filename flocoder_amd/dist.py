@@ -25,7 +25,8 @@ def init(backend: str | None = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this host driver
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # FLOCODER_AMD_DIST_BACKEND=gloo rehearses the multi-rank code path where the ranks cannot each have a GPU
+            backend = os.environ.get("FLOCODER_AMD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -36,7 +36,7 @@ def main():
     rank, local_rank, world = fdist.init()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", 0 if os.environ.get("FLOCODER_AMD_SINGLE_GPU") else local_rank)
     torch.cuda.set_device(device)
     torch.manual_seed(0)
     model = Unet(dim=args.dim, dim_mults=(1, 2, 4, 8), channels=4, n_classes=args.classes).to(device)
