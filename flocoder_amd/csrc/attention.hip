@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(256) linattn_apply_kernel(const float* qkv, co
     __syncthreads();
     const float scale = 0.17677669529663687f;  // 32^-0.5
     for (int j = tid; j < pix_per * heads; j += 256) {
-        const int h = j % heads, pix = blockIdx.x * pix_per + j / heads;
+        const int h = j / pix_per, pix = blockIdx.x * pix_per + j % pix_per;   // one head per wave: context reads are pure broadcasts
         if (pix >= n) continue;
         const float* qp = qkv + ((size_t)b * n + pix) * C3 + h * DH;
         float q[DH];

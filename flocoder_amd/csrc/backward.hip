@@ -23,56 +23,72 @@ static inline int grid_1d(size_t total, int cap = 4096) {
 
 // ===================================================================================================
 // GroupNorm (+FiLM, +SiLU) backward.   Forward: u = (gamma*xhat + beta)*(sc+1) + sh,  y = act(u),  xhat = (h - mean)*rstd.
-// Pass 1: s1[b][c] = sum_hw du, s2[b][c] = sum_hw du*xhat with du = dy*act'(u).             grid (ceil(C/32), B)
-__global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const GnBwdArgs a) {
-    __shared__ float r1[8][32], r2[8][32];
-    const int b = blockIdx.y, lane = threadIdx.x & 31, row = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + lane;
-    const bool valid = c < a.C;
-    float s1 = 0.f, s2 = 0.f;
-    if (valid) {
-        const int cpg = a.C / a.xf.G;
-        float mean, rstd;
-        combine_partials(a.xf, b, c / cpg, &mean, &rstd);
-        float A = rstd * a.xf.gamma[c], Bv = a.xf.beta[c] - mean * A;
-        if (a.xf.ss) {
-            const float sc = a.xf.ss[(size_t)b * a.xf.ss_stride + c] + 1.0f;
-            const float sh = a.xf.ss[(size_t)b * a.xf.ss_stride + a.C + c];
-            A *= sc;
-            Bv = Bv * sc + sh;
+// Pass 1: per 64-pixel chunk, s1[c] = sum du, s2[c] = sum du*xhat with du = dy*act'(u) -> s12p[b][chunk][c][2].
+// grid (nchunks, B); 256 threads = (256/CW) pixel rows x CW channels, CW = min(64, C rounded up to a power of two)
+constexpr int kGnChunk = 64;
+__global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const GnBwdArgs a, int CW, int nchunks) {
+    __shared__ float r1[256], r2[256];
+    const int b = blockIdx.y, chunk = blockIdx.x, lane = threadIdx.x % CW, row = threadIdx.x / CW, rows = 256 / CW;
+    const int p0 = chunk * kGnChunk, p1 = min(a.HW, p0 + kGnChunk), cpg = a.C / a.xf.G;
+    const bool act = a.xf.mode == 2;
+    for (int c0 = 0; c0 < a.C; c0 += CW) {
+        const int c = c0 + lane;
+        float s1 = 0.f, s2 = 0.f;
+        if (c < a.C) {
+            float mean, rstd;
+            combine_partials(a.xf, b, c / cpg, &mean, &rstd);
+            float A = rstd * a.xf.gamma[c], Bv = a.xf.beta[c] - mean * A;
+            if (a.xf.ss) {
+                const float sc = a.xf.ss[(size_t)b * a.xf.ss_stride + c] + 1.0f;
+                const float sh = a.xf.ss[(size_t)b * a.xf.ss_stride + a.C + c];
+                A *= sc;
+                Bv = Bv * sc + sh;
+            }
+            const float* hp = a.h + (size_t)b * a.HW * a.C + c;
+            const float* dp = a.dy + (size_t)b * a.HW * a.C + c;
+            for (int p = p0 + row; p < p1; p += rows) {
+                const float hv = hp[(size_t)p * a.C];
+                float du = dp[(size_t)p * a.C];
+                if (act) du *= silu_grad_e(A * hv + Bv);
+                s1 += du;
+                s2 += du * ((hv - mean) * rstd);
+            }
         }
-        const bool act = a.xf.mode == 2;
-        const float* hp = a.h + (size_t)b * a.HW * a.C + c;
-        const float* dp = a.dy + (size_t)b * a.HW * a.C + c;
-        for (int p = row; p < a.HW; p += 8) {
-            const float hv = hp[(size_t)p * a.C];
-            float du = dp[(size_t)p * a.C];
-            if (act) du *= silu_grad_e(A * hv + Bv);
-            s1 += du;
-            s2 += du * ((hv - mean) * rstd);
+        __syncthreads();
+        r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+        __syncthreads();
+        if (row == 0 && c < a.C) {
+            float t1 = 0.f, t2 = 0.f;
+            for (int r = 0; r < rows; ++r) { t1 += r1[r * CW + lane]; t2 += r2[r * CW + lane]; }
+            float* d = a.s12p + (((size_t)b * nchunks + chunk) * a.C + c) * 2;
+            d[0] = t1;
+            d[1] = t2;
         }
-    }
-    r1[row][lane] = s1; r2[row][lane] = s2;
-    __syncthreads();
-    if (row == 0 && valid) {
-        float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) { t1 += r1[r][lane]; t2 += r2[r][lane]; }
-        a.s12[((size_t)b * a.C + c) * 2] = t1;
-        a.s12[((size_t)b * a.C + c) * 2 + 1] = t2;
     }
 }
 
 // Pass 2: dh = rstd * (gamma' du - P1/n - xhat P2/n),  gamma' = gamma (sc+1),  P1 = sum_{c in g} gamma' s1,  P2 = sum gamma' s2.
-// grid (bps, B); dynamic LDS: [G][4] (mean, rstd, k1, k2) | A[C] | Bv[C] | ga[C]
-__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const GnBwdArgs a, int bps) {
+// grid (bps, B); dynamic LDS: [G][4] (mean, rstd, k1, k2) | A[C] | Bv[C] | ga[C] | s1[C] | s2[C]
+__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const GnBwdArgs a, int bps, int nchunks) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* gt = sm;
     float* A = gt + 4 * a.xf.G;
     float* Bv = A + a.C;
     float* ga = Bv + a.C;
+    float* f1 = ga + a.C;
+    float* f2 = f1 + a.C;
     const int b = blockIdx.y, tid = threadIdx.x, cpg = a.C / a.xf.G;
     for (int g = tid; g < a.xf.G; g += 256) combine_partials(a.xf, b, g, &gt[4 * g], &gt[4 * g + 1]);
+    for (int c = tid; c < a.C; c += 256) {   // fold the chunk partials of this sample (fixed order); block 0 keeps the result for the parameter gradients
+        float t1 = 0.f, t2 = 0.f;
+        for (int k = 0; k < nchunks; ++k) {
+            const float* d = a.s12p + (((size_t)b * nchunks + k) * a.C + c) * 2;
+            t1 += d[0];
+            t2 += d[1];
+        }
+        f1[c] = t1; f2[c] = t2;
+        if (blockIdx.x == 0) { a.s12[((size_t)b * a.C + c) * 2] = t1; a.s12[((size_t)b * a.C + c) * 2 + 1] = t2; }
+    }
     __syncthreads();
     for (int c = tid; c < a.C; c += 256) {
         const int g = c / cpg;
@@ -92,8 +108,8 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const GnBwdArgs a, in
         const float rstd = gt[4 * g + 1];
         for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
             const float gp = ga[c] / rstd;     // gamma'
-            p1 += gp * a.s12[((size_t)b * a.C + c) * 2];
-            p2 += gp * a.s12[((size_t)b * a.C + c) * 2 + 1];
+            p1 += gp * f1[c];
+            p2 += gp * f2[c];
         }
         const float inv_n = 1.0f / ((float)a.HW * (float)cpg);
         gt[4 * g + 2] = rstd * p1 * inv_n;
@@ -123,14 +139,19 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const GnBwdArgs a, in
     }
 }
 
+int gn_bwd_chunks(int HW) { return (HW + kGnChunk - 1) / kGnChunk; }
+
 int gn_bwd_launch(const GnBwdArgs& a, hipStream_t s) {
     if (a.C & 3) return fail(FC_E_SHAPE, "gn_bwd: C must be a multiple of 4");
-    if (!a.xf.mode || !a.xf.stats || !a.s12 || !a.dh) return fail(FC_E_ARG, "gn_bwd: needs statistics and workspaces");
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(cdiv(a.C, 32), a.B), dim3(256), 0, s, a);
+    if (!a.xf.mode || !a.xf.stats || !a.s12 || !a.s12p || !a.dh) return fail(FC_E_ARG, "gn_bwd: needs statistics and workspaces");
+    int CW = 4;
+    while (CW < a.C && CW < 64) CW *= 2;
+    const int nchunks = gn_bwd_chunks(a.HW);
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(nchunks, a.B), dim3(256), 0, s, a, CW, nchunks);
     FC_HIP(hipGetLastError());
     const int bps = finalize_blocks_per_sample(a.HW, a.C);
-    const size_t lds = (size_t)(4 * a.xf.G + 3 * a.C) * sizeof(float);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(bps, a.B), dim3(256), lds, s, a, bps);
+    const size_t lds = (size_t)(4 * a.xf.G + 5 * a.C) * sizeof(float);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(bps, a.B), dim3(256), lds, s, a, bps, nchunks);
     FC_HIP(hipGetLastError());
     return FC_OK;
 }
@@ -284,72 +305,92 @@ __global__ void __launch_bounds__(256) linattn_bwd_ctx_kernel(const float* qkv, 
     if ((tid & 7) == 0) rr[(size_t)blockIdx.x * DH + d] = part;
 }
 
-// Kernel 2, grid (ceil(n/pix_per), B), one thread per (pixel, head): dqkv[b][n][3*heads*32].
+// Kernel 2, grid (ceil(n/64), B), 64*heads threads: wave h owns head h of 64 consecutive pixels, one thread per pixel, so every LDS
+// read of the 32x32 context matrices is a wave-wide broadcast of consecutive addresses (float4 reads, no bank conflicts -- with
+// the heads interleaved across lanes each read hit one bank four times and the kernel took 180 us on average).
 __global__ void __launch_bounds__(256) linattn_bwd_apply_kernel(const float* qkv, const float* dout, const float* ctx, const float* dctx,
-                                                                const float* kst, const float* rr, float* dqkv, int n, int heads, int pix_per) {
+                                                                const float* kst, const float* rr, float* dqkv, int n, int heads) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // ctx[heads][32][32] | dctx[...] | kst[heads][32][2] | rr[heads][32]
     float* cs = sm;
     float* dcs = cs + heads * DH * DH;
     float* ks = dcs + heads * DH * DH;
     float* rs = ks + heads * DH * 2;
-    const int b = blockIdx.y, tid = threadIdx.x;
+    const int b = blockIdx.y, tid = threadIdx.x, nthr = 64 * heads;
     const int C3 = 3 * heads * DH, CO = heads * DH;
-    for (int i = tid; i < heads * DH * DH; i += 256) { cs[i] = ctx[(size_t)b * heads * DH * DH + i]; dcs[i] = dctx[(size_t)b * heads * DH * DH + i]; }
-    for (int i = tid; i < heads * DH * 2; i += 256) ks[i] = kst[(size_t)b * heads * DH * 2 + i];
-    for (int i = tid; i < heads * DH; i += 256) rs[i] = rr[(size_t)b * heads * DH + i];
+    for (int i = tid; i < heads * DH * DH; i += nthr) { cs[i] = ctx[(size_t)b * heads * DH * DH + i]; dcs[i] = dctx[(size_t)b * heads * DH * DH + i]; }
+    for (int i = tid; i < heads * DH * 2; i += nthr) ks[i] = kst[(size_t)b * heads * DH * 2 + i];
+    for (int i = tid; i < heads * DH; i += nthr) rs[i] = rr[(size_t)b * heads * DH + i];
     __syncthreads();
     const float scale = 0.17677669529663687f;
-    for (int j = tid; j < pix_per * heads; j += 256) {
-        const int h = j % heads, pix = blockIdx.x * pix_per + j / heads;
-        if (pix >= n) continue;
-        const float* base = qkv + ((size_t)b * n + pix) * C3 + h * DH;
-        const float* dop = dout + ((size_t)b * n + pix) * CO + h * DH;
-        float* outp = dqkv + ((size_t)b * n + pix) * C3 + h * DH;
-        const float* ch = cs + h * DH * DH;
-        const float* dch = dcs + h * DH * DH;
-        float p[DH], g[DH];
-        // ---- q: p = softmax_d(q_raw); dq = ctx . dout; dq_raw = p (s dq - sum_d p s dq)
+    const int h = tid >> 6, pix = blockIdx.x * 64 + (tid & 63);
+    if (pix >= n) return;
+    const float* base = qkv + ((size_t)b * n + pix) * C3 + h * DH;
+    const float* dop = dout + ((size_t)b * n + pix) * CO + h * DH;
+    float* outp = dqkv + ((size_t)b * n + pix) * C3 + h * DH;
+    const float4* ch = reinterpret_cast<const float4*>(cs + h * DH * DH);
+    const float4* dch = reinterpret_cast<const float4*>(dcs + h * DH * DH);
+    float p[DH], g[DH];
 #pragma unroll
-        for (int i = 0; i < DH; ++i) { p[i] = base[i]; g[i] = dop[i]; }
-        float m = p[0];
+    for (int i = 0; i < DH; i += 4) {
+        const float4 a4 = *reinterpret_cast<const float4*>(base + i), b4 = *reinterpret_cast<const float4*>(dop + i);
+        p[i] = a4.x; p[i + 1] = a4.y; p[i + 2] = a4.z; p[i + 3] = a4.w;
+        g[i] = b4.x; g[i + 1] = b4.y; g[i + 2] = b4.z; g[i + 3] = b4.w;
+    }
+    // ---- q: p = softmax_d(q_raw); dq = ctx . dout; dq_raw = p (s dq - sum_d p s dq)
+    float m = p[0];
 #pragma unroll
-        for (int i = 1; i < DH; ++i) m = fmaxf(m, p[i]);
-        float sum = 0.f;
+    for (int i = 1; i < DH; ++i) m = fmaxf(m, p[i]);
+    float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < DH; ++i) { p[i] = __expf(p[i] - m); sum += p[i]; }
-        const float inv = 1.0f / sum;
-        float dot = 0.f;
-        float dp[DH];
+    for (int i = 0; i < DH; ++i) { p[i] = __expf(p[i] - m); sum += p[i]; }
+    const float inv = 1.0f / sum;
+    float dot = 0.f;
+    float dp[DH];
 #pragma unroll
-        for (int d = 0; d < DH; ++d) {
-            float acc = 0.f;
+    for (int d = 0; d < DH; ++d) {
+        float acc = 0.f;
 #pragma unroll
-            for (int e = 0; e < DH; ++e) acc += ch[d * DH + e] * g[e];
-            p[d] *= inv;
-            dp[d] = acc * scale;
-            dot += p[d] * dp[d];
+        for (int e4 = 0; e4 < DH / 4; ++e4) {
+            const float4 c4 = ch[d * (DH / 4) + e4];
+            acc += c4.x * g[4 * e4] + c4.y * g[4 * e4 + 1] + c4.z * g[4 * e4 + 2] + c4.w * g[4 * e4 + 3];
         }
+        p[d] *= inv;
+        dp[d] = acc * scale;
+        dot += p[d] * dp[d];
+    }
 #pragma unroll
-        for (int d = 0; d < DH; ++d) outp[d] = p[d] * (dp[d] - dot);
-        // ---- k, v: k = exp(k_raw - max) / Z; dk = dctx . v; dk_raw = k (dk - rr); dv = dctx^T . k
-        const float* kp = base + heads * DH;
-        const float* vp = kp + heads * DH;
+    for (int d = 0; d < DH; d += 4)
+        *reinterpret_cast<float4*>(outp + d) = make_float4(p[d] * (dp[d] - dot), p[d + 1] * (dp[d + 1] - dot), p[d + 2] * (dp[d + 2] - dot), p[d + 3] * (dp[d + 3] - dot));
+    // ---- k, v: k = exp(k_raw - max) / Z; dk = dctx . v; dk_raw = k (dk - rr); dv = dctx^T . k
+    const float* kp = base + heads * DH;
+    const float* vp = kp + heads * DH;
 #pragma unroll
-        for (int i = 0; i < DH; ++i) { p[i] = __expf(kp[i] - ks[(h * DH + i) * 2]) * ks[(h * DH + i) * 2 + 1]; g[i] = vp[i]; }
+    for (int i = 0; i < DH; i += 4) {
+        const float4 a4 = *reinterpret_cast<const float4*>(kp + i), b4 = *reinterpret_cast<const float4*>(vp + i);
+        p[i] = __expf(a4.x - ks[(h * DH + i) * 2]) * ks[(h * DH + i) * 2 + 1];
+        p[i + 1] = __expf(a4.y - ks[(h * DH + i + 1) * 2]) * ks[(h * DH + i + 1) * 2 + 1];
+        p[i + 2] = __expf(a4.z - ks[(h * DH + i + 2) * 2]) * ks[(h * DH + i + 2) * 2 + 1];
+        p[i + 3] = __expf(a4.w - ks[(h * DH + i + 3) * 2]) * ks[(h * DH + i + 3) * 2 + 1];
+        g[i] = b4.x; g[i + 1] = b4.y; g[i + 2] = b4.z; g[i + 3] = b4.w;
+    }
+    float dv[DH];
 #pragma unroll
-        for (int d = 0; d < DH; ++d) {
-            float acc = 0.f;
+    for (int e = 0; e < DH; ++e) dv[e] = 0.f;
 #pragma unroll
-            for (int e = 0; e < DH; ++e) acc += dch[d * DH + e] * g[e];
-            outp[heads * DH + d] = p[d] * (acc - rs[h * DH + d]);
+    for (int d = 0; d < DH; ++d) {
+        float acc = 0.f;
+#pragma unroll
+        for (int e4 = 0; e4 < DH / 4; ++e4) {
+            const float4 c4 = dch[d * (DH / 4) + e4];
+            acc += c4.x * g[4 * e4] + c4.y * g[4 * e4 + 1] + c4.z * g[4 * e4 + 2] + c4.w * g[4 * e4 + 3];
+            dv[4 * e4] += c4.x * p[d]; dv[4 * e4 + 1] += c4.y * p[d]; dv[4 * e4 + 2] += c4.z * p[d]; dv[4 * e4 + 3] += c4.w * p[d];
         }
+        dp[d] = p[d] * (acc - rs[h * DH + d]);
+    }
 #pragma unroll
-        for (int e = 0; e < DH; ++e) {
-            float acc = 0.f;
-#pragma unroll
-            for (int d = 0; d < DH; ++d) acc += dch[d * DH + e] * p[d];
-            outp[2 * heads * DH + e] = acc;
-        }
+    for (int d = 0; d < DH; d += 4) {
+        *reinterpret_cast<float4*>(outp + heads * DH + d) = make_float4(dp[d], dp[d + 1], dp[d + 2], dp[d + 3]);
+        *reinterpret_cast<float4*>(outp + 2 * heads * DH + d) = make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]);
     }
 }
 
@@ -357,9 +398,9 @@ int linattn_bwd_launch(const float* qkv, const float* dout, const float* ctx, fl
                        int heads, hipStream_t s) {
     hipLaunchKernelGGL(linattn_bwd_ctx_kernel, dim3(B * heads), dim3(256), 0, s, qkv, dout, ctx, dctx, kst, rr, n, heads);
     FC_HIP(hipGetLastError());
-    const int pix_per = 256 / heads > 0 ? 256 / heads : 1;
+    if (heads < 1 || heads > 4) return fail(FC_E_SHAPE, "linattn_bwd: at most 4 heads");
     const size_t lds = (size_t)(2 * heads * DH * DH + 3 * heads * DH) * sizeof(float);
-    hipLaunchKernelGGL(linattn_bwd_apply_kernel, dim3(cdiv(n, pix_per), B), dim3(256), lds, s, qkv, dout, ctx, dctx, kst, rr, dqkv, n, heads, pix_per);
+    hipLaunchKernelGGL(linattn_bwd_apply_kernel, dim3(cdiv(n, 64), B), dim3(64 * heads), lds, s, qkv, dout, ctx, dctx, kst, rr, dqkv, n, heads);
     FC_HIP(hipGetLastError());
     return FC_OK;
 }
@@ -471,6 +512,33 @@ int dense_bwd_w_launch(const float* dy, int ldy, const float* xpre, int in_act, 
     FC_HIP(hipGetLastError());
     return FC_OK;
 }
+// Every ResnetBlock.mlp weight / bias gradient in one launch: job j owns rows [col, col + O) of the concatenated FiLM gradient
+// dss [B][S]; x = act(xpre) is shared.   blocks[k] = (job, chunk of 256 (o, i) pairs)
+__global__ void __launch_bounds__(256) dense_bwd_w_table_kernel(const DenseWJob* jobs, const int2* blocks, const float* dss, int S, const float* xpre,
+                                                                int in_act, float* grads, int B, int I) {
+    extern __shared__ float xs[];   // act(xpre) [B][I] when it fits, else read through
+    const int2 bj = blocks[blockIdx.x];
+    const DenseWJob j = jobs[bj.x];
+    const size_t t = (size_t)bj.y * 256 + threadIdx.x;
+    if (t >= (size_t)j.O * I) return;
+    const int i = (int)(t % I), o = (int)(t / I);
+    float acc = 0.f, bs = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float d = dss[(size_t)b * S + j.col + o];
+        acc += d * act_apply(xpre[(size_t)b * I + i], in_act);
+        bs += d;
+    }
+    grads[j.dw + t] = acc;
+    if (i == 0) grads[j.db + o] = bs;
+}
+int dense_bwd_w_table_launch(const DenseWJob* jobs_dev, const int2* blocks_dev, int nblocks, const float* dss, int S, const float* xpre, int in_act,
+                             float* grads, int B, int I, hipStream_t s) {
+    if (!nblocks) return FC_OK;
+    hipLaunchKernelGGL(dense_bwd_w_table_kernel, dim3(nblocks), dim3(256), 0, s, jobs_dev, blocks_dev, dss, S, xpre, in_act, grads, B, I);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
 // dxpre[b][i] = act'(xpre[b][i]) * sum_o dy[b][o] W[o][i]     (w_t: weights stored [I][ldw] instead of [O][I])
 __global__ void __launch_bounds__(256) dense_bwd_x_kernel(const float* dy, int ldy, const float* w, int w_t, int ldw, const float* xpre, int in_act,
                                                           float* dx, int accumulate, int B, int I, int O) {

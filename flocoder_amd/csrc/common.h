@@ -243,10 +243,12 @@ struct GnBwdArgs {          // backward of y = act((gamma xhat + beta)(sc+1) + s
     const float* h = nullptr;   // raw normalised tensor (the convolution output)
     SrcXform xf;
     float* s12 = nullptr;       // [B][C][2]: per-channel sums of du and du*xhat (kept for norm_param_grads_launch)
+    float* s12p = nullptr;      // [B][gn_bwd_chunks(HW)][C][2]: the same per 64-pixel chunk (scratch between the two passes)
     float* dh = nullptr;        // NHWC [B][HW][C]
     int accumulate = 0;         // dh += instead of dh =
     int B = 0, HW = 0, C = 0;
 };
+int gn_bwd_chunks(int HW);
 int gn_bwd_launch(const GnBwdArgs& a, hipStream_t s);
 int norm_param_grads_launch(const float* s12, const float* gamma, const float* beta, const float* ss, int ss_stride, float* dgamma,
                             float* dbeta, float* dss, int B, int C, hipStream_t s);
@@ -258,6 +260,9 @@ int attn_small_bwd_launch(const float* qkv, const float* dout, float* dqkv, int 
 // dense layers of the conditioning path; in_act: 0 none, 1 GELU(erf), 2 SiLU applied to `xpre` on the way in
 int dense_fwd_launch(const float* xpre, int in_act, const float* w, const float* bias, float* y, int B, int I, int O, hipStream_t s);
 int dense_bwd_w_launch(const float* dy, int ldy, const float* xpre, int in_act, float* dw, float* db, int B, int I, int O, hipStream_t s);
+struct DenseWJob { int col, O; int64_t dw, db; };
+int dense_bwd_w_table_launch(const DenseWJob* jobs_dev, const int2* blocks_dev, int nblocks, const float* dss, int S, const float* xpre, int in_act,
+                             float* grads, int B, int I, hipStream_t s);
 int dense_bwd_x_launch(const float* dy, int ldy, const float* w, int w_t, int ldw, const float* xpre, int in_act, float* dx, int accumulate,
                        int B, int I, int O, hipStream_t s);
 int sin_emb_launch(const float* time, const float* freqs, float* e, int B, int dim, hipStream_t s);

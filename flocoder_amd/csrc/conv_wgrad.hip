@@ -131,13 +131,24 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradDev p) {
     }
 }
 
+// 256 threads = 64 elements x 4 split lanes (fixed assignment and fixed combine order: bit-reproducible)
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* ws, int nsplit, size_t stride, float* dw, size_t nw, float* db, int nb) {
+    __shared__ float part[4][64];
     const size_t total = nw + (db ? nb : 0);
-    for (size_t e = blockIdx.x * 256ull + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    for (size_t e0 = (size_t)blockIdx.x * 64; e0 < total; e0 += (size_t)gridDim.x * 64) {
+        const size_t e = e0 + el;
         float acc = 0.f;
-        for (int s = 0; s < nsplit; ++s) acc += ws[(size_t)s * stride + e];
-        if (e < nw) dw[e] = acc;
-        else db[e - nw] = acc;
+        if (e < total)
+            for (int s = sl; s < nsplit; s += 4) acc += ws[(size_t)s * stride + e];
+        __syncthreads();
+        part[sl][el] = acc;
+        __syncthreads();
+        if (sl == 0 && e < total) {
+            const float v = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
+            if (e < nw) dw[e] = v;
+            else db[e - nw] = v;
+        }
     }
 }
 
@@ -201,7 +212,7 @@ int conv_wgrad_launch(const WgradArgs& a, hipStream_t s) {
     if (d.nsplit > 1) {
         const size_t nw = (size_t)a.Cout * a.Cin * a.KS * a.KS;
         const size_t total = nw + (a.db ? a.Cout : 0);
-        const int g = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        const int g = (int)((total + 63) / 64 < 4096 ? (total + 63) / 64 : 4096);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g), dim3(256), 0, s, a.ws, d.nsplit, d.part_stride, a.dw, nw, a.db, a.Cout);
         FC_HIP(hipGetLastError());
     }

@@ -27,7 +27,7 @@ struct BwdBuilder : PlanBuilder {
     const Plan* fw;
     struct Slot { Act g; bool written = false; };
     std::map<const float*, Slot> gmap;
-    float *ws = nullptr, *s12 = nullptr, *dss = nullptr;
+    float *ws = nullptr, *s12 = nullptr, *s12p = nullptr, *dss = nullptr;
     size_t ws_floats = 0;
     BwdBuilder(fc_unet* u_, const Plan* fw_, Plan* pl_, int B_) : u(u_), fw(fw_) { pl = pl_; B = B_; }
 
@@ -96,7 +96,7 @@ struct BwdBuilder : PlanBuilder {
         if (err) return;
         GnBwdArgs g;
         float* s12l = dmalloc((size_t)B * h.C * 2);      // kept until the batched parameter-gradient launch at the end
-        g.dy = dy.p; g.h = h.p; g.xf = xf; g.s12 = s12l; g.dh = dh; g.accumulate = acc ? 1 : 0; g.HW = h.H * h.W; g.C = h.C;
+        g.dy = dy.p; g.h = h.p; g.xf = xf; g.s12 = s12l; g.s12p = s12p; g.dh = dh; g.accumulate = acc ? 1 : 0; g.HW = h.H * h.W; g.C = h.C;
         push([g](const FwdCtx& c, hipStream_t s) { GnBwdArgs k = g; k.B = c.B; return gn_bwd_launch(k, s); }, "gn_bwd");
         norm_jobs.push_back({s12l, xf.gamma, xf.beta, xf.ss, off(norm + ".weight"), off(norm + ".bias"), ss_col, h.C});
     }
@@ -264,6 +264,10 @@ int build_backward(fc_unet* u) {
     b.ws_floats = max_wgrad_ws(u, fw, B);
     b.ws = b.dmalloc(b.ws_floats ? b.ws_floats : 4);
     b.s12 = b.dmalloc((size_t)B * maxC * 2);
+    {   // chunk partials of the GroupNorm backward: the largest (pixels/64) x channels product over the tape
+        size_t m = (size_t)gn_bwd_chunks(H * W) * maxC;
+        b.s12p = b.dmalloc((size_t)B * m * 2);
+    }
     b.dss = b.dmalloc((size_t)B * S);
     float* redws = b.dmalloc(256);
     (void)redws;
@@ -319,11 +323,23 @@ int build_backward(fc_unet* u) {
         b.scope = "resblock.mlp";
         const float* te = fw.t_emb;
         float* dss = b.dss;
-        for (auto& kv : u->ss_off) {
-            const std::string& p = kv.first;
-            const int col = kv.second, rows = (int)u->params[u->pidx.at(p + ".mlp.1.bias")].numel;
-            const int64_t wo = b.off(p + ".mlp.1.weight"), bo = b.off(p + ".mlp.1.bias");
-            b.push([=](const FwdCtx& cx, hipStream_t s) { return dense_bwd_w_launch(dss + col, S, te, 2, cx.grads + wo, cx.grads + bo, cx.B, td, rows, s); }, "dense_bwd_w");
+        {   // every block's mlp.1 weight / bias gradient: one table-driven launch
+            std::vector<DenseWJob> jobs;
+            std::vector<int2> blocks;
+            for (auto& kv : u->ss_off) {
+                const std::string& p = kv.first;
+                const int rows = (int)u->params[u->pidx.at(p + ".mlp.1.bias")].numel;
+                jobs.push_back({kv.second, rows, b.off(p + ".mlp.1.weight"), b.off(p + ".mlp.1.bias")});
+                const int nb = cdiv(rows * td, 256);
+                for (int k = 0; k < nb; ++k) blocks.push_back(make_int2((int)jobs.size() - 1, k));
+            }
+            DenseWJob* jd = reinterpret_cast<DenseWJob*>(b.dmalloc((jobs.size() * sizeof(DenseWJob) + 3) / 4 + 4));
+            int2* bd = reinterpret_cast<int2*>(b.dmalloc(blocks.size() * 2 + 4));
+            if (b.err) return b.err;
+            FC_HIP(hipMemcpy(jd, jobs.data(), jobs.size() * sizeof(DenseWJob), hipMemcpyHostToDevice));
+            FC_HIP(hipMemcpy(bd, blocks.data(), blocks.size() * sizeof(int2), hipMemcpyHostToDevice));
+            const int nblk = (int)blocks.size();
+            b.push([=](const FwdCtx& cx, hipStream_t s) { return dense_bwd_w_table_launch(jd, bd, nblk, dss, S, te, 2, cx.grads, cx.B, td, s); }, "dense_bwd_w");
         }
         float* dT = b.dmalloc((size_t)B * td);
         const float* wt = u->P("__ss_wt");
