@@ -85,6 +85,7 @@ SIGNATURES = {
     "fc_vqvae_flops_per_sample": (C.c_double, [_vp, _i]),
     "fc_vae_op_info": (_i, [_vp, _i, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_double)]),
     "fc_vae_profile_ops": (_i, [_vp, _i, _vp, _vp, _i, _i, C.POINTER(C.c_float), _i, _vp]),
+    "fc_rvq_quantize": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "fc_mask_encoder_create": (_i, [_i, C.POINTER(_vp)]),
     "fc_mask_encoder_destroy": (None, [_vp]),
     "fc_mask_encoder_param_count": (_i, [_vp]),

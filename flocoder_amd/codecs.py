@@ -230,13 +230,70 @@ class _NoiseInjectionParams(nn.Module):
         nn.init.zeros_(self.to_noise_bias.weight)
 
 
+class _Codebook(nn.Module):
+    def __init__(self, size, dim):
+        super().__init__()
+        self.register_buffer("initted", torch.tensor(False))
+        self.register_buffer("cluster_size", torch.zeros(1, size))
+        self.register_buffer("embed_avg", torch.zeros(1, size, dim))
+        self.register_buffer("embed", torch.zeros(1, size, dim))
+
+
+class _VQLayer(nn.Module):
+    def __init__(self, size, dim):
+        super().__init__()
+        self._codebook = _Codebook(size, dim)
+
+
+class ResidualVQ(nn.Module):
+    """Inference form of ``vector_quantize_pytorch.ResidualVQ`` as VQVAE builds it (codecs.py:456-467), holding the buffers under the
+    package's state_dict names (``layers.{i}._codebook.{initted,cluster_size,embed_avg,embed}``) so trained checkpoints load.
+    THIRD-PARTY ALGORITHM, PARITY UNPINNED (the package is absent offline): per level the nearest codeword of the running
+    residual, output = their sum; k-means initialisation, EMA updates and the training losses are not built -- calling it with
+    codebooks that were never initialised (``initted`` false) or in training mode raises."""
+
+    def __init__(self, dim, codebook_size, num_quantizers, **unused):
+        super().__init__()
+        self.dim, self.codebook_size, self.num_quantizers = dim, codebook_size, num_quantizers
+        self.layers = nn.ModuleList([_VQLayer(codebook_size, dim) for _ in range(num_quantizers)])
+
+    @property
+    def codebooks(self):
+        return torch.stack([l._codebook.embed[0] for l in self.layers])
+
+    def _check(self, t):
+        if self.training:
+            raise NotImplementedError("ResidualVQ: only the inference form is built (codec training is out of scope)")
+        if not all(bool(l._codebook.initted) for l in self.layers):
+            raise NotImplementedError("ResidualVQ: codebooks are uninitialised (k-means init is not built); load a trained checkpoint")
+        if not t.is_cuda:
+            raise RuntimeError("flocoder_amd.ResidualVQ runs on MI355X (gfx950) only; there is no CPU path")
+
+    def quantize_nchw(self, z):
+        self._check(z)
+        bsz, d, h, w = z.shape
+        z = z.contiguous().float()
+        cb = self.codebooks.to(z.device).contiguous()
+        zq = torch.empty_like(z)
+        idx = torch.empty(bsz * h * w, self.num_quantizers, dtype=torch.int64, device=z.device)
+        B.check(B.lib().fc_rvq_quantize(B.ptr(z), B.ptr(cb), B.ptr(zq), B.ptr(idx), bsz, d, h * w, self.codebook_size, self.num_quantizers,
+                                        B.current_stream(z.device)))
+        return zq, idx, torch.zeros(1, self.num_quantizers, device=z.device)
+
+    def forward(self, x):
+        """x [N, dim] (as VQVAE.quantize passes it) or [B, n, dim] -> (quantized, indices [..., levels], losses [1, levels])."""
+        flat = x.reshape(-1, x.shape[-1])
+        zq, idx, loss = self.quantize_nchw(flat.t().contiguous().view(1, x.shape[-1], flat.shape[0], 1))
+        return zq.view(x.shape[-1], flat.shape[0]).t().reshape(x.shape), idx.view(*x.shape[:-1], self.num_quantizers), loss
+
+
 class VQVAE(nn.Module):
     """codecs.py:395-574 -- encode / decode on the gfx950 library (``fc_vqvae_*``), NATTEN-less, eval mode.
 
     Parameters carry the reference's state_dict names (``encoder.0.conv1.weight`` ... ``decoder.layers.0.q_proj.weight`` ...), so
-    ``load_state_dict(ckpt['model_state_dict'], strict=False)`` takes a reference checkpoint as is.  ``quantize`` / ``forward``
-    need ResidualVQ (third-party ``vector_quantize_pytorch``, not restated -- SURVEY.md 8c) and raise NotImplementedError, as does
-    ``decode`` with a non-zero ``noise_strength`` (training-time NoiseInjection)."""
+    ``load_state_dict(ckpt['model_state_dict'], strict=False)`` takes a reference checkpoint as is.  ``quantize`` / ``forward`` run the
+    inference form of ResidualVQ (third party, parity unpinned -- see ``ResidualVQ`` above); ``decode`` with a non-zero
+    ``noise_strength`` (training-time NoiseInjection) raises NotImplementedError."""
 
     def __init__(self, in_channels=3, hidden_channels=256, num_downsamples=3, vq_num_embeddings=512, internal_dim=256,
                  codebook_levels=3, vq_embedding_dim=4, commitment_weight=0.25, use_checkpoint=False, no_natten=False,
@@ -290,6 +347,7 @@ class VQVAE(nn.Module):
             cur, i = co, i + 7
         self.decoder.layers.add_module(str(i), _NoiseInjectionParams(cur))
         self.decoder.layers.add_module(str(i + 3), _NoiseInjectionParams(64))
+        self.vq = ResidualVQ(dim=vq_embedding_dim, codebook_size=vq_num_embeddings, num_quantizers=codebook_levels)
         self.register_buffer('codebook_usage', torch.zeros(codebook_levels, vq_num_embeddings))
         self.usage_count = 0
         self._handle, self._handle_device, self._synced = None, None, None
@@ -358,11 +416,31 @@ class VQVAE(nn.Module):
         return out
 
     def quantize(self, z, debug=False):
-        raise NotImplementedError("VQVAE.quantize needs ResidualVQ (vector_quantize_pytorch, third-party): not part of this build "
-                                  "(SURVEY.md 8c); run with preencoding.quantize=false")
+        """codecs.py:504-521: z [B,C,h,w] -> (z_q [B,C,h,w], commit_loss); the indices of the last call stay in ``self.indices``."""
+        z_q, self.indices, commit_loss = self.vq.quantize_nchw(z)
+        return z_q, commit_loss
+
+    @torch.no_grad()
+    def calc_distance_stats(self, z, z_q):
+        """codecs.py:527-536 (diagnostic)."""
+        z_flat = z.reshape(-1, z.shape[1])
+        distances = torch.norm(z_flat.unsqueeze(1) - self.vq.codebooks[0].to(z.device), dim=-1)
+        return {'codebook_mean_dist': distances.mean().item(), 'codebook_max_dist': distances.max().item()}
 
     def forward(self, x, noise_strength=None, minval=0, get_stats=False):
-        raise NotImplementedError("VQVAE.forward goes through quantize(); use encode()/decode() (the flow path never calls forward)")
+        """codecs.py:545-574 in eval mode: encode -> quantize -> decode; returns (recon, commit_loss.mean()[, stats])."""
+        if self.training:
+            raise NotImplementedError("VQVAE.forward: training mode (codec training) is out of scope; call .eval()")
+        z = self.encode(x)
+        if noise_strength is None:
+            noise_strength = 0.0
+        if self.info is None:
+            self.info = z.shape
+        z_q, commit_loss = self.quantize(z)
+        x_recon = self.decode(z_q, noise_strength=noise_strength)
+        if get_stats:
+            return x_recon, commit_loss.mean(), self.calc_distance_stats(z, z_q)
+        return x_recon, commit_loss.mean()
 
     def flops_per_sample(self, decode=True) -> float:
         return float(B.lib().fc_vqvae_flops_per_sample(self._handle, int(decode))) if self._handle else 0.0

@@ -222,6 +222,12 @@ int fc_vqvae_encode(fc_vqvae* v, const float* x_dev, float* z_out_dev, int batch
 /* x = vqvae.decode(z_q)  (codecs.py:523-525, noise_strength 0): z_dev [B,vq_embedding_dim,h,w] -> x_out_dev [B,in_channels,H,W]. */
 int fc_vqvae_decode(fc_vqvae* v, const float* z_dev, float* x_out_dev, int batch, int lat_height, int lat_width, void* stream);
 double fc_vqvae_flops_per_sample(const fc_vqvae* v, int decode);
+/* z_q, indices = ResidualVQ(z) in inference form (replaces VQVAE.quantize, codecs.py:504-521 -> vector_quantize_pytorch.ResidualVQ,
+ * third party, parity unpinned): per level the nearest codeword of the running residual, z_q = their sum.
+ * z_dev / zq_out_dev [B,dim,hw] (NCHW with hw = h*w); codebooks_dev [levels][codebook_size][dim]; indices_out_dev [B*hw][levels]
+ * int64 or NULL. */
+int fc_rvq_quantize(const float* z_dev, const float* codebooks_dev, float* zq_out_dev, int64_t* indices_out_dev, int batch, int dim, int hw,
+                    int codebook_size, int levels, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Inpainting conditioning  (replaces flocoder/inpainting.py:161-253 MaskEncoder / mask_blending)

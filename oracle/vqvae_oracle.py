@@ -3,8 +3,9 @@
 TEST INFRASTRUCTURE ONLY -- see ``oracle/__init__.py``.  Parity status: PINNED for ``encode`` and ``decode`` --
 ``tools/make_golden.py`` runs the reference's own ``VQVAE`` (with a stand-in for the absent ``vector_quantize_pytorch``
 package, which neither method calls) on seeded weights and ``tests/test_oracle_golden.py`` holds this file to the result
-(fixture g9).  ``quantize`` (ResidualVQ, third-party, absent) is NOT restated: parity unpinned, out of the first build
-(SURVEY.md 8c).  NATTEN is absent here, so ``attention='natten'`` blocks have no attention (codecs.py:170-175, SURVEY Q23);
+(fixture g9).  ``quantize`` = ``vector_quantize_pytorch.ResidualVQ`` (``>=1.22.4``, pyproject.toml:41; call sites codecs.py:456-467,
+504-521) is third-party and absent: ``residual_vq`` / ``quantize`` below restate its published INFERENCE behaviour -- PARITY
+UNPINNED.  NATTEN is absent here, so ``attention='natten'`` blocks have no attention (codecs.py:170-175, SURVEY Q23);
 eval mode: dropout is the identity and NoiseInjection is a no-op at noise_strength 0 (codecs.py:229-232).
 """
 from __future__ import annotations
@@ -129,3 +130,28 @@ def decode(sd: SD, z: Tensor) -> Tensor:
         i += 7
     h = F.silu(_conv(sd, L + str(i + 1), h, padding=1))   # i is a NoiseInjection
     return _conv(sd, L + str(i + 4), h, padding=1)        # i+2 SiLU, i+3 NoiseInjection
+
+
+def residual_vq(codebooks: Tensor, x: Tensor):
+    """ResidualVQ.forward in eval mode on flattened vectors x [N, D] with codebooks [L, K, D] (vector_quantize_pytorch: per layer
+    ``embed_ind = argmax(-cdist(residual, embed))``, ``quantize = embed[embed_ind]``, ``residual -= quantize``; outputs the sum of the
+    layers' codewords, indices [N, L] and -- nothing is learnt in eval -- zero losses [1, L]).  PARITY UNPINNED (third party)."""
+    residual, out, idx = x.clone(), torch.zeros_like(x), []
+    for cb in codebooks:
+        d = ((residual[:, None, :] - cb[None, :, :]) ** 2).sum(-1)
+        i = d.argmin(dim=1)
+        q = cb[i]
+        residual = residual - q
+        out = out + q
+        idx.append(i)
+    return out, torch.stack(idx, dim=-1), torch.zeros(1, codebooks.shape[0])
+
+
+def quantize(sd: SD, z: Tensor):
+    """VQVAE.quantize, codecs.py:504-521: permute to [N, C], ResidualVQ, back to NCHW.  Codebooks = ``vq.layers.{i}._codebook.embed``
+    ([1, K, D] each).  Returns (z_q, commit_loss [1, L], indices [N, L])."""
+    L = len({k.split(".")[2] for k in sd if k.startswith("vq.layers.") and k.endswith("._codebook.embed")})
+    cbs = torch.stack([sd[f"vq.layers.{i}._codebook.embed"].reshape(-1, z.shape[1]) for i in range(L)])
+    zp = z.permute(0, 2, 3, 1)
+    zq, idx, loss = residual_vq(cbs, zp.reshape(-1, z.shape[1]))
+    return zq.view(zp.shape).permute(0, 3, 1, 2).contiguous(), loss, idx

@@ -91,24 +91,30 @@ def test_vqvae_mirror_state_dict_and_checkpoint(tmp_path):
     codec = setup_codec(vq, "cpu", load_checkpoint=False)
     assert isinstance(codec, VQVAE) and codec.in_channels == 3 and not codec.training
     ref = g["midi_vqgan_shapes"]
-    own = {k: tuple(v.shape) for k, v in codec.state_dict().items() if k != "codebook_usage"}
+    own = {k: tuple(v.shape) for k, v in codec.state_dict().items() if k != "codebook_usage" and not k.startswith("vq.")}
     assert own == {k: tuple(v) for k, v in ref.items()}
     assert list(own) != [] and sum(1 for _ in codec.parameters()) == len(ref)
+    # ResidualVQ buffers under vector_quantize_pytorch's names (codecs.py:456-467), 4 per level
+    vqk = [k for k in codec.state_dict() if k.startswith("vq.")]
+    assert len(vqk) == 4 * codec.codebook_levels and "vq.layers.0._codebook.embed" in vqk
+    assert tuple(codec.state_dict()["vq.layers.0._codebook.embed"].shape) == (1, codec.vq_num_embeddings, 4)
     sd = synth_state_dict(ref, 9)
-    sd["vq.layers.0._codebook.embed"] = torch.zeros(1, 512, 4)                 # present in real checkpoints, ignored here
+    sd["vq.layers.0._codebook.embed"] = torch.ones(1, codec.vq_num_embeddings, 4)     # real checkpoints carry the codebooks
+    sd["vq.layers.0._codebook.initted"] = torch.tensor(True)
     path = str(tmp_path / "vqgan_best.pt")
     torch.save({"model_state_dict": sd, "epoch": 3}, path)
     vq.vqgan_checkpoint = path
     codec = setup_codec(vq, "cpu")
     assert torch.equal(codec.state_dict()["encoder.0.conv1.weight"], sd["encoder.0.conv1.weight"])
     assert torch.equal(codec.state_dict()["decoder.layers.0.q_proj.bias"], sd["decoder.layers.0.q_proj.bias"])
+    assert bool(codec.vq.layers[0]._codebook.initted) and float(codec.vq.codebooks[0].sum()) == codec.vq_num_embeddings * 4
     with pytest.raises(RuntimeError, match="no CPU path"):
         codec.encode(torch.zeros(1, 3, 128, 128))
     with pytest.raises(NotImplementedError):
         codec.quantize(torch.zeros(1, 4, 16, 16))
     small = VQVAE(in_channels=1, hidden_channels=32, num_downsamples=4, internal_dim=32, vq_embedding_dim=4)
     ref = g["gray_nd4_small_shapes"]
-    assert {k: tuple(v.shape) for k, v in small.state_dict().items() if k != "codebook_usage"} == {k: tuple(v) for k, v in ref.items()}
+    assert {k: tuple(v.shape) for k, v in small.state_dict().items() if k != "codebook_usage" and not k.startswith("vq.")} == {k: tuple(v) for k, v in ref.items()}
 
 
 def test_sd_vae_wrapper_state_dict_layout_and_no_cpu_path():

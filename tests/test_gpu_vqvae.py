@@ -21,7 +21,7 @@ def build(tag):
     sd = synth_state_dict(g[tag + "_shapes"], 9)
     m = VQVAE(**CFG[tag]).eval()
     missing, unexpected = m.load_state_dict(sd, strict=False)
-    assert not unexpected and set(missing) <= {"codebook_usage"}
+    assert not unexpected and all(k == "codebook_usage" or k.startswith("vq.") for k in missing)
     return m.to(DEV), sd, g
 
 
@@ -53,6 +53,43 @@ def test_batch_and_resolution_vs_oracle():
     assert y.shape == (3, 1, 64, 128) and rel_l2(y.cpu(), vq.decode(sd, zq)) < TOL
     assert rel_l2(m.decode(zq[2:3].to(DEV)).cpu(), y[2:3].cpu()) < 1e-5          # batch independence
     assert torch.equal(m.decode(zq.to(DEV)), y)                                    # bit-reproducible launches
+
+
+def test_quantize_and_forward_inference_form():
+    """VQVAE.quantize / forward on the inference form of ResidualVQ (third party, parity unpinned): the GPU kernel against the
+    oracle's restatement, plus the structural properties any residual quantiser has."""
+    from flocoder_amd.codecs import VQVAE
+    g = load_golden("g9_vqvae")
+    m = VQVAE(vq_num_embeddings=64, codebook_levels=3, **CFG["gray_nd4_small"]).eval()
+    m.load_state_dict(synth_state_dict(g["gray_nd4_small_shapes"], 9), strict=False)
+    gen = torch.Generator().manual_seed(1)
+    sdv = {}
+    for i in range(3):
+        cb = torch.randn(1, 64, 4, generator=gen) * (0.5 ** i)
+        m.vq.layers[i]._codebook.embed.copy_(cb)
+        m.vq.layers[i]._codebook.initted.fill_(True)
+        sdv[f"vq.layers.{i}._codebook.embed"] = cb
+    m = m.to(DEV)
+    z = torch.randn(3, 4, 8, 8, generator=gen)
+    zq, loss = m.quantize(z.to(DEV))
+    ref_q, ref_loss, ref_idx = vq.quantize(sdv, z)
+    assert torch.equal(m.indices.cpu(), ref_idx) and m.indices.shape == (3 * 64, 3)
+    assert rel_l2(zq.cpu(), ref_q) < 1e-6 and loss.shape == (1, 3) and float(loss.abs().sum()) == 0.0
+    assert float((z - zq.cpu()).norm()) < float(z.norm())                        # quantisation reduces the residual
+    zq2, _ = m.quantize(zq)                                                      # re-quantising stays within the codebook lattice
+    assert float((zq2 - zq).abs().max()) < float(zq.abs().max())
+    flat = z.permute(0, 2, 3, 1).reshape(-1, 4).to(DEV)                          # the `.vq(flat)` protocol of sampling.py:281
+    q2, idx2, _ = m.vq(flat)
+    assert torch.equal(idx2.cpu(), ref_idx) and rel_l2(q2.cpu(), ref_q.permute(0, 2, 3, 1).reshape(-1, 4)) < 1e-6
+    x = torch.rand(2, 1, 128, 128, generator=gen)
+    recon, closs, stats = m(x.to(DEV), get_stats=True)
+    sd_all = synth_state_dict(g["gray_nd4_small_shapes"], 9)
+    zr = vq.encode(sd_all, x)
+    assert recon.shape == x.shape and float(closs) == 0.0 and stats["codebook_mean_dist"] > 0
+    assert rel_l2(recon.cpu(), vq.decode(sd_all, vq.quantize(sdv, zr)[0])) < 1e-3   # an encoder rounding flip may move one codeword
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m(x.to(DEV))
 
 
 def test_protocol_errors():
