@@ -22,7 +22,8 @@ def family(name):
         a = [x.strip() for x in m.group(1).split(",")]
         return TILES.get(tuple(a[:5]), name)
     m = re.match(r"(?:void )?fc::(\w+?)_kernel", name)
-    return m.group(1) if m else name
+    fam = m.group(1) if m else name
+    return {"la_ctx_fast": "linattn_fused", "la_apply_fast": "linattn_fused", "la_ctx": "linattn_fused", "la_apply": "linattn_fused"}.get(fam, fam)
 
 
 def load(path, counter):
@@ -36,7 +37,7 @@ def load(path, counter):
 def main():
     fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
     n_fwd = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-    skip = {"pack_conv", "pack_transpose", "pack_s2d", "pack_conv_pad"}
+    skip = {"pack_conv", "pack_transpose", "pack_s2d", "pack_conv_pad", "pack_table"}
     out, tot_r, tot_w = {}, 0.0, 0.0
     for k in sorted(set(fetch) | set(write)):
         if k in skip:
