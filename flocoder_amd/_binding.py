@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "_lib", "libflocoder_amd.so")
 FC_OK, FC_E_ARG, FC_E_SHAPE, FC_E_ARCH, FC_E_HIP, FC_E_STATE = 0, -1, -2, -3, -4, -5
 FC_METHOD_EULER, FC_METHOD_RK4 = 0, 1
 TILE_AUTO = -1
-TILES = {"M128N32": 0, "M128N64": 1, "M64N32K2": 2, "M32N32K4": 3, "M64N64K2": 4}
+TILES = {"M128N32": 0, "M128N64": 1, "M64N32K2": 2, "M32N32K4": 3, "M64N64K2": 4, "M256N64": 5}
 
 
 class fc_unet_config(C.Structure):

@@ -98,7 +98,7 @@ struct ConvArgs {
 
 // Tile configurations of the implicit-GEMM kernel (see conv_igemm.hip).
 enum ConvTile { TILE_AUTO = -1, TILE_M128N32 = 0, TILE_M128N64 = 1, TILE_M64N32K2 = 2, TILE_M32N32K4 = 3, TILE_M64N64K2 = 4,
-                TILE_COUNT = 5 };
+                TILE_M256N64 = 5, TILE_COUNT = 6 };
 
 struct ConvGeom {  // filled by conv_plan(): what a consumer must know about `stats_out`
     int tile = 0, grid = 0, T = 0, pipe = 0;

@@ -235,6 +235,7 @@ static const TileInfo kTiles[TILE_COUNT] = {
     {64, 32, 32, 2, 1, 2},   // TILE_M64N32K2
     {32, 32, 32, 4, 1, 1},   // TILE_M32N32K4
     {64, 64, 16, 2, 2, 2},   // TILE_M64N64K2
+    {256, 64, 16, 1, 4, 4},  // TILE_M256N64: pipelined kernel only
 };
 
 // the pipelined kernel's instantiations (conv_pipe.hip): same wave layouts, chunk depth chosen so that two stages fit
@@ -244,6 +245,7 @@ static const TileInfo kTilesPipe[TILE_COUNT] = {
     {64, 32, 32, 2, 1, 2},   // TILE_M64N32K2
     {32, 32, 32, 4, 1, 1},   // TILE_M32N32K4
     {64, 64, 16, 2, 2, 2},   // TILE_M64N64K2
+    {256, 64, 16, 1, 4, 4},  // TILE_M256N64: 64 x 64 per wave (2 x 2 MFMA tiles): one LDS read per MFMA, weights reused by 256 rows
 };
 constexpr int kPipeNPL = 8;   // patch float4 elements a thread may own per stage
 
@@ -345,6 +347,7 @@ static int conv_geometry(const ConvArgs& a, int tile, bool pipe, ConvDev* d, Con
         return FC_OK;
     }
     if (a.fin.gamma) return fail(FC_E_SHAPE, "conv: fused tail is implemented in the pipelined kernel only");
+    if (tile == TILE_M256N64) return fail(FC_E_SHAPE, "conv: M256N64 exists in the pipelined kernel only");
     // LDS carve (in floats)
     int o = 0;
     p.o_pixoff = o; o += align4(p.P);
@@ -383,7 +386,14 @@ static int auto_tile(const ConvArgs& a) {
     const int hw = a.H * a.W;
     auto blocks = [&](int t) { return (M / kTiles[t].BM) * cdiv(a.Cout, kTiles[t].BN); };
     auto ok = [&](int t) { return !(a.w_batch_stride && hw < kTiles[t].BM) && M >= kTiles[t].BM; };
-    if (a.Cout >= 64 && ok(TILE_M128N64) && blocks(TILE_M128N64) >= 512) return TILE_M128N64;
+    // measured on the SD-VAE shapes (tools/conv_microbench.py --vae, B=16): M256N64 113 / 109 / 101 TFLOP/s at 512@64^2 / 256@128^2 /
+    // 128@256^2 against 101 / 97 / 90 for M128N64 and 98 / 105 / 98 for M128N32; the 64-wide column tile only pays for 1x1 layers
+    if (a.Cout >= 64 && ok(TILE_M256N64) && blocks(TILE_M256N64) >= 1024 && !pipe_disabled()) {
+        ConvDev d;
+        ConvGeom g;
+        if (conv_geometry(a, TILE_M256N64, true, &d, &g) == FC_OK) return TILE_M256N64;   // else: patch / LDS limits, fall through
+    }
+    if (a.KS == 1 && a.Cout >= 64 && ok(TILE_M128N64) && blocks(TILE_M128N64) >= 512) return TILE_M128N64;
     if (ok(TILE_M128N32) && blocks(TILE_M128N32) >= 256) return TILE_M128N32;   // one full wave of workgroups: measured 20 vs 29 us on the 64-channel 16x16 layers (profiles/r01_c_conv_microbench.txt)
     if (a.Cout >= 64 && ok(TILE_M64N64K2) && blocks(TILE_M64N64K2) >= 384) return TILE_M64N64K2;
     if (ok(TILE_M64N32K2) && blocks(TILE_M64N32K2) >= 256) return TILE_M64N32K2;

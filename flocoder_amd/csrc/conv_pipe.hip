@@ -339,7 +339,8 @@ const float* conv_zeros16() { return g_zeros16; }
     X(TILE_M128N64, 4, 1, 1, 1, 2, 16, KS)  \
     X(TILE_M64N32K2, 2, 1, 2, 1, 1, 32, KS) \
     X(TILE_M32N32K4, 1, 1, 4, 1, 1, 32, KS) \
-    X(TILE_M64N64K2, 2, 1, 2, 1, 2, 16, KS)
+    X(TILE_M64N64K2, 2, 1, 2, 1, 2, 16, KS) \
+    X(TILE_M256N64, 4, 1, 1, 2, 2, 16, KS)
 
 template <int KS>
 static int pipe_attr_ks() {

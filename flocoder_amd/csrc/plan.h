@@ -66,7 +66,7 @@ struct PackOp { int kind; int64_t src, dst; int a, b, c, d, e = 0; };
 // kind 0 conv OIHW(O=a,I=b,KH=c,KW=d), 1 s2d, 2 transpose(R=a,Cc=b,ld=c,col0=d), 3 copy(a floats), 4 conv with channel padding(O=a,I=b,KK=c,Opad=d,Ipad=e)
 
 static const char* const kTileNames[] = {"conv_igemm<M128,N32>", "conv_igemm<M128,N64>", "conv_igemm<M64,N32,K2>", "conv_igemm<M32,N32,K4>",
-                                         "conv_igemm<M64,N64,K2>"};
+                                         "conv_igemm<M64,N64,K2>", "conv_igemm<M256,N64>"};
 
 // Parameters as the reference stores them (`raw`, flat, table order, every tensor 16-byte aligned) plus the operand
 // layouts the kernels read (`packed`), and the list of re-layout launches that turns one into the other.

@@ -8,7 +8,7 @@ from conftest import rel_l2
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
-TILES = ["M128N32", "M128N64", "M64N32K2", "M32N32K4", "M64N64K2"]
+TILES = ["M128N32", "M128N64", "M64N32K2", "M32N32K4", "M64N64K2", "M256N64"]
 
 
 def dev():
@@ -18,6 +18,17 @@ def dev():
 def rnd(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed + sum(shape))
     return torch.randn(*shape, generator=g) * scale
+
+
+def conv_or_skip(*args, **kw):
+    """conv_debug; a forced M256N64 on a shape the pipelined kernel cannot take (it has no synchronous twin) skips the case."""
+    from flocoder_amd._ops import conv_debug
+    try:
+        return conv_debug(*args, **kw)
+    except ValueError as e:
+        if kw.get("tile") == "M256N64" and "pipelined kernel only" in str(e):
+            pytest.skip(str(e))
+        raise
 
 
 def gn_ref(y, groups):
@@ -48,6 +59,8 @@ def test_conv_tiles(tile, shape):
     try:
         out, _ = conv_debug(x.to(dev()), w.to(dev()), b.to(dev()), pad=pad, tile=tile)
     except ValueError as e:            # a forced tile may not fit (1x1 images are all halo); "auto" below must
+        if tile == "M256N64" and "pipelined kernel only" in str(e):
+            pytest.skip(str(e))        # the 256-row tile has no synchronous-kernel twin to fall back to (5x5 halos, tiny images)
         assert "does not fit in LDS" in str(e) and H * W < 16
         pytest.skip(str(e))
     assert out.shape == ref.shape
@@ -64,7 +77,7 @@ def test_conv_concat_stats_act_add(tile):
     pre = F.conv2d(torch.cat([x0, x1], 1), w, b, padding=1)
     ref = F.silu(pre) + add
     for groups in (4, 1):
-        out, (mean, var) = conv_debug(x0.to(dev()), w.to(dev()), b.to(dev()), x1=x1.to(dev()), add=add.to(dev()), pad=1, out_act=True,
+        out, (mean, var) = conv_or_skip(x0.to(dev()), w.to(dev()), b.to(dev()), x1=x1.to(dev()), add=add.to(dev()), pad=1, out_act=True,
                                       groups_out=groups, tile=tile)
         assert rel_l2(out.cpu(), ref) < TOL
         rm, rv = gn_ref(pre, groups)
@@ -77,7 +90,7 @@ def test_conv_stats_small_spatial_multi_sample_tiles(tile):
     B, ci, co, H = 6, 128, 256, 4
     x, w, b = rnd(B, ci, H, H, seed=9), rnd(co, ci, 3, 3, seed=10, scale=0.03), rnd(co, seed=11)
     pre = F.conv2d(x, w, b, padding=1)
-    out, (mean, var) = conv_debug(x.to(dev()), w.to(dev()), b.to(dev()), pad=1, groups_out=4, tile=tile)
+    out, (mean, var) = conv_or_skip(x.to(dev()), w.to(dev()), b.to(dev()), pad=1, groups_out=4, tile=tile)
     assert rel_l2(out.cpu(), pre) < TOL
     rm, rv = gn_ref(pre, 4)
     assert rel_l2(mean.cpu(), rm) < 1e-4 and rel_l2(var.cpu(), rv) < 1e-5
@@ -92,7 +105,7 @@ def test_conv_stride2_is_space_to_depth(tile):
     xs = x.reshape(B, c, H // 2, 2, H // 2, 2).permute(0, 1, 3, 5, 2, 4).reshape(B, 4 * c, H // 2, H // 2)
     ref = F.conv2d(xs, w1, b)
     w2 = w1.reshape(co, c, 2, 2)            # [o][c][p1][p2]
-    out, _ = conv_debug(x.to(dev()), w2.to(dev()), b.to(dev()), pad=0, stride=2, tile=tile)
+    out, _ = conv_or_skip(x.to(dev()), w2.to(dev()), b.to(dev()), pad=0, stride=2, tile=tile)
     assert rel_l2(out.cpu(), ref) < TOL
 
 
@@ -102,7 +115,7 @@ def test_conv_nearest_upsample_folded(tile):
     B, ci, co, H = 2, 64, 32, 8
     x, w, b = rnd(B, ci, H, H, seed=15), rnd(co, ci, 3, 3, seed=16, scale=0.05), rnd(co, seed=17)
     ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1)
-    out, _ = conv_debug(x.to(dev()), w.to(dev()), b.to(dev()), pad=1, upsample=True, tile=tile)
+    out, _ = conv_or_skip(x.to(dev()), w.to(dev()), b.to(dev()), pad=1, upsample=True, tile=tile)
     assert rel_l2(out.cpu(), ref) < TOL
 
 
@@ -110,10 +123,10 @@ def test_conv_rejects_bad_shapes():
     from flocoder_amd._ops import conv_debug
     x, w = rnd(1, 8, 6, 6).to(dev()), rnd(8, 8, 3, 3).to(dev())
     with pytest.raises(ValueError, match="powers of two"):
-        conv_debug(x, w, pad=1)
+        conv_or_skip(x, w, pad=1)
     x, w = rnd(1, 6, 8, 8).to(dev()), rnd(8, 6, 3, 3).to(dev())
     with pytest.raises(ValueError, match="multiples of 4"):
-        conv_debug(x, w, pad=1)
+        conv_or_skip(x, w, pad=1)
 
 
 def test_ot_pairing_matches_oracle():

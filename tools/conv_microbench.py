@@ -34,6 +34,12 @@ LAYERS = [
     ("up 64>32 3x3 ups @16>32", 64, 0, 32, 16, 3, 1, 1, 1, 0),
     ("up 256>128 3x3 ups @4>8", 256, 0, 128, 4, 3, 1, 1, 1, 0),
 ]
+VAE_LAYERS = [  # SD-VAE decoder shapes (--vae, use --batch 16)
+    ("V 512>512 3x3 @64", 512, 0, 512, 64, 3, 1, 1, 0, 32),
+    ("V 256>256 3x3 @128", 256, 0, 256, 128, 3, 1, 1, 0, 32),
+    ("V 128>128 3x3 @256", 128, 0, 128, 256, 3, 1, 1, 0, 32),
+    ("V up 512>512 3x3 ups @64>128", 512, 0, 512, 64, 3, 1, 1, 1, 32),
+]
 TILES = ["auto", "M128N32", "M128N64", "M64N32K2", "M32N32K4", "M64N64K2"]
 
 
@@ -43,11 +49,12 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--tiles", default=",".join(TILES))
     ap.add_argument("--repeats", type=int, default=50)
+    ap.add_argument("--vae", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     tiles = args.tiles.split(",")
     print(f"{'layer':28s} " + " ".join(f"{t:>16s}" for t in tiles) + "   (us | TFLOP/s)")
-    for name, c0, c1, co, H, ks, pad, stride, ups, G in LAYERS:
+    for name, c0, c1, co, H, ks, pad, stride, ups, G in (VAE_LAYERS if args.vae else LAYERS):
         if args.only and args.only not in name:
             continue
         B = args.batch
