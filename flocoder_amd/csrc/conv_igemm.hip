@@ -388,12 +388,12 @@ static int auto_tile(const ConvArgs& a) {
     auto ok = [&](int t) { return !(a.w_batch_stride && hw < kTiles[t].BM) && M >= kTiles[t].BM; };
     // measured on the SD-VAE shapes (tools/conv_microbench.py --vae, B=16): M256N64 113 / 109 / 101 TFLOP/s at 512@64^2 / 256@128^2 /
     // 128@256^2 against 101 / 97 / 90 for M128N64 and 98 / 105 / 98 for M128N32; the 64-wide column tile only pays for 1x1 layers
-    if (a.Cout >= 64 && ok(TILE_M256N64) && blocks(TILE_M256N64) >= 1024 && !pipe_disabled()) {
+    if (a.Cout >= 64 && ok(TILE_M256N64) && blocks(TILE_M256N64) >= 512 && !pipe_disabled()) {
         ConvDev d;
         ConvGeom g;
         if (conv_geometry(a, TILE_M256N64, true, &d, &g) == FC_OK) return TILE_M256N64;   // else: patch / LDS limits, fall through
     }
-    if (a.KS == 1 && a.Cout >= 64 && ok(TILE_M128N64) && blocks(TILE_M128N64) >= 512) return TILE_M128N64;
+    if ((a.KS == 1 || a.Cout >= 512) && a.Cout >= 64 && ok(TILE_M128N64) && blocks(TILE_M128N64) >= 512) return TILE_M128N64;
     if (ok(TILE_M128N32) && blocks(TILE_M128N32) >= 256) return TILE_M128N32;   // one full wave of workgroups: measured 20 vs 29 us on the 64-channel 16x16 layers (profiles/r01_c_conv_microbench.txt)
     if (a.Cout >= 64 && ok(TILE_M64N64K2) && blocks(TILE_M64N64K2) >= 384) return TILE_M64N64K2;
     if (ok(TILE_M64N32K2) && blocks(TILE_M64N32K2) >= 256) return TILE_M64N32K2;
