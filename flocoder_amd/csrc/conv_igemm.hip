@@ -248,6 +248,7 @@ static const TileInfo kTilesPipe[TILE_COUNT] = {
     {256, 64, 16, 1, 4, 4},  // TILE_M256N64: 64 x 64 per wave (2 x 2 MFMA tiles): one LDS read per MFMA, weights reused by 256 rows
 };
 constexpr int kPipeNPL = 8;   // patch float4 elements a thread may own per stage
+static const int kPipeLoaderThreads[TILE_COUNT] = {256, 256, 512, 512, 256, 256};   // 64 x loader waves of each pipelined instantiation (1x1 kernels: 256 everywhere)
 
 static int align4(int v) { return (v + 3) & ~3; }
 
@@ -304,7 +305,7 @@ static int conv_geometry(const ConvArgs& a, int tile, bool pipe, ConvDev* d, Con
     g->pipe = pipe ? 1 : 0;
     if (pipe) {
         if (!conv_pipe_supports_ks(a.KS)) return fail(FC_E_SHAPE, "conv: kernel size not instantiated in the pipelined kernel");
-        if (p.P * (t.CC / 4) > 256 * kPipeNPL) return fail(FC_E_SHAPE, "conv: patch too large for the pipelined kernel");
+        if (p.P * (t.CC / 4) > (a.KS == 1 ? 256 : kPipeLoaderThreads[tile]) * kPipeNPL) return fail(FC_E_SHAPE, "conv: patch too large for the pipelined kernel");
         const int G0 = a.s0.xf.mode ? a.s0.xf.G : 0, G1 = a.s1.xf.mode ? a.s1.xf.G : 0;
         int o = 0;
         p.o_pixoff = p.o_pixtb = 0;

@@ -71,9 +71,13 @@ __device__ __forceinline__ void loader_handover() {   // LDS stores of this wave
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int WM, int WN, int WK, int MT, int NT, int CC, int NPL, int KS>
-__global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvDev p) {
-    constexpr int BN = 32 * NT * WN, CS = CC + 1, KSTEPS = CC / 2, KPW = KSTEPS / WK, Q = CC / 4, PIXSTEP = 256 / Q, KK = KS * KS;
+// NL = loader waves (4 or 8).  The small-M tiles stream a whole weight slab per 32 or 64 output rows: with four loader waves the
+// slab's LDS-DMA issue (~190 cycles per 1 KB piece per wave) took 1.65x the consumers' MFMA time per chunk and the consumers sat
+// at the chunk barrier half of the time (profiles/r01_c_stamps.txt); eight loader waves halve the issue time per wave.
+template <int WM, int WN, int WK, int MT, int NT, int CC, int NPL, int KS, int NL>
+__global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev p) {
+    constexpr int NTHR = 256 + 64 * NL, LT = 64 * NL;
+    constexpr int BN = 32 * NT * WN, CS = CC + 1, KSTEPS = CC / 2, KPW = KSTEPS / WK, Q = CC / 4, PIXSTEP = LT / Q, KK = KS * KS;
     static_assert(WM * WN * WK == 4, "4 consumer waves per workgroup");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const ConvArgs& a = p.a;
@@ -84,7 +88,8 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvDev p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6;
     const bool consumer = wave8 < 4;
-    const int wave = wave8 & 3, ltid = tid & 255;
+    const int wave = wave8 & 3;                                   // consumer wave 0..3 (meaningless in a loader wave)
+    const int lw = (wave8 - 4) & (NL - 1), ltid = (tid - 256) & (LT - 1);   // loader wave / loader thread (meaningless in a consumer wave)
     const int half = lane >> 5, l31 = lane & 31;
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
 
@@ -105,7 +110,7 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvDev p) {
     auto gn_tables = [&]() {
       if (p.any_xf) {
         const int G0 = a.s0.xf.mode ? a.s0.xf.G : 0, G1 = a.s1.xf.mode ? a.s1.xf.G : 0;
-        for (int i = tid; i < p.TB * (G0 + G1); i += 512) {
+        for (int i = tid; i < p.TB * (G0 + G1); i += NTHR) {
             const bool first = i < p.TB * G0;
             const SrcXform& xf = first ? a.s0.xf : a.s1.xf;
             const int j = first ? i : i - p.TB * G0;
@@ -124,7 +129,7 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvDev p) {
             gstat[2 * i + 1] = rstd;
         }
         __syncthreads();
-        for (int i = tid; i < p.TB * Cin; i += 512) {
+        for (int i = tid; i < p.TB * Cin; i += NTHR) {
             const int tb = i / Cin, c = i - tb * Cin, b = b0 + tb;
             float A = 1.f, Bv = 0.f;
             const bool first = c < C0;
@@ -176,18 +181,18 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvDev p) {
         }
         conv_stamp(p, 1);
         const int nwb = p.nwb;                    // weight stages in LDS: 3 = slabs run two chunks ahead, 2 = one ahead
-        // LDS-DMA plan of this wave: piece j = wave + 4m covers 256 floats of the slab = (256/BN) rows x BN columns.  A lane's
+        // LDS-DMA plan of this lw: piece j = lw + 4m covers 256 floats of the slab = (256/BN) rows x BN columns.  A lane's
         // source pointer at chunk 0 is fixed for the whole kernel and advances by CC*Cout floats per chunk, so issuing a slab
         // costs one 64-bit add + one scalar add per piece (the address arithmetic used to outweigh the transfer: the loaders,
         // not the MFMA waves, set the pace of the small-M layers -- profiles/r01_c_stamps.txt).
-        constexpr int MAXP = ((KK + 1) * CC * BN / 256 + 3) / 4;
+        constexpr int MAXP = ((KK + 1) * CC * BN / 256 + NL - 1) / NL;
         const int rows_main = KK * CC, npieces = (rows_main + (has_res ? CC : 0)) * BN / 256;
-        const int my_pieces = __builtin_amdgcn_readfirstlane(npieces > wave ? (npieces - wave + 3) / 4 : 0);
+        const int my_pieces = __builtin_amdgcn_readfirstlane(npieces > lw ? (npieces - lw + NL - 1) / NL : 0);
         const float* d_ptr[MAXP];   // nullptr: column beyond Cout -> zero block
         int d_row[MAXP];            // channel row inside the chunk (for the Cin tail test)
 #pragma unroll
         for (int m = 0; m < MAXP; ++m) {
-            const int j = wave + 4 * m, f = j * 256 + lane * 4, row = f / BN, n = n0 + (f % BN);
+            const int j = lw + NL * m, f = j * 256 + lane * 4, row = f / BN, n = n0 + (f % BN);
             const bool res = row >= rows_main;
             d_row[m] = res ? row - rows_main : row % CC;
             d_ptr[m] = n >= Cout ? nullptr : (res ? a.res_w + (size_t)d_row[m] * Cout + n : wbase + ((size_t)(row / CC) * Cin + d_row[m]) * Cout + n);
@@ -195,17 +200,17 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvDev p) {
         auto dma_weights = [&](int i) {
             const int c0 = i * CC;
             const size_t adv = (size_t)c0 * Cout;
-            float* wb = wl0 + (i % nwb) * p.wl_stride + wave * 256;
+            float* wb = wl0 + (i % nwb) * p.wl_stride + lw * 256;
             const bool tail = c0 + CC > Cin;            // only the last chunk can run past Cin
 #pragma unroll
             for (int m = 0; m < MAXP; ++m) {
                 if (m >= my_pieces) break;
                 const bool ok = d_ptr[m] != nullptr && (!tail || c0 + d_row[m] < Cin);
-                lds_dma16(ok ? d_ptr[m] + adv : p.zeros16, wb + m * 1024);
+                lds_dma16(ok ? d_ptr[m] + adv : p.zeros16, wb + m * (NL * 256));
             }
         };
         f32x4 pv[NPL];
-        const int nk = __builtin_amdgcn_readfirstlane((p.P * Q + 255) / 256);   // element slots in use (scalar: cheap loop exits)
+        const int nk = __builtin_amdgcn_readfirstlane((p.P * Q + LT - 1) / LT);   // element slots in use (scalar: cheap loop exits)
         auto issue_patch = [&](int i) {           // input window of chunk i -> registers, every load issued back to back
             const int c = i * CC + q4;
             const bool live = c < Cin, first = c < C0;
@@ -263,7 +268,7 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvDev p) {
             if (p.stamps) { dbg_mem += t1 - t0; dbg_store += t2 - t1; dbg_bar += __builtin_amdgcn_s_memtime() - t2; }
         }
         if (p.stamps && lane == 0) {
-            unsigned long long* d = p.stamps + ((size_t)blockIdx.x * 8 + wave8) * 16;
+            unsigned long long* d = p.stamps + ((size_t)blockIdx.x * 8 + (wave8 < 8 ? wave8 : 7)) * 16;
             d[9] = dbg_mem; d[10] = dbg_store; d[11] = dbg_bar; d[12] = dbg_issue; d[13] = dbg_dma;
         }
     } else {
@@ -327,25 +332,25 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvDev p) {
         if (p.stamps && lane == 0) p.stamps[((size_t)blockIdx.x * 8 + wave8) * 16 + 11] = dbg_cbar;
         conv_stamp(p, 5);
     }
-    conv_epilogue<WM, WN, WK, MT, NT>(p, acc, accr, smem, tid, lane, wave, b0, y0, x0, n0, tx, ty, consumer, 512);
+    conv_epilogue<WM, WN, WK, MT, NT>(p, acc, accr, smem, tid, lane, wave, b0, y0, x0, n0, tx, ty, consumer, NTHR);
 }
 
 // ---------------------------------------------------------------------------------------------------
 static float* g_zeros16 = nullptr;
 const float* conv_zeros16() { return g_zeros16; }
 
-#define FC_PIPE_TILES(X, KS)        \
-    X(TILE_M128N32, 4, 1, 1, 1, 1, 16, KS)  \
-    X(TILE_M128N64, 4, 1, 1, 1, 2, 16, KS)  \
-    X(TILE_M64N32K2, 2, 1, 2, 1, 1, 32, KS) \
-    X(TILE_M32N32K4, 1, 1, 4, 1, 1, 32, KS) \
-    X(TILE_M64N64K2, 2, 1, 2, 1, 2, 16, KS) \
-    X(TILE_M256N64, 4, 1, 1, 2, 2, 16, KS)
+#define FC_PIPE_TILES(X, KS)               \
+    X(TILE_M128N32, 4, 1, 1, 1, 1, 16, KS, 4)  \
+    X(TILE_M128N64, 4, 1, 1, 1, 2, 16, KS, 4)  \
+    X(TILE_M64N32K2, 2, 1, 2, 1, 1, 32, KS, (KS == 1 ? 4 : 8)) \
+    X(TILE_M32N32K4, 1, 1, 4, 1, 1, 32, KS, (KS == 1 ? 4 : 8)) \
+    X(TILE_M64N64K2, 2, 1, 2, 1, 2, 16, KS, 4) \
+    X(TILE_M256N64, 4, 1, 1, 2, 2, 16, KS, 4)
 
 template <int KS>
 static int pipe_attr_ks() {
-#define X(T, WM, WN, WK, MT, NT, CC, K)                                                                                   \
-    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pipe_kernel<WM, WN, WK, MT, NT, CC, 8, K>),            \
+#define X(T, WM, WN, WK, MT, NT, CC, K, NL)                                                                               \
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pipe_kernel<WM, WN, WK, MT, NT, CC, 8, K, NL>),        \
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     FC_PIPE_TILES(X, KS)
 #undef X
@@ -370,8 +375,8 @@ bool conv_pipe_supports_ks(int ks) { return ks == 1 || ks == 2 || ks == 3 || ks 
 template <int KS>
 static int pipe_launch_ks(const ConvDev& d, int tile, int grid, size_t lds, hipStream_t s) {
     switch (tile) {
-#define X(T, WM, WN, WK, MT, NT, CC, K) \
-    case T: hipLaunchKernelGGL((conv_pipe_kernel<WM, WN, WK, MT, NT, CC, 8, K>), dim3(grid), dim3(512), lds, s, d); break;
+#define X(T, WM, WN, WK, MT, NT, CC, K, NL) \
+    case T: hipLaunchKernelGGL((conv_pipe_kernel<WM, WN, WK, MT, NT, CC, 8, K, NL>), dim3(grid), dim3(256 + 64 * NL), lds, s, d); break;
         FC_PIPE_TILES(X, KS)
 #undef X
         default: return fail(FC_E_ARG, "conv: bad tile id");
