@@ -625,6 +625,69 @@ int add_into_launch(float* dst, const float* src, size_t n, hipStream_t s) {
     FC_HIP(hipGetLastError());
     return FC_OK;
 }
+// y = SiLU(z) (+ add);  dz = dy * SiLU'(z)      (the mask-conditioning convolutions keep their pre-activations when training)
+__global__ void __launch_bounds__(256) silu_fwd_kernel(const float* z, const float* add, float* y, size_t n4) {
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 v = reinterpret_cast<const float4*>(z)[i];
+        v.x = silu_e(v.x); v.y = silu_e(v.y); v.z = silu_e(v.z); v.w = silu_e(v.w);
+        if (add) { const float4 a = reinterpret_cast<const float4*>(add)[i]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+        reinterpret_cast<float4*>(y)[i] = v;
+    }
+}
+int silu_fwd_launch(const float* z, const float* add, float* y, size_t n, hipStream_t s) {
+    if (n & 3) return fail(FC_E_SHAPE, "silu_fwd: length must be a multiple of 4");
+    hipLaunchKernelGGL(silu_fwd_kernel, dim3(grid_1d(n / 4)), dim3(256), 0, s, z, add, y, n / 4);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+__global__ void __launch_bounds__(256) silu_bwd_kernel(const float* dy, const float* z, float* dz, size_t n4) {
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 g = reinterpret_cast<const float4*>(dy)[i], v = reinterpret_cast<const float4*>(z)[i];
+        reinterpret_cast<float4*>(dz)[i] = make_float4(g.x * silu_grad_e(v.x), g.y * silu_grad_e(v.y), g.z * silu_grad_e(v.z), g.w * silu_grad_e(v.w));
+    }
+}
+int silu_bwd_launch(const float* dy, const float* z, float* dz, size_t n, hipStream_t s) {
+    if (n & 3) return fail(FC_E_SHAPE, "silu_bwd: length must be a multiple of 4");
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3(grid_1d(n / 4)), dim3(256), 0, s, dy, z, dz, n / 4);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+// Adjoint of F.interpolate(mode='bilinear', align_corners=False) on NHWC: gsrc[b][Y][X][c] += sum over destination pixels of
+// weight(dst -> src) * gdst.  One thread per source element walking every destination pixel (tiny tensors; fixed order).
+__global__ void __launch_bounds__(256) bilinear_bwd_kernel(const float* gdst, float* gsrc, int B, int C, int Hs, int Ws, int Hd, int Wd) {
+    const size_t total = (size_t)B * Hs * Ws * C;
+    const float sy = (float)Hs / (float)Hd, sx = (float)Ws / (float)Wd;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int X = (int)(r % Ws); r /= Ws;
+        const int Y = (int)(r % Hs), b = (int)(r / Hs);
+        float acc = 0.f;
+        for (int y = 0; y < Hd; ++y) {
+            float fy = ((float)y + 0.5f) * sy - 0.5f;
+            fy = fy < 0.f ? 0.f : fy;
+            const int y0 = (int)fy, y1 = y0 + (y0 < Hs - 1 ? 1 : 0);
+            const float ly = fy - (float)y0;
+            const float wy = (y0 == Y ? 1.f - ly : 0.f) + (y1 == Y ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int x = 0; x < Wd; ++x) {
+                float fx = ((float)x + 0.5f) * sx - 0.5f;
+                fx = fx < 0.f ? 0.f : fx;
+                const int x0 = (int)fx, x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+                const float lx = fx - (float)x0;
+                const float wx = (x0 == X ? 1.f - lx : 0.f) + (x1 == X ? lx : 0.f);
+                if (wx != 0.f) acc += wy * wx * gdst[(((size_t)b * Hd + y) * Wd + x) * C + c];
+            }
+        }
+        gsrc[i] += acc;
+    }
+}
+int bilinear_bwd_launch(const float* gdst, float* gsrc, int B, int C, int Hs, int Ws, int Hd, int Wd, hipStream_t s) {
+    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_1d((size_t)B * Hs * Ws * C)), dim3(256), 0, s, gdst, gsrc, B, C, Hs, Ws, Hd, Wd);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
 // nearest x2 backward: dst[b][y][x][c] (+)= sum of the 2x2 block of src [B][2H][2W][C]
 __global__ void __launch_bounds__(256) sumpool2_kernel(const float* src, float* dst, int B, int H, int W, int C, int accumulate) {
     const size_t total = (size_t)B * H * W * C;

@@ -269,6 +269,9 @@ int sin_emb_launch(const float* time, const float* freqs, float* e, int B, int d
 int gather_rows_launch(const float* table, const int64_t* ids, float* out, int B, int D, hipStream_t s);
 int scatter_rows_launch(const float* d, const int64_t* ids, float* dtable, int B, int D, int R, hipStream_t s);
 int add_into_launch(float* dst, const float* src, size_t n, hipStream_t s);
+int silu_fwd_launch(const float* z, const float* add, float* y, size_t n, hipStream_t s);
+int silu_bwd_launch(const float* dy, const float* z, float* dz, size_t n, hipStream_t s);
+int bilinear_bwd_launch(const float* gdst, float* gsrc /* += */, int B, int C, int Hs, int Ws, int Hd, int Wd, hipStream_t s);
 int sumpool2_nhwc_launch(const float* src, float* dst, int B, int H, int W, int C, int accumulate, hipStream_t s);
 int depth_to_space_launch(const float* src, float* dst, int B, int H, int W, int C, int accumulate, hipStream_t s);
 int flow_interp_launch(const float* src, const float* tgt, const float* t, float* x, float* v, int B, int per, hipStream_t s);

@@ -33,6 +33,8 @@ struct FwdCtx {             // per-call inputs of one forward
     int B = 0;
     const float* d_out = nullptr;      // backward only: NCHW gradient of `out`
     float* grads = nullptr;            // backward only: flat parameter gradients, table layout
+    float* dx_out = nullptr;           // backward only, optional: NCHW gradient of the input x
+    float* dmask_out = nullptr;        // backward only, optional: NCHW gradient of the mask
 };
 using Op = std::function<int(const FwdCtx&, hipStream_t)>;
 
@@ -41,7 +43,9 @@ struct ResRec { std::string p; Act x, skip, h1, h2, rb, out; Stat st1, st2; int 
 struct LinRec { std::string p; Act x, qkv, lao, yb, out; float* ctx = nullptr; Stat gn1, sty; };
 struct MidRec { Act x, qkv, ao, out; Stat gn1; };
 struct ConvRec { std::string name; Act x, out; int KS = 1, pad = 0, stride = 1, ups = 0; };
-struct TapeItem { int kind, idx; };   // 0 ResRec, 1 LinRec, 2 MidRec, 3 ConvRec -- in forward order
+struct InjRec { std::string name; Act x, mr, z, out; };                      // x + SiLU(conv3x3(cat[x, bilinear(mask)])), unet.py:336-340
+struct FuseRec { bool present = false; Act xi, mask, z1, f1, z2, f2, x0; };  // mask_fusion_conv, unet.py:298-305
+struct TapeItem { int kind, idx; };   // 0 ResRec, 1 LinRec, 2 MidRec, 3 ConvRec, 4 InjRec -- in forward order
 
 struct Plan {                 // one launch plan + activation arena for up to maxB rows
     int maxB = 0, H = 0, W = 0;
@@ -52,7 +56,8 @@ struct Plan {                 // one launch plan + activation arena for up to ma
     double flops = 0.0;
     float *t_emb = nullptr, *ss = nullptr;
     std::map<std::string, Act> named;              // debug taps: block outputs by reference module name
-    std::vector<ResRec> res; std::vector<LinRec> lin; std::vector<MidRec> mid; std::vector<ConvRec> convs;
+    std::vector<ResRec> res; std::vector<LinRec> lin; std::vector<MidRec> mid; std::vector<ConvRec> convs; std::vector<InjRec> inj;
+    FuseRec fuse;
     std::vector<TapeItem> tape;
     Act x0, head;                                   // init_conv output, final_res_block output
     std::vector<int*> fin_err;                      // device flags of the fused Block tails (a timed-out wait sets one)
@@ -171,7 +176,17 @@ struct PlanBuilder {
     int err = FC_OK;
     std::string scope;  // reference module the ops being emitted belong to
 
+    // guard: 0 always | 1 only when the call has a mask | 2 only when it runs mask_fusion_conv | 3 only when it has NO mask | 4 mask but no fusion
+    int guard = 0;
     void push(Op op, const std::string& kernel, double flops = 0.0) {
+        if (guard) {
+            const int g = guard;
+            Op inner = std::move(op);
+            op = [inner, g](const FwdCtx& c, hipStream_t s) -> int {
+                const bool on = g == 1 ? c.mask != nullptr : g == 2 ? c.mask_fuse != 0 : g == 3 ? c.mask == nullptr : (c.mask != nullptr && !c.mask_fuse);
+                return on ? inner(c, s) : FC_OK;
+            };
+        }
         pl->ops.push_back(std::move(op));
         pl->op_kernel.push_back(kernel);
         pl->op_what.push_back(scope);

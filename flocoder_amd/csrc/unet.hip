@@ -269,22 +269,30 @@ struct Builder : PlanBuilder {
         Act mr = act(mask_nhwc.C, x.H, x.W), out = act(x.C, x.H, x.W);
         const float* mp = mask_nhwc.p; float* rp = mr.p;
         const int C = mask_nhwc.C, Hs = mask_nhwc.H, Ws = mask_nhwc.W, Hd = x.H, Wd = x.W;
+        const bool keep = u->keep_all;             // training: the pre-activation z stays (SiLU' needs it), SiLU + residual as a pass of its own
+        Act z = keep ? act(x.C, x.H, x.W) : Act();
         ConvArgs a;
         a.s0.p = x.p; a.s0.C = x.C; a.s1.p = mr.p; a.s1.C = C;
-        a.Hs = x.H; a.Ws = x.W; a.KS = 3; a.pad = 1; a.out_act = 1; a.add = x.p;
+        a.Hs = x.H; a.Ws = x.W; a.KS = 3; a.pad = 1;
+        if (!keep) { a.out_act = 1; a.add = x.p; }
         a.w = u->P(name + ".weight"); a.bias = u->R(name + ".bias");
-        a.B = B; a.H = x.H; a.W = x.W; a.Cout = x.C; a.out = out.p; a.Cin = x.C + C;
+        a.B = B; a.H = x.H; a.W = x.W; a.Cout = x.C; a.out = keep ? z.p : out.p; a.Cin = x.C + C;
         ConvGeom g;
         if ((err = conv_plan(a, TILE_AUTO, &g)) != FC_OK) return out;
         const int tile = g.tile;
-        const size_t bytes_per = (size_t)x.H * x.W * x.C * sizeof(float);
-        const float* xp = x.p; float* op = out.p;
+        const size_t per = (size_t)x.H * x.W * x.C;
+        const float* xp = x.p; float* op = out.p; const float* zp = z.p;
         push([=](const FwdCtx& c, hipStream_t s) -> int {
-            if (!c.mask) { FC_HIP(hipMemcpyAsync(op, xp, bytes_per * c.B, hipMemcpyDeviceToDevice, s)); return FC_OK; }
+            if (!c.mask) { FC_HIP(hipMemcpyAsync(op, xp, per * sizeof(float) * c.B, hipMemcpyDeviceToDevice, s)); return FC_OK; }
             FC_TRY(bilinear_nhwc_launch(mp, rp, c.B, C, Hs, Ws, Hd, Wd, s));
             ConvArgs b = a; b.B = c.B;
-            return conv_launch(b, tile, s);
+            FC_TRY(conv_launch(b, tile, s));
+            return keep ? silu_fwd_launch(zp, xp, op, per * c.B, s) : FC_OK;
         }, std::string("bilinear+") + kTileNames[tile], 2.0 * x.H * x.W * 9 * (double)a.Cin * a.Cout);
+        InjRec rec;
+        rec.name = name.substr(0, name.size() - 0); rec.x = x; rec.mr = mr; rec.z = z; rec.out = out;
+        pl->tape.push_back({4, (int)pl->inj.size()});
+        pl->inj.push_back(rec);
         return out;
     }
 };
@@ -351,6 +359,8 @@ static int build_plan(fc_unet* u, Plan* pl, int maxB, int H, int W) {
             b.push([=](const FwdCtx& cx, hipStream_t s) { return init_conv_launch(cx.x, cx.x_mod, w, bias, x0p, cx.B, ch, HW, dim, s); }, "init_conv", 2.0 * HW * ch * dim);
         } else {
             Act xi = b.act(dim, H, W), f1 = b.act(2 * dim, H, W), f2 = b.act(2 * dim, H, W);
+            const bool keep = u->keep_all;         // training keeps the pre-activations z1, z2 of the two SiLU layers
+            Act z1 = keep ? b.act(2 * dim, H, W) : Act(), z2 = keep ? b.act(2 * dim, H, W) : Act();
             mask_nhwc = b.act(ch, H, W);
             float *xip = xi.p, *mp = mask_nhwc.p;
             b.push([=](const FwdCtx& cx, hipStream_t s) -> int {
@@ -360,12 +370,12 @@ static int build_plan(fc_unet* u, Plan* pl, int maxB, int H, int W) {
             ConvArgs a[3];
             const char* names[3] = {"mask_fusion_conv.0", "mask_fusion_conv.2", "mask_fusion_conv.4"};
             const Act* srcs[3] = {&xi, &f1, &f2};
-            const Act* dsts[3] = {&f1, &f2, &x0};
+            const Act* dsts[3] = {keep ? &z1 : &f1, keep ? &z2 : &f2, &x0};
             int tiles[3];
             for (int i = 0; i < 3 && !b.err; ++i) {
                 a[i].s0.p = srcs[i]->p; a[i].s0.C = srcs[i]->C;
                 if (i == 0) { a[i].s1.p = mask_nhwc.p; a[i].s1.C = ch; }
-                a[i].Hs = H; a[i].Ws = W; a[i].KS = i == 0 ? 5 : 3; a[i].pad = i == 0 ? 2 : 1; a[i].out_act = i < 2;
+                a[i].Hs = H; a[i].Ws = W; a[i].KS = i == 0 ? 5 : 3; a[i].pad = i == 0 ? 2 : 1; a[i].out_act = (i < 2 && !keep);
                 a[i].w = u->P(std::string(names[i]) + ".weight"); a[i].bias = u->R(std::string(names[i]) + ".bias");
                 a[i].B = maxB; a[i].H = H; a[i].W = W; a[i].Cout = dsts[i]->C; a[i].out = dsts[i]->p; a[i].Cin = a[i].s0.C + a[i].s1.C;
                 ConvGeom g;
@@ -375,13 +385,20 @@ static int build_plan(fc_unet* u, Plan* pl, int maxB, int H, int W) {
             if (b.err) return b.err;
             const ConvArgs a0 = a[0], a1 = a[1], a2 = a[2];
             const int t0 = tiles[0], t1 = tiles[1], t2 = tiles[2];
+            const float *z1p = z1.p, *z2p = z2.p;
+            float *f1p = f1.p, *f2p = f2.p;
+            const size_t nf = (size_t)HW * 2 * dim;
             b.scope = "mask_fusion_conv";
             b.push([=](const FwdCtx& cx, hipStream_t s) -> int {
                 if (!cx.mask_fuse) return FC_OK;
                 ConvArgs q = a0; q.B = cx.B; FC_TRY(conv_launch(q, t0, s));
+                if (keep) FC_TRY(silu_fwd_launch(z1p, nullptr, f1p, nf * cx.B, s));
                 q = a1; q.B = cx.B; FC_TRY(conv_launch(q, t1, s));
+                if (keep) FC_TRY(silu_fwd_launch(z2p, nullptr, f2p, nf * cx.B, s));
                 q = a2; q.B = cx.B; return conv_launch(q, t2, s);
             }, "mask_fusion(3 x conv_igemm)", 2.0 * HW * (25.0 * (dim + ch) * 2 * dim + 9.0 * 2 * dim * 2 * dim + 9.0 * 2 * dim * dim));
+            pl->fuse.present = true;
+            pl->fuse.xi = xi; pl->fuse.mask = mask_nhwc; pl->fuse.z1 = z1; pl->fuse.f1 = f1; pl->fuse.z2 = z2; pl->fuse.f2 = f2; pl->fuse.x0 = x0;
         }
     }
 

@@ -223,6 +223,72 @@ struct BwdBuilder : PlanBuilder {
             dgrad(r.name + ".weight", r.out.C, r.x.C, r.KS, r.pad, g_out, 0, r.x);
         }
     }
+
+    // ---- mask conditioning (unet.py:298-305,336-340,360-364).  The forward decides per call whether these branches run (a mask
+    // given / not all ones); the backward's launches carry the same guards, and both variants leave d(x) written.
+    Act gmask;                 // d(mask) NHWC, zeroed at the start of every backward and accumulated into
+
+    void silu_bwd(const Act& dy, const Act& z, const Act& dz) {
+        const float *dp = dy.p, *zp = z.p; float* op = dz.p;
+        const size_t per = (size_t)z.H * z.W * z.C;
+        push([=](const FwdCtx& c, hipStream_t s) { return silu_bwd_launch(dp, zp, op, per * c.B, s); }, "silu_bwd");
+    }
+
+    void inject(const InjRec& r) {
+        scope = r.name;
+        const Act g_out = grad_of(r.out);
+        if (err) return;
+        const bool x_written = slot(r.x).written;
+        const int C = r.x.C, H = r.x.H, W = r.x.W;
+        // -- a mask was given: out = x + SiLU(z), z = conv3x3(cat[x, bilinear(mask)]) --
+        guard = 1;
+        Act dz = act(C, H, W);
+        silu_bwd(g_out, r.z, dz);
+        wgrad(r.name + ".weight", r.name + ".bias", r.x, &r.mr, dz, 3, 1, 1, 0);
+        dgrad(r.name + ".weight", C, C + r.mr.C, 3, 1, dz, 0, r.x);
+        Act gmr = act(r.mr.C, H, W);
+        dgrad_to(r.name + ".weight", C, C + r.mr.C, 3, 1, dz, C, gmr, nullptr);
+        accumulate(r.x, g_out);
+        {
+            const float* gp = gmr.p; float* mp = gmask.p;
+            const int mc = r.mr.C, Hs = gmask.H, Ws = gmask.W;
+            push([=](const FwdCtx& c, hipStream_t s) { return bilinear_bwd_launch(gp, mp, c.B, mc, Hs, Ws, H, W, s); }, "bilinear_bwd");
+        }
+        release(dz); release(gmr);
+        // -- no mask: out = x --
+        guard = 3;
+        slot(r.x).written = x_written;
+        accumulate(r.x, g_out);
+        guard = 0;
+    }
+
+    // returns the tensor holding d(init_conv output) per variant: with fusion d(xi), without d(x0)
+    void fusion(const FuseRec& f) {
+        scope = "mask_fusion_conv";
+        const Act g_x0 = grad_of(f.x0);
+        if (err) return;
+        const int dim = f.xi.C, ch = f.mask.C, H = f.xi.H, W = f.xi.W;
+        guard = 2;
+        Act df2 = act(2 * dim, H, W), dz2 = act(2 * dim, H, W), df1 = act(2 * dim, H, W), dz1 = act(2 * dim, H, W), gm = act(ch, H, W);
+        wgrad("mask_fusion_conv.4.weight", "mask_fusion_conv.4.bias", f.f2, nullptr, g_x0, 3, 1, 1, 0);
+        dgrad_to("mask_fusion_conv.4.weight", dim, 2 * dim, 3, 1, g_x0, 0, df2, nullptr);
+        silu_bwd(df2, f.z2, dz2);
+        wgrad("mask_fusion_conv.2.weight", "mask_fusion_conv.2.bias", f.f1, nullptr, dz2, 3, 1, 1, 0);
+        dgrad_to("mask_fusion_conv.2.weight", 2 * dim, 2 * dim, 3, 1, dz2, 0, df1, nullptr);
+        silu_bwd(df1, f.z1, dz1);
+        wgrad("mask_fusion_conv.0.weight", "mask_fusion_conv.0.bias", f.xi, &f.mask, dz1, 5, 2, 1, 0);
+        Slot& sx = slot(f.xi);
+        dgrad_to("mask_fusion_conv.0.weight", 2 * dim, dim + ch, 5, 2, dz1, 0, sx.g, nullptr);
+        sx.written = true;
+        dgrad_to("mask_fusion_conv.0.weight", 2 * dim, dim + ch, 5, 2, dz1, dim, gm, nullptr);
+        {
+            const float* gp = gm.p; float* mp = gmask.p;
+            const size_t per = (size_t)H * W * ch;
+            push([=](const FwdCtx& c, hipStream_t s) { return add_into_launch(mp, gp, per * c.B, s); }, "add_into");
+        }
+        release(df2); release(dz2); release(df1); release(dz1); release(gm);
+        guard = 0;
+    }
 };
 
 static size_t max_wgrad_ws(const fc_unet* u, const Plan& fw, int B) {
@@ -254,7 +320,6 @@ int build_backward(fc_unet* u) {
     u->dgrad_packs.clear();
     u->dgrad_table.release();
     u->dgrad_version = ~0ull;
-    if (c.mask_cond) return fail(FC_E_STATE, "unet: the backward pass of the mask-conditioning branches is not built");
     if (u->nchains != 1) return fail(FC_E_STATE, "unet: training needs a single-chain plan (unset FLOCODER_AMD_CHAINS)");
     FC_TRY(conv_wgrad_init());
     const int B = fw.maxB, H = fw.H, W = fw.W, HW = H * W, dim = c.dim, ch = c.channels, td = u->td, S = u->S, ncls = c.n_classes;
@@ -278,6 +343,14 @@ int build_backward(fc_unet* u) {
         u->class_hi = last.offset + ((last.numel + 3) & ~3ll);
     }
 
+    if (c.mask_cond) {
+        if (!fw.fuse.present) return fail(FC_E_STATE, "unet: mask-conditioned plan without a fusion record");
+        b.gmask = b.act(ch, H, W);
+        float* gp = b.gmask.p;
+        const size_t per = (size_t)HW * ch;
+        b.scope = "mask";
+        b.push([=](const FwdCtx& cx, hipStream_t s) -> int { FC_HIP(hipMemsetAsync(gp, 0, per * cx.B * sizeof(float), s)); return FC_OK; }, "memset");
+    }
     // -- head: d(out) NCHW -> NHWC, final_conv (unet.py:372) --
     b.scope = "final_conv";
     Act dv = b.act(ch, H, W);
@@ -293,17 +366,58 @@ int build_backward(fc_unet* u) {
         if (t.kind == 0) b.resblock(fw.res[t.idx]);
         else if (t.kind == 1) b.linattn(fw.lin[t.idx]);
         else if (t.kind == 2) b.midattn(fw.mid[t.idx]);
-        else b.resample(fw.convs[t.idx]);
+        else if (t.kind == 3) b.resample(fw.convs[t.idx]);
+        else b.inject(fw.inj[t.idx]);
     }
     if (b.err) return b.err;
-    // -- init_conv (unet.py:295): only its parameters need a gradient --
+    // -- mask_fusion_conv (unet.py:298-305), then init_conv (unet.py:295); d(x) and d(mask) leave through the boundary when asked for --
+    if (c.mask_cond) b.fusion(fw.fuse);
+    if (b.err) return b.err;
     {
         b.scope = "init_conv";
         Act xin = b.act(ch, H, W);
         float* xp = xin.p;
         b.push([=](const FwdCtx& cx, hipStream_t s) { return nchw_to_nhwc_launch(cx.x, xp, cx.B, ch, HW, ch, cx.B, s); }, "nchw_to_nhwc");
         const Act g0 = b.grad_of(fw.x0);
-        b.wgrad("init_conv.weight", "init_conv.bias", xin, nullptr, g0, 1, 0, 1, 0);
+        if (b.err) return b.err;
+        const float* gx0 = g0.p;
+        const float* gxi = c.mask_cond ? b.slot(fw.fuse.xi).g.p : g0.p;
+        // the gradient of init_conv's output lives in d(xi) when the fusion ran, in d(x0) otherwise: two guarded variants
+        WgradArgs a;
+        a.x0 = xin.p; a.C0 = ch; a.H = H; a.W = W; a.Hs = H; a.Ws = W; a.Cin = ch; a.Cout = dim; a.KS = 1; a.B = B;
+        a.ws = b.ws; a.ws_floats = b.ws_floats;
+        const int64_t wo = b.off("init_conv.weight"), bo = b.off("init_conv.bias");
+        b.push([=](const FwdCtx& cx, hipStream_t s) {
+            WgradArgs q = a;
+            q.B = cx.B; q.dy = cx.mask_fuse ? gxi : gx0; q.dw = cx.grads + wo; q.db = cx.grads + bo;
+            return conv_wgrad_launch(q, s);
+        }, "conv_wgrad", 2.0 * HW * (double)ch * dim);
+        // d(x) = init_conv^T d(.) as an NHWC tensor, converted to the NCHW boundary layout on request (fc_unet_backward_ex)
+        Act dxn = b.act(ch, H, W);
+        float* wp = b.dmalloc((size_t)dim * ch);
+        u->dgrad_packs.push_back({b.off("init_conv.weight"), wp, dim, ch, 1, 0, ch});
+        ConvArgs q;
+        q.s0.C = dim; q.Hs = H; q.Ws = W; q.KS = 1; q.w = wp;
+        q.B = B; q.H = H; q.W = W; q.Cout = ch; q.out = dxn.p; q.Cin = dim;
+        q.s0.p = gx0;
+        ConvGeom g;
+        if ((b.err = conv_plan(q, TILE_AUTO, &g)) != FC_OK) return b.err;
+        const int tile = g.tile;
+        const float* dxp = dxn.p;
+        b.push([=](const FwdCtx& cx, hipStream_t s) -> int {
+            if (!cx.dx_out) return FC_OK;
+            ConvArgs k = q;
+            k.B = cx.B; k.s0.p = cx.mask_fuse ? gxi : gx0;
+            FC_TRY(conv_launch(k, tile, s));
+            return nhwc_to_nchw_launch(dxp, cx.dx_out, cx.B, ch, HW, ch, s);
+        }, "dgrad(init_conv)");
+        if (c.mask_cond) {
+            const float* gm = b.gmask.p;
+            b.push([=](const FwdCtx& cx, hipStream_t s) -> int {
+                if (!cx.dmask_out) return FC_OK;
+                return nhwc_to_nchw_launch(gm, cx.dmask_out, cx.B, ch, HW, ch, s);
+            }, "nhwc_to_nchw");
+        }
     }
     if (b.err) return b.err;
     // -- parameter gradients of every norm layer and the FiLM gradients, one launch --
@@ -409,8 +523,8 @@ int fc_unet_train_reserve(fc_unet* u, int max_batch, int height, int width) {
     return r;
 }
 
-int fc_unet_backward(fc_unet* u, const float* x, const float* time, const int64_t* ids, const float* d_out, float* grads, int64_t numel,
-                     int B, int H, int W, void* stream) {
+int fc_unet_backward_ex(fc_unet* u, const float* x, const float* time, const int64_t* ids, const float* mask, int mask_is_ones,
+                        const float* d_out, float* grads, int64_t numel, float* dx_out, float* dmask_out, int B, int H, int W, void* stream) {
     if (!u || !x || !time || !d_out || !grads || B < 1) return fail(FC_E_ARG, "fc_unet_backward: null argument");
     if (u->bwd.maxB < B || u->bwd.H != H || u->bwd.W != W || u->plan[0].maxB < B) return fail(FC_E_STATE, "unet: no backward plan for this shape; call fc_unet_train_reserve");
     if (numel != u->raw_numel) return fail(FC_E_ARG, "fc_unet_backward: gradient vector must have " + std::to_string(u->raw_numel) + " floats (padded table layout)");
@@ -424,8 +538,15 @@ int fc_unet_backward(fc_unet* u, const float* x, const float* time, const int64_
     FC_HIP(hipMemsetAsync(grads, 0, (size_t)numel * sizeof(float), s));
     FwdCtx c;
     c.x = x; c.x_mod = B; c.time = time; c.ids = u->cfg.n_classes > 0 ? ids : nullptr; c.ids_mod = B; c.B = B;
-    c.d_out = d_out; c.grads = grads;
+    c.mask = u->cfg.mask_cond ? mask : nullptr;
+    c.mask_fuse = (c.mask && !mask_is_ones) ? 1 : 0;
+    c.d_out = d_out; c.grads = grads; c.dx_out = dx_out; c.dmask_out = c.mask ? dmask_out : nullptr;
     return run_plan(u->bwd, c, s);
+}
+
+int fc_unet_backward(fc_unet* u, const float* x, const float* time, const int64_t* ids, const float* d_out, float* grads, int64_t numel,
+                     int B, int H, int W, void* stream) {
+    return fc_unet_backward_ex(u, x, time, ids, nullptr, 0, d_out, grads, numel, nullptr, nullptr, B, H, W, stream);
 }
 
 int fc_unet_class_param_range(const fc_unet* u, int64_t* lo, int64_t* hi) {

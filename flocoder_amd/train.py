@@ -101,8 +101,6 @@ class FlowTrainer:
         device = torch.device(device) if device is not None else next(model.parameters()).device
         if device.type != "cuda":
             raise RuntimeError("flocoder_amd.FlowTrainer runs on MI355X (gfx950) only; there is no CPU path")
-        if model._cfg.mask_cond:
-            raise NotImplementedError("FlowTrainer: the backward pass of the mask-conditioning branches is not built")
         self.model, self.device = model, device
         self.lr, self.betas, self.eps, self.max_norm, self.ema_decay = lr, betas, eps, max_norm, ema_decay
         self.t_eps, self.t_scale = t_eps, t_scale
@@ -112,8 +110,12 @@ class FlowTrainer:
         model.to(device)
         model.adopt_flat(self.params)
         self.ema = self.params.clone()
-        self._lo, self._hi = model.class_param_range()
-        self.step_main, self.step_class = 0, 0
+        # parameter groups that can go without a gradient in a step (torch's optimiser skips p.grad is None, step count included):
+        # class embedding path (cond=None), mask_fusion_conv (no mask, or a mask that is all ones: unet.py:301), the per-scale injections
+        self._groups = {"class": model.param_range("class_cond_mlp."), "fusion": model.param_range("mask_fusion_conv."),
+                        "inject": model.param_range("down_mask_fusions.", "up_mask_fusions.")}
+        self._lo, self._hi = self._groups["class"]
+        self.step_main, self.steps = 0, {k: 0 for k in self._groups}
         self._scal = torch.zeros(4, dtype=torch.float32, device=device)      # loss | grad norm | clip coefficient
         self._ws = torch.zeros(256, dtype=torch.float32, device=device)
         self.pg = process_group
@@ -129,39 +131,47 @@ class FlowTrainer:
                                        B.current_stream(self.device)))
         return x, v
 
-    def loss_and_grads(self, x, t, cls, v_target):
+    def loss_and_grads(self, x, t, cls, v_target, mask=None):
         """forward -> loss -> backward; leaves the gradients in ``self.grads`` and returns (loss 0-d tensor, v_model)."""
         m, lib, st = self.model, B.lib(), B.current_stream(self.device)
         time = (t * self.t_scale).contiguous()
-        v = m._forward_native(x, time, cls, None, train=True)
+        v = m._forward_native(x, time, cls, mask, train=True)
         dv = torch.empty_like(v)
         B.check(lib.fc_mse_loss_grad(B.ptr(v), B.ptr(v_target), B.ptr(dv), self._scal.data_ptr(), self._ws.data_ptr(), v.numel(), st))
-        m.backward_native(x, time, cls, dv, self.grads)
+        m.backward_native(x, time, cls, dv, self.grads, mask=mask)
         return self._scal[0], v
 
-    def optimizer_step(self, has_class_grads: bool):
-        """clip_grad_norm_ -> Adam -> EMA (train_flow.py:392-397).  Parameters without a gradient (class_cond_mlp.* in a step
-        without conditioning) are skipped by Adam, step count included, exactly as torch.optim skips ``p.grad is None``."""
+    @property
+    def step_class(self):
+        return self.steps["class"]
+
+    def optimizer_step(self, has_class_grads: bool, has_mask_grads: bool = False, has_fusion_grads: Optional[bool] = None):
+        """clip_grad_norm_ -> Adam -> EMA (train_flow.py:392-397).  Parameters without a gradient in this step (class_cond_mlp.*
+        without conditioning, the mask branches without a mask, mask_fusion_conv with an all-ones mask) are skipped by Adam, step
+        count included, exactly as torch.optim skips ``p.grad is None``; the EMA still averages them."""
         lib, st = B.lib(), B.current_stream(self.device)
-        n, lo, hi = self.params.numel(), self._lo, self._hi
+        n = self.params.numel()
         P, G, M, V, E = (t.data_ptr() for t in (self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.ema))
         coef = self._scal.data_ptr() + 8
         B.check(lib.fc_grad_clip_coef(G, n, None, 0, self.max_norm, self._scal.data_ptr() + 4, self._ws.data_ptr(), st))
         b1, b2 = self.betas
         self.step_main += 1
+        present = {"class": has_class_grads, "inject": has_mask_grads,
+                   "fusion": has_mask_grads if has_fusion_grads is None else has_fusion_grads}
 
         def run(a, b, step, adam):
             if b > a:
                 B.check(lib.fc_adam_ema_step(P + 4 * a, G + 4 * a, M + 4 * a, V + 4 * a, E + 4 * a, b - a, coef, self.lr, b1, b2, self.eps,
                                              max(step, 1), self.ema_decay, int(adam), st))
-        if hi > lo:
-            if has_class_grads:
-                self.step_class += 1
-            run(0, lo, self.step_main, True)
-            run(lo, hi, self.step_class, has_class_grads)
-            run(hi, n, self.step_main, True)
-        else:
-            run(0, n, self.step_main, True)
+        cuts = sorted((lo, hi, k) for k, (lo, hi) in self._groups.items() if hi > lo)
+        pos = 0
+        for lo, hi, k in cuts:
+            run(pos, lo, self.step_main, True)
+            if present[k]:
+                self.steps[k] += 1
+            run(lo, hi, self.steps[k], present[k])
+            pos = hi
+        run(pos, n, self.step_main, True)
         self.model.sync_flat()
 
     # ---- the step -------------------------------------------------------------------------------------------------
@@ -175,18 +185,23 @@ class FlowTrainer:
             u = torch.rand(bsz, device=dev)
         t = warp_time(u.to(dev, torch.float32) * (1 - self.t_eps) + self.t_eps).contiguous()
         cls = cond.get('class_cond') if isinstance(cond, dict) else None
-        if isinstance(cond, dict) and cond.get('mask_cond') is not None:
-            raise NotImplementedError("FlowTrainer: mask-conditioned training is not built")
+        mask = cond.get('mask_cond') if isinstance(cond, dict) else None
+        if mask is not None and not self.model._cfg.mask_cond:
+            mask = None
+        if mask is not None:
+            # the mask latents enter as data: the U-Net's mask branches train, the MaskEncoder that produced them does not
+            mask = mask.detach().to(dev, torch.float32).contiguous()
         if cls is not None and not self.model.class_condition:
             cls = None
         if cls is not None:
             cls = cls.to(dev, torch.int64).contiguous()
         x, v_target = self.interpolate(source, target, t)
-        loss, _ = self.loss_and_grads(x, t, cls, v_target)
+        loss, _ = self.loss_and_grads(x, t, cls, v_target, mask)
         loss = loss.clone()
         if self.distributed:                                     # DDP semantics: average the gradients over ranks
             average_gradients(self.grads, self.pg)
-        self.optimizer_step(has_class_grads=cls is not None)
+        fused = mask is not None and not bool(torch.allclose(mask, torch.ones_like(mask)))    # unet.py:301 (host sync, as upstream)
+        self.optimizer_step(has_class_grads=cls is not None, has_mask_grads=mask is not None, has_fusion_grads=fused)
         return loss
 
     def train_batch(self, batch, epoch=None, cfg_drop: float = 0.1, mask_encoder=None, blank_latents=None):
@@ -215,8 +230,8 @@ class FlowTrainer:
 
     def state_dict(self):
         return {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "ema": self.ema.clone(),
-                "step_main": self.step_main, "step_class": self.step_class}
+                "step_main": self.step_main, "steps": dict(self.steps)}
 
     def load_state_dict(self, sd):
         self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"]); self.ema.copy_(sd["ema"])
-        self.step_main, self.step_class = int(sd["step_main"]), int(sd["step_class"])
+        self.step_main, self.steps = int(sd["step_main"]), {k: int(v) for k, v in sd["steps"].items()}

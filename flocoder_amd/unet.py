@@ -55,26 +55,32 @@ class _Node(nn.Module):
 
 
 class _UnetFunction(torch.autograd.Function):
-    """Autograd bridge: forward and backward both run in the library; parameters receive ``.grad`` as torch expects."""
+    """Autograd bridge: forward and backward both run in the library; parameters receive ``.grad`` as torch expects, and so do
+    ``x`` and the mask when they require it (the inpainting step reaches the MaskEncoder through both, train_flow.py:146-147)."""
 
     @staticmethod
-    def forward(ctx, model, x, time, cls, *params):
+    def forward(ctx, model, x, time, cls, mask, *params):
         ctx.model, ctx.cls = model, cls
-        ctx.save_for_backward(x, time)
-        return model._forward_native(x, time, cls, None, train=True)
+        ctx.save_for_backward(x, time, mask if mask is not None else x.new_empty(0))
+        ctx.has_mask = mask is not None
+        return model._forward_native(x, time, cls, mask, train=True)
 
     @staticmethod
     def backward(ctx, d_out):
-        x, time = ctx.saved_tensors
+        x, time, mask = ctx.saved_tensors
         model = ctx.model
-        flat = model.backward_native(x, time, ctx.cls, d_out)
+        mask = mask if ctx.has_mask else None
+        need_dx, need_dm = ctx.needs_input_grad[1], ctx.has_mask and ctx.needs_input_grad[4]
+        flat, dx, dm = model.backward_native(x, time, ctx.cls, d_out, mask=mask, want_dx=need_dx, want_dmask=need_dm)
         grads = []
         for name, shape, off in model._table:
             if ctx.cls is None and name.startswith("class_cond_mlp."):
                 grads.append(None)                                # unused this step: p.grad stays None, as in the reference
+            elif mask is None and (name.startswith("mask_fusion_conv.") or "_mask_fusions." in name):
+                grads.append(None)
             else:
                 grads.append(flat[off:off + math.prod(shape)].view(shape).clone())
-        return (None, None, None, None, *grads)
+        return (None, dx, None, None, dm, *grads)
 
 
 class Unet(nn.Module):
@@ -240,10 +246,8 @@ class Unet(nn.Module):
                 raise ValueError("mask_cond must have the shape of x (unet.py:302)")
         if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
             # loss.backward() support (train_flow.py:358-371): gradients come from the library's backward plan
-            if mask is not None:
-                raise NotImplementedError("flocoder_amd.Unet: the backward pass of the mask-conditioning branches is not built")
             params = [self.get_parameter(n) for n, _, _ in self._table]
-            return _UnetFunction.apply(self, x, time, cls, *params)
+            return _UnetFunction.apply(self, x, time, cls, mask, *params)
         return self._forward_native(x, time, cls, mask, train=False)
 
     def _forward_native(self, x, time, cls, mask, train: bool) -> torch.Tensor:
@@ -259,24 +263,32 @@ class Unet(nn.Module):
                                         B.current_stream(dev)))
         return out
 
-    def backward_native(self, x, time, cls, d_out, grads: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Parameter gradients of the LAST training forward (same x / time / class ids) for d(out) = ``d_out``: a flat fp32
-        vector in the library's table layout (``grad_views`` splits it).  train_flow.py:371 loss.backward()."""
+    def backward_native(self, x, time, cls, d_out, grads: Optional[torch.Tensor] = None, mask=None, want_dx=False, want_dmask=False):
+        """Parameter gradients of the LAST training forward (same x / time / class ids / mask) for d(out) = ``d_out``: a flat fp32
+        vector in the library's table layout (``grad_views`` splits it), plus d(x) / d(mask) on request.  Returns
+        ``(flat, dx | None, dmask | None)``.  train_flow.py:371 loss.backward()."""
         dev = x.device
         bsz, _, h, w = x.shape
         if grads is None:
             grads = torch.empty(self._flat_numel, dtype=torch.float32, device=dev)
-        B.check(B.lib().fc_unet_backward(self._native(dev), B.ptr(x), B.ptr(time), B.ptr(cls), B.ptr(d_out.contiguous()), B.ptr(grads),
-                                         grads.numel(), bsz, h, w, B.current_stream(dev)))
-        return grads
+        ones = int(torch.allclose(mask, torch.ones_like(mask))) if mask is not None else 0
+        dx = torch.empty_like(x) if want_dx else None
+        dm = torch.empty_like(x) if (want_dmask and mask is not None) else None
+        B.check(B.lib().fc_unet_backward_ex(self._native(dev), B.ptr(x), B.ptr(time), B.ptr(cls), B.ptr(mask), ones, B.ptr(d_out.contiguous()),
+                                            B.ptr(grads), grads.numel(), B.ptr(dx), B.ptr(dm), bsz, h, w, B.current_stream(dev)))
+        return grads, dx, dm
 
     def grad_views(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
         return {name: flat[off:off + math.prod(shape)].view(shape) for name, shape, off in self._table}
 
-    def class_param_range(self) -> Tuple[int, int]:
-        """[lo, hi) of class_cond_mlp.* inside the flat table (these get no gradient when a step runs without conditioning)."""
-        names = [(off, off + (math.prod(shape) + 3) // 4 * 4) for name, shape, off in self._table if name.startswith("class_cond_mlp.")]
+    def param_range(self, *prefixes) -> Tuple[int, int]:
+        """[lo, hi) inside the flat table of the (contiguous) parameters whose names start with one of ``prefixes``."""
+        names = [(off, off + (math.prod(shape) + 3) // 4 * 4) for name, shape, off in self._table if name.startswith(tuple(prefixes))]
         return (min(a for a, _ in names), max(b for _, b in names)) if names else (0, 0)
+
+    def class_param_range(self) -> Tuple[int, int]:
+        """class_cond_mlp.*: no gradient when a step runs without conditioning."""
+        return self.param_range("class_cond_mlp.")
 
     def adopt_flat(self, flat: torch.Tensor) -> None:
         """Make every parameter a view into ``flat`` (table layout) so that an optimiser working on the flat vector updates the

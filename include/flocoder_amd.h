@@ -146,13 +146,19 @@ int fc_debug_conv(const float* src0_nhwc, int c0, const float* src1_nhwc, int c1
  * Flow training step  (replaces train_flow.py:346-397: interpolation, loss.backward() through flocoder/unet.py,
  * clip_grad_norm_, torch.optim.Adam.step, EMA.update :46-54).  All vectors are caller-owned device memory.
  * ---------------------------------------------------------------------------------------------- */
-/* Forward plan (fc_unet_reserve) plus the backward plan over the same arena.  Not available with mask_cond. */
+/* Forward plan (fc_unet_reserve) plus the backward plan over the same arena. */
 int fc_unet_train_reserve(fc_unet* u, int max_batch, int height, int width);
 /* Gradients of all parameters for the LAST fc_unet_forward(x, time, ids) on this handle (same arguments again), given d(out):
  * grads_flat_dev[numel] in the parameter table's layout (fc_unet_param_info offsets; padding stays zero).  With ids == NULL
  * the class_cond_mlp.* range receives no gradient (zeros); an optimiser must skip it as torch skips p.grad is None. */
 int fc_unet_backward(fc_unet* u, const float* x_dev, const float* time_dev, const int64_t* class_ids_dev, const float* d_out_dev,
                      float* grads_flat_dev, int64_t numel, int batch, int height, int width, void* stream);
+/* The same with mask conditioning (cond['mask_cond'], unet.py:298-305,336-340,360-364) and the input gradients: mask_dev /
+ * mask_is_ones as in fc_unet_forward; dx_out_dev / dmask_out_dev [B,C,H,W] receive d(x) / d(mask) when not NULL (the inpainting
+ * step needs both: source and mask reach x through mask_blending, train_flow.py:146-147). */
+int fc_unet_backward_ex(fc_unet* u, const float* x_dev, const float* time_dev, const int64_t* class_ids_dev, const float* mask_dev,
+                        int mask_is_ones, const float* d_out_dev, float* grads_flat_dev, int64_t numel, float* dx_out_dev,
+                        float* dmask_out_dev, int batch, int height, int width, void* stream);
 /* [lo, hi) of class_cond_mlp.* inside the flat table (0,0 without classes). */
 int fc_unet_class_param_range(const fc_unet* u, int64_t* lo, int64_t* hi);
 /* x = (1-t) source + t target ; v* = target - source   (train_flow.py:350-353), t per sample. */

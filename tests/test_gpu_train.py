@@ -220,3 +220,103 @@ def test_batch_to_data_and_train_batch():
     tr = FlowTrainer(m, lr=1e-3)
     losses = [float(tr.train_batch((lat, cls))) for _ in range(12)]
     assert all(np.isfinite(losses)) and np.mean(losses[-4:]) < np.mean(losses[:4])       # it learns
+
+
+@pytest.mark.parametrize("variant", ["mask", "ones", "nomask"])
+@pytest.mark.parametrize("dim,hw,ncls", [(8, 8, 0), (16, 16, 5)])
+def test_mask_conditioned_gradients(variant, dim, hw, ncls):
+    """Backward of the mask-conditioning branches (mask_fusion_conv, per-scale injections; unet.py:298-305,336-340,360-364): every
+    parameter gradient plus d(x) and d(mask) against the oracle's autograd, for a real mask, an all-ones mask (fusion bypassed,
+    unet.py:301) and no mask at all (cond dropped)."""
+    from flocoder_amd.unet import Unet
+    torch.manual_seed(11)
+    m = Unet(dim=dim, channels=4, dim_mults=(1, 2, 4, 8), n_classes=ncls, mask_cond=True)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(dev()).train()
+    gen = torch.Generator().manual_seed(6)
+    B = 3
+    x = torch.randn(B, 4, hw, hw, generator=gen)
+    t = torch.rand(B, generator=gen) * 999
+    cls = torch.randint(0, ncls, (B,), generator=gen) if ncls else None
+    mask = {"mask": torch.rand(B, 4, hw, hw, generator=gen), "ones": torch.ones(B, 4, hw, hw), "nomask": None}[variant]
+    dv = torch.randn(B, 4, hw, hw, generator=gen)
+    # oracle: autograd through the functional U-Net, x and mask as leaves
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    mr = mask.clone().requires_grad_(True) if mask is not None else None
+    from oracle import flow_oracle as fo
+    cond = {"class_cond": cls, "mask_cond": mr}
+    v_ref = fo.unet_forward(leaves, xr, t, cond)
+    (v_ref * dv).sum().backward()
+    # library
+    xd, td = x.to(dev()), t.to(dev())
+    md = mask.to(dev()) if mask is not None else None
+    cd = cls.to(dev()) if cls is not None else None
+    v = m._forward_native(xd, td, cd, md, train=True)
+    assert rel_l2(v.cpu(), v_ref.detach()) < 2e-5
+    flat, dx, dm = m.backward_native(xd, td, cd, dv.to(dev()), mask=md, want_dx=True, want_dmask=True)
+    views = m.grad_views(flat)
+    total = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in leaves.values() if p.grad is not None)))
+    worst = ("", 0.0)
+    for k, p in leaves.items():
+        got = views[k].cpu()
+        if p.grad is None:
+            assert float(got.abs().max()) == 0.0, k
+            continue
+        e = rel_l2(got, p.grad)
+        lim = 2e-5 if float(p.grad.norm()) > 1e-4 * total else 5e-3
+        worst = max(worst, (k, e), key=lambda kv: kv[1])
+        assert e < lim, (k, e)
+    assert rel_l2(dx.cpu(), xr.grad) < 2e-5
+    if mask is not None:
+        ref_dm = mr.grad if mr.grad is not None else torch.zeros_like(mask)
+        if float(ref_dm.norm()) > 0:
+            assert rel_l2(dm.cpu(), ref_dm) < 2e-5
+        else:
+            assert float(dm.abs().max()) == 0.0
+    unused = [k for k, p in leaves.items() if p.grad is None]
+    if variant == "nomask":
+        assert any(k.startswith("mask_fusion_conv") for k in unused) and any("mask_fusions" in k for k in unused)
+    if variant == "ones":
+        assert any(k.startswith("mask_fusion_conv") for k in unused) and not any("mask_fusions" in k for k in unused)
+    print(variant, "worst parameter gradient:", worst)
+
+
+def test_mask_conditioned_training_steps_match_torch_adam():
+    """Three FlowTrainer steps on a mask-conditioned model (mask, all-ones mask, cond dropped) against the same steps taken with the
+    oracle's gradients and its explicit Adam: the mask parameter groups are skipped exactly when torch would skip them."""
+    from flocoder_amd.train import FlowTrainer
+    from flocoder_amd.unet import Unet
+    torch.manual_seed(12)
+    m = Unet(dim=8, channels=4, dim_mults=(1, 2, 4, 8), n_classes=0, mask_cond=True)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(dev())
+    tr = FlowTrainer(m, lr=1e-3)
+    state = to.new_state(sd)
+    gen = torch.Generator().manual_seed(7)
+    well = {}
+    for step, kind in enumerate(["mask", "ones", "nomask"]):
+        src, tgt = torch.randn(4, 4, 8, 8, generator=gen), torch.randn(4, 4, 8, 8, generator=gen)
+        u = torch.rand(4, generator=gen)
+        mask = {"mask": torch.rand(4, 4, 8, 8, generator=gen), "ones": torch.ones(4, 4, 8, 8), "nomask": None}[kind]
+        cond = {"class_cond": None, "mask_cond": mask} if mask is not None else None
+        loss = tr.step(src, tgt, cond, u=u)
+        t = to.train_time(u)
+        loss_ref, grads, _ = to.loss_and_grads(sd, src, tgt, t, cond)
+        to.adam_ema_step(sd, grads, state, lr=1e-3)
+        assert abs(float(loss) - float(loss_ref)) < 5e-6 * float(loss_ref)
+        got = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        # Adam's update g/(|g|+eps)-like ratio is ill-conditioned where a gradient is ~eps (1e-8): hold the well-conditioned elements
+        # (|g| > 1e-5 in every step so far) to 1e-3 of the learning rate, the rest to the learning rate itself
+        for k in sd:
+            if grads[k] is not None:
+                well[k] = well.get(k, torch.ones_like(sd[k], dtype=torch.bool)) & (grads[k].abs() > 1e-5)
+            d = (got[k] - sd[k]).abs()
+            w = well.get(k, torch.ones_like(sd[k], dtype=torch.bool))
+            assert float(d[w].max()) < 1e-3 * 1e-3 if bool(w.any()) else True, (kind, k, float(d[w].max()))
+            assert float(d.max()) < 1.01e-3 * (step + 1), (kind, k)
+    assert tr.steps == {"class": 0, "fusion": 1, "inject": 2} and tr.step_main == 3
