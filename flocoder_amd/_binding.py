@@ -95,6 +95,7 @@ SIGNATURES = {
     "fc_mask_encoder_load_params": (_i, [_vp, _vp, _i64, _i, _vp]),
     "fc_mask_encoder_reserve": (_i, [_vp, _i, _i, _i]),
     "fc_mask_encoder_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "fc_mask_encoder_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "fc_mask_blend": (_i, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "fc_ot_pairing": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _vp]),
 }

@@ -16,6 +16,25 @@ class _Node(nn.Module):
     pass
 
 
+class _MaskEncoderFunction(torch.autograd.Function):
+    """Autograd bridge for MaskEncoder training (train_flow.py:312-318,361-371).  The reference calls the encoder three times per
+    step (the batch's masks, all ones, all zeros) before ``loss.backward()``; the native object keeps the activations of its LAST
+    forward only, so the backward re-runs the (3 MFLOP) forward of its own call first."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        ctx.model = model
+        ctx.save_for_backward(x)
+        return model._forward_native(x)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (x,) = ctx.saved_tensors
+        model = ctx.model
+        flat = model.backward_native(x, d_out)
+        return (None, None, *[flat[off:off + math.prod(shape)].view(shape).clone() for _, shape, off in model._table])
+
+
 class MaskEncoder(nn.Module):
     """inpainting.py:182-245 with the defaults the flow trainer uses (output_channels=4, shrink_fac=4, mode='pool', sigmoid):
     pixel mask [B,1,H,W] -> [B,4,H/16,W/16]; channel 0 is the 16x average-pooled raw mask, channels 1-3 are learned.
@@ -81,21 +100,40 @@ class MaskEncoder(nn.Module):
         except Exception:
             pass
 
-    @torch.no_grad()
     def forward(self, mask_pixels):
         if not mask_pixels.is_cuda:
             raise RuntimeError("flocoder_amd.MaskEncoder runs on MI355X (gfx950) only; there is no CPU path")
         if mask_pixels.dtype in (torch.uint8, torch.int32, torch.int64, torch.bool):      # inpainting.py:236-237
             mask_pixels = mask_pixels.float()
-        x = mask_pixels.contiguous().float()
-        bsz, ch, h, w = x.shape
-        if ch != 1:
+        x = mask_pixels.detach().contiguous().float()
+        if x.shape[1] != 1:
             raise ValueError("mask_pixels must have one channel")
+        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
+            return _MaskEncoderFunction.apply(self, x, *[self.get_parameter(n) for n, _, _ in self._table])
+        with torch.no_grad():
+            return self._forward_native(x)
+
+    def _forward_native(self, x):
+        bsz, _, h, w = x.shape
         hnd = self._native(x.device)
         B.check(B.lib().fc_mask_encoder_reserve(hnd, bsz, h, w))
         out = torch.empty(bsz, 4, h // 16, w // 16, device=x.device)
         B.check(B.lib().fc_mask_encoder_forward(hnd, B.ptr(x), B.ptr(out), bsz, h, w, B.current_stream(x.device)))
         return out
+
+    def backward_native(self, x, d_out, grads=None, accumulate=False):
+        """Parameter gradients (flat, table layout) for d(mask_latents) = ``d_out`` of the forward on ``x`` -- which is re-run first."""
+        bsz, _, h, w = x.shape
+        out = self._forward_native(x)
+        if grads is None:
+            grads = torch.zeros(self._flat_numel, device=x.device)
+            accumulate = False
+        B.check(B.lib().fc_mask_encoder_backward(self._native(x.device), B.ptr(x), B.ptr(out), B.ptr(d_out.contiguous().float()), B.ptr(grads),
+                                                 grads.numel(), int(accumulate), bsz, h, w, B.current_stream(x.device)))
+        return grads
+
+    def grad_views(self, flat):
+        return {name: flat[off:off + math.prod(shape)].view(shape) for name, shape, off in self._table}
 
 
 def mask_blending(source, mask, noise=None):
@@ -104,6 +142,8 @@ def mask_blending(source, mask, noise=None):
         noise = torch.randn_like(source)
     if not source.is_cuda:
         raise RuntimeError("flocoder_amd.mask_blending runs on MI355X (gfx950) only; there is no CPU path")
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (source, mask, noise)):
+        return source + mask * (noise - source)             # under autograd (MaskEncoder training): three device elementwise ops on a latent
     s, m, n = (t.contiguous().float() for t in (source, mask.expand_as(source), noise))
     out = torch.empty_like(s)
     B.check(B.lib().fc_mask_blend(B.ptr(s), B.ptr(m), B.ptr(n), B.ptr(out), s.numel(), B.current_stream(s.device)))

@@ -150,10 +150,16 @@ class FlowTrainer:
         without conditioning, the mask branches without a mask, mask_fusion_conv with an all-ones mask) are skipped by Adam, step
         count included, exactly as torch.optim skips ``p.grad is None``; the EMA still averages them."""
         lib, st = B.lib(), B.current_stream(self.device)
+        B.check(lib.fc_grad_clip_coef(self.grads.data_ptr(), self.params.numel(), None, 0, self.max_norm, self._scal.data_ptr() + 4,
+                                      self._ws.data_ptr(), st))
+        self._adam_all(has_class_grads, has_mask_grads, has_fusion_grads)
+
+    def _adam_all(self, has_class_grads: bool, has_mask_grads: bool = False, has_fusion_grads: Optional[bool] = None):
+        """Adam + EMA over the U-Net's flat vectors with the clip coefficient already in ``_scal[2]``."""
+        lib, st = B.lib(), B.current_stream(self.device)
         n = self.params.numel()
         P, G, M, V, E = (t.data_ptr() for t in (self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.ema))
         coef = self._scal.data_ptr() + 8
-        B.check(lib.fc_grad_clip_coef(G, n, None, 0, self.max_norm, self._scal.data_ptr() + 4, self._ws.data_ptr(), st))
         b1, b2 = self.betas
         self.step_main += 1
         present = {"class": has_class_grads, "inject": has_mask_grads,
@@ -204,8 +210,99 @@ class FlowTrainer:
         self.optimizer_step(has_class_grads=cls is not None, has_mask_grads=mask is not None, has_fusion_grads=fused)
         return loss
 
+    # ---- inpainting: the MaskEncoder trains with the U-Net (train_flow.py:312-318,361-395) ----------------------------------
+    def attach_mask_encoder(self, mask_encoder, lr_scale: float = 0.1, max_norm: float = 0.5):
+        """The second parameter group of the reference's optimiser (lr x 0.1, train_flow.py:313-318) with its own flat vectors."""
+        me = mask_encoder.to(self.device).train()
+        n = me._flat_numel
+        z = lambda: torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.me, self.me_lr, self.me_max_norm = me, self.lr * lr_scale, max_norm
+        self.me_params, self.me_grads, self.me_m, self.me_v = z(), z(), z(), z()
+        with torch.no_grad():
+            for name, shape, off in me._table:
+                p = me.get_parameter(name)
+                self.me_params[off:off + p.numel()].copy_(p.detach().reshape(-1))
+                p.data = self.me_params[off:off + p.numel()].view(shape)
+        self.me_ema = self.me_params.clone()
+        self.me_step = 0
+        self._me_scal = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self.model.mask_encoder = me                          # as upstream (train_flow.py:333): checkpoints / EMA see it through the model
+
+    def inpaint_step(self, source_latents, target, mask_pixels, class_cond=None, noise=None, u=None, drop_cond=False, ot=False):
+        """One inpainting training step entirely on the device (batch_to_data's mask branch + train_flow.py:346-397):
+        mask = MaskEncoder(mask_pixels); source = blend(source_latents, mask, noise); flow loss through the mask-conditioned U-Net;
+        + MSE(MaskEncoder(1), 1) + MSE(MaskEncoder(0), 0); backward into both networks (the encoder is reached through the U-Net's
+        mask input AND through the blended source); joint clip at 1.0, the encoder's own at 0.5, Adam (lr, lr x 0.1), EMA of both."""
+        lib, dev, st = B.lib(), self.device, B.current_stream(self.device)
+        me = self.me
+        f = lambda t_: t_.to(dev, torch.float32).contiguous()
+        s0, tgt, mp = f(source_latents), f(target), f(mask_pixels)
+        if mp.dim() < 4:
+            mp = mp.unsqueeze(1)
+        bsz = tgt.shape[0]
+        noise = f(noise) if noise is not None else torch.randn_like(tgt)
+        if u is None:
+            u = torch.rand(bsz, device=dev)
+        t = warp_time(f(u) * (1 - self.t_eps) + self.t_eps).contiguous()
+        cls = class_cond.to(dev, torch.int64).contiguous() if (class_cond is not None and self.model.class_condition) else None
+        with torch.no_grad():
+            time = (t * self.t_scale).contiguous()
+            if drop_cond:                                     # the 10 % classifier-free-guidance drop (train_flow.py:343-345): no cond, pure noise source
+                mask, cls = None, None
+                x, v_target = self.interpolate(torch.randn_like(tgt), tgt, t)
+                loss_t, _ = self.loss_and_grads(x, t, None, v_target, None)
+                self.me_grads.zero_()
+            else:
+                mask = me._forward_native(mp)
+                source = mask_blending(s0, mask, noise)
+                if ot:                                        # batch_to_data re-indexes the TARGET by the greedy pairing (train_flow.py:160-163)
+                    tgt = tgt[compute_ot_pairing(source, tgt)].contiguous()
+                x, v_target = self.interpolate(source, tgt, t)
+                v = self.model._forward_native(x, time, cls, mask, train=True)
+                dv = torch.empty_like(v)
+                B.check(lib.fc_mse_loss_grad(B.ptr(v), B.ptr(v_target), B.ptr(dv), self._scal.data_ptr(), self._ws.data_ptr(), v.numel(), st))
+                _, dx, dmask = self.model.backward_native(x, time, cls, dv, self.grads, mask=mask, want_dx=True, want_dmask=True)
+                # chain rule through x = (1-t) s' + t g,  v* = g - s',  s' = s + m (noise - s)
+                d_src = (1 - t).view(-1, 1, 1, 1) * dx + dv
+                d_mask = dmask + d_src * (noise - s0)
+                me.backward_native(mp, d_mask, self.me_grads, accumulate=False)
+            loss = self._scal[0].clone()
+            for fill in (1.0, 0.0):                           # the 0/1 anchors of the mask latents (train_flow.py:361-369)
+                pix = torch.full_like(mp, fill)
+                y = me._forward_native(pix)
+                want = torch.full_like(y, fill)
+                dy = torch.empty_like(y)
+                B.check(lib.fc_mse_loss_grad(B.ptr(y), B.ptr(want), B.ptr(dy), self._me_scal.data_ptr(), self._ws.data_ptr(), y.numel(), st))
+                me.backward_native(pix, dy, self.me_grads, accumulate=True)
+                loss = loss + self._me_scal[0]
+            if self.distributed:
+                average_gradients(self.grads, self.pg)
+                average_gradients(self.me_grads, self.pg)
+            # clip_grad_norm_(model.parameters(), 1.0) covers the attached encoder too (train_flow.py:333,392), then the encoder alone at 0.5
+            n, nm = self.params.numel(), self.me_params.numel()
+            B.check(lib.fc_grad_clip_coef(self.grads.data_ptr(), n, self.me_grads.data_ptr(), nm, self.max_norm, self._scal.data_ptr() + 4,
+                                          self._ws.data_ptr(), st))
+            B.check(lib.fc_grad_clip_coef(self.me_grads.data_ptr(), nm, None, 0, 1e30, self._me_scal.data_ptr() + 4, self._ws.data_ptr(), st))
+            c1 = self._scal[2]
+            self._me_scal[2] = c1 * torch.clamp(self.me_max_norm / (c1 * self._me_scal[1] + 1e-6), max=1.0)
+        fused = mask is not None and not bool(torch.allclose(mask, torch.ones_like(mask)))
+        self._adam_all(has_class_grads=cls is not None, has_mask_grads=mask is not None, has_fusion_grads=fused)
+        self.me_step += 1
+        b1, b2 = self.betas
+        B.check(lib.fc_adam_ema_step(self.me_params.data_ptr(), self.me_grads.data_ptr(), self.me_m.data_ptr(), self.me_v.data_ptr(),
+                                     self.me_ema.data_ptr(), nm, self._me_scal.data_ptr() + 8, self.me_lr, b1, b2, self.eps, self.me_step,
+                                     self.ema_decay, 1, st))
+        me._synced = None                                     # its flat vector changed under the views: re-upload on next use
+        return loss
+
     def train_batch(self, batch, epoch=None, cfg_drop: float = 0.1, mask_encoder=None, blank_latents=None):
-        """batch_to_data + the 10 % conditioning drop of train_flow.py:338-345 + step."""
+        """batch_to_data + the 10 % conditioning drop of train_flow.py:338-345 + step.  With an attached MaskEncoder and an
+        inpainting batch (dict with mask_pixels) the encoder trains too (``inpaint_step``)."""
+        data = batch[0]
+        if getattr(self, "me", None) is not None and isinstance(data, dict) and 'mask_pixels' in data:
+            target = data['target_latents'].to(self.device)
+            return self.inpaint_step(data['source_latents'], target, data['mask_pixels'].float(), class_cond=batch[1],
+                                     drop_cond=random.random() < cfg_drop, ot=True)
         source, target, class_cond, mask_cond, _ = batch_to_data(batch, self.device, True, mask_encoder, epoch=epoch, blank_latents=blank_latents)
         cond = {'class_cond': class_cond, 'mask_cond': mask_cond}
         if random.random() < cfg_drop:

@@ -249,6 +249,11 @@ int fc_mask_encoder_reserve(fc_mask_encoder* m, int max_batch, int height, int w
 /* MaskEncoder.forward (inpainting.py:235-245): mask_pixels_dev [B,1,H,W] fp32 -> mask_latents_dev [B,4,H/16,W/16]. */
 int fc_mask_encoder_forward(fc_mask_encoder* m, const float* mask_pixels_dev, float* mask_latents_dev, int batch, int height, int width,
                             void* stream);
+/* Parameter gradients of the LAST fc_mask_encoder_forward on this object (same mask_pixels again, its output in mask_latents_dev)
+ * for d(mask_latents): grads_flat_dev[numel] in the parameter-table layout, overwritten or (accumulate != 0) added to.  Replaces
+ * the MaskEncoder leg of loss.backward() in the inpainting step (train_flow.py:312-318,361-371). */
+int fc_mask_encoder_backward(fc_mask_encoder* m, const float* mask_pixels_dev, const float* mask_latents_dev, const float* d_latents_dev,
+                             float* grads_flat_dev, int64_t numel, int accumulate, int batch, int height, int width, void* stream);
 /* mask_blending (inpainting.py:250-253): out = source + mask * (noise - source), elementwise over numel floats. */
 int fc_mask_blend(const float* source_dev, const float* mask_dev, const float* noise_dev, float* out_dev, int64_t numel, void* stream);
 

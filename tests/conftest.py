@@ -28,8 +28,8 @@ def load_golden(name):
 
 def rel_l2(a, b):
     import torch
-    a = torch.as_tensor(a, dtype=torch.float64).flatten()
-    b = torch.as_tensor(b, dtype=torch.float64).flatten()
+    a = torch.as_tensor(a, dtype=torch.float64).detach().flatten()
+    b = torch.as_tensor(b, dtype=torch.float64).detach().flatten()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 

@@ -320,3 +320,155 @@ def test_mask_conditioned_training_steps_match_torch_adam():
             assert float(d[w].max()) < 1e-3 * 1e-3 if bool(w.any()) else True, (kind, k, float(d[w].max()))
             assert float(d.max()) < 1.01e-3 * (step + 1), (kind, k)
     assert tr.steps == {"class": 0, "fusion": 1, "inject": 2} and tr.step_main == 3
+
+
+def test_mask_encoder_gradients_match_oracle():
+    """MaskEncoder backward (five direct convolutions, SiLU / sigmoid) against autograd through the oracle's restatement, including
+    the accumulate mode the three-pass inpainting step uses."""
+    from flocoder_amd.inpainting import MaskEncoder
+    from oracle import flow_oracle as fo
+    torch.manual_seed(3)
+    me = MaskEncoder()
+    sd = {k: v.detach().clone() for k, v in me.state_dict().items()}
+    me = me.to(dev()).train()
+    gen = torch.Generator().manual_seed(9)
+    mp = (torch.rand(3, 1, 128, 128, generator=gen) > 0.6).float()
+    dl = torch.randn(3, 4, 8, 8, generator=gen)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ml = fo.mask_encoder_forward(leaves, mp)
+    (ml * dl).sum().backward()
+    out = me(mp.to(dev()))
+    assert out.requires_grad and rel_l2(out.detach().cpu(), ml.detach()) < 2e-6
+    flat = me.backward_native(mp.to(dev()), dl.to(dev()))
+    for k, v in me.grad_views(flat).items():
+        assert rel_l2(v.cpu(), leaves[k].grad) < 2e-5, k
+    flat2 = me.backward_native(mp.to(dev()), dl.to(dev()), grads=flat.clone(), accumulate=True)
+    assert rel_l2(flat2.cpu(), 2 * flat.cpu()) < 1e-6
+    (out * dl.to(dev())).sum().backward()                                     # and through autograd
+    for k, p in me.named_parameters():
+        assert rel_l2(p.grad.cpu(), leaves[k].grad) < 2e-5, k
+
+
+def test_inpainting_step_in_the_reference_loop_shape():
+    """train_flow.py:338-397 with a MaskEncoder, verbatim on the mirrors: mask latents from the encoder, blended source, mask-conditioned
+    U-Net, the two mask losses, loss.backward() -- every gradient (U-Net and MaskEncoder) against the oracle's autograd."""
+    from flocoder_amd.inpainting import MaskEncoder, mask_blending
+    from flocoder_amd.sampling import warp_time
+    from flocoder_amd.unet import Unet
+    from oracle import flow_oracle as fo
+    torch.manual_seed(21)
+    model, me = Unet(dim=8, channels=4, dim_mults=(1, 2, 4, 8), n_classes=0, mask_cond=True), MaskEncoder()
+    sdm = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    sde = {k: v.detach().clone() for k, v in me.state_dict().items()}
+    model, me = model.to(dev()).train(), me.to(dev()).train()
+    gen = torch.Generator().manual_seed(22)
+    B = 3
+    target, src0, noise = (torch.randn(B, 4, 8, 8, generator=gen) for _ in range(3))
+    mask_pixels = (torch.rand(B, 1, 128, 128, generator=gen) > 0.5).float()
+    u = torch.rand(B, generator=gen)
+
+    def step(unet_fn, enc_fn, blend, to_dev):
+        mp, tg, s0, nz, uu = (to_dev(t) for t in (mask_pixels, target, src0, noise, u))
+        mask = enc_fn(mp)
+        source = blend(s0, mask, nz)
+        t = warp_time(uu * (1 - 0.001) + 0.001)
+        te = t.view(-1, 1, 1, 1).repeat(1, tg.shape[1], tg.shape[2], tg.shape[3])
+        x = (1 - te) * source + te * tg
+        v_guess = tg - source
+        v_model = unet_fn(x, t * 999, {"class_cond": None, "mask_cond": mask})
+        loss = torch.nn.functional.mse_loss(v_model, v_guess)
+        mask_loss = torch.nn.functional.mse_loss(enc_fn(torch.ones_like(mp)), torch.ones_like(mask))
+        mask_loss = mask_loss + torch.nn.functional.mse_loss(enc_fn(torch.zeros_like(mp)), torch.zeros_like(mask))
+        loss = loss + 1.0 * mask_loss
+        loss.backward()
+        return loss.detach()
+
+    lm = {k: v.clone().requires_grad_(True) for k, v in sdm.items()}
+    le = {k: v.clone().requires_grad_(True) for k, v in sde.items()}
+    loss_ref = step(lambda x, t, c: fo.unet_forward(lm, x, t, c), lambda mp: fo.mask_encoder_forward(le, mp), fo.mask_blending, lambda t: t)
+    loss = step(model, me, mask_blending, lambda t: t.to(dev()))
+    assert abs(float(loss) - float(loss_ref)) < 5e-6 * float(loss_ref)
+    tot = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in list(lm.values()) + list(le.values()) if p.grad is not None)))
+    for name, p in list(model.named_parameters()) + [("ME." + k, v) for k, v in me.named_parameters()]:
+        ref = le[name[3:]].grad if name.startswith("ME.") else lm[name].grad
+        if ref is None:
+            assert p.grad is None, name
+            continue
+        lim = 5e-5 if float(ref.norm()) > 1e-4 * tot else 1e-2
+        assert rel_l2(p.grad.cpu(), ref) < lim, (name, rel_l2(p.grad.cpu(), ref))
+
+
+def test_fused_inpaint_step_equals_reference_loop_with_two_param_groups():
+    """FlowTrainer.inpaint_step (everything through the C ABI, no autograd) against train_flow.py:312-397 run verbatim on the mirrors
+    with torch.optim.Adam's two parameter groups, the joint clip at 1.0 and the encoder's clip at 0.5, over two steps."""
+    from flocoder_amd.inpainting import MaskEncoder, mask_blending
+    from flocoder_amd.sampling import warp_time
+    from flocoder_amd.train import FlowTrainer
+    from flocoder_amd.unet import Unet
+
+    def make():
+        torch.manual_seed(31)
+        return Unet(dim=8, channels=4, dim_mults=(1, 2, 4, 8), n_classes=0, mask_cond=True).to(dev()).train(), MaskEncoder().to(dev()).train()
+    model, me = make()
+    model_b, me_b = make()
+    lr = 1e-3
+    opt = torch.optim.Adam([{'params': model.parameters(), 'lr': lr}, {'params': me.parameters(), 'lr': lr * 0.1}])
+    model.mask_encoder = me                                  # train_flow.py:333 -- from here on model.parameters() includes the encoder
+    tr = FlowTrainer(model_b, lr=lr)
+    tr.attach_mask_encoder(me_b)
+    gen = torch.Generator().manual_seed(32)
+    well = {}
+    for step in range(2):
+        tgt, s0, noise = (torch.randn(3, 4, 8, 8, generator=gen).to(dev()) for _ in range(3))
+        mp = (torch.rand(3, 1, 128, 128, generator=gen) > 0.5).float().to(dev())
+        u = torch.rand(3, generator=gen).to(dev())
+        # -- reference loop shape
+        opt.zero_grad()
+        mask = me(mp)
+        source = mask_blending(s0, mask, noise)
+        t = warp_time(u * (1 - 0.001) + 0.001)
+        te = t.view(-1, 1, 1, 1).repeat(1, 4, 8, 8)
+        x = (1 - te) * source + te * tgt
+        loss = torch.nn.functional.mse_loss(model(x, t * 999, {'class_cond': None, 'mask_cond': mask}), tgt - source)
+        mask_loss = torch.nn.functional.mse_loss(me(torch.ones_like(mp)), torch.ones_like(mask))
+        mask_loss = mask_loss + torch.nn.functional.mse_loss(me(torch.zeros_like(mp)), torch.zeros_like(mask))
+        loss = loss + 1.0 * mask_loss
+        loss.backward()
+        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+        torch.nn.utils.clip_grad_norm_(me.parameters(), max_norm=0.5)
+        opt.step()
+        # -- fused step
+        loss_b = tr.inpaint_step(s0, tgt, mp, noise=noise, u=u)
+        assert abs(float(loss.detach()) - float(loss_b)) < 2e-6 * float(loss.detach())
+        pa, pb = dict(model.named_parameters()), dict(model_b.named_parameters())
+        assert set(pa) == set(pb) and any(k.startswith("mask_encoder.") for k in pa)
+        for k in pa:
+            well[k] = well.get(k, torch.ones_like(pa[k], dtype=torch.bool)) & (grads[k].abs() > 1e-5)
+            d = (pa[k].detach() - pb[k].detach()).abs()
+            if bool(well[k].any()):
+                assert float(d[well[k]].max()) < 2e-3 * lr, (step, k, float(d[well[k]].max()))
+            assert float(d.max()) < 1.01 * lr * (step + 1), (step, k)
+    assert tr.me_step == 2 and tr.step_main == 2
+
+
+def test_train_batch_inpainting_dict_batches():
+    """train_batch on the dict batches of the inpainting dataset (data.py / preencode_data.py:130-156): encoder attached, OT pairing,
+    the 10 % condition drop -- finite losses and both networks move."""
+    from flocoder_amd.inpainting import MaskEncoder
+    from flocoder_amd.train import FlowTrainer
+    from flocoder_amd.unet import Unet
+    torch.manual_seed(41)
+    model, me = Unet(dim=8, channels=4, dim_mults=(1, 2, 4, 8), n_classes=0, mask_cond=True).to(dev()), MaskEncoder()
+    tr = FlowTrainer(model, lr=1e-3)
+    tr.attach_mask_encoder(me)
+    before = tr.me_params.clone(), tr.params.clone()
+    gen = torch.Generator().manual_seed(42)
+    batch = ({"target_latents": torch.randn(6, 4, 8, 8, generator=gen), "source_latents": torch.randn(6, 4, 8, 8, generator=gen),
+              "mask_pixels": torch.rand(6, 1, 128, 128, generator=gen) > 0.5}, torch.zeros(6, dtype=torch.long))
+    import random
+    random.seed(0)
+    losses = [float(tr.train_batch(batch, cfg_drop=0.5)) for _ in range(12)]
+    assert all(np.isfinite(losses)) and not torch.equal(before[0], tr.me_params) and not torch.equal(before[1], tr.params)
+    assert tr.me_step == 12 and tr.steps["inject"] < 12                     # some steps dropped the condition
+    assert "mask_encoder.layers.0.conv1.weight" in dict(model.named_parameters())
