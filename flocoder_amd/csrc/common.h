@@ -154,7 +154,8 @@ struct TembArgs {
     float* t_out = nullptr;            // [B][td]
     int B = 0, dim = 0, td = 0;
 };
-int temb_launch(const TembArgs& a, hipStream_t s);
+// h, c1: [B][td] scratch for the two hidden layers
+int temb_launch(const TembArgs& a, float* h, float* c1, hipStream_t s);
 // ss[b][j] = sum_i silu(t[b][i]) * wt[i][j] + bias[j]   for the concatenation of every ResnetBlock.mlp
 int ss_launch(const float* t, const float* wt, const float* bias, float* ss, int B, int td, int S, hipStream_t s);
 

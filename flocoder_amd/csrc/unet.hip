@@ -336,9 +336,10 @@ static int build_plan(fc_unet* u, Plan* pl, int maxB, int H, int W) {
         }
         t.n_classes = ncls; t.t_out = pl->t_emb; t.dim = dim; t.td = td;
         b.scope = "time_mlp";
-        b.push([t](const FwdCtx& cx, hipStream_t s) {
+        float *hid = b.dmalloc((size_t)maxB * td), *chid = b.dmalloc((size_t)maxB * td);
+        b.push([t, hid, chid](const FwdCtx& cx, hipStream_t s) {
             TembArgs a = t; a.B = cx.B; a.time = cx.time; a.class_ids = cx.ids; a.class_batch_mod = cx.ids_mod; a.null_from = cx.null_from;
-            return temb_launch(a, s);
+            return temb_launch(a, hid, chid, s);
         }, "temb", 2.0 * ((double)dim * td + (double)td * td * (ncls > 0 ? 3 : 1)));
         const float *te = pl->t_emb, *wt = u->P("__ss_wt"), *sb = u->P("__ss_bias");
         float* ss = pl->ss;
