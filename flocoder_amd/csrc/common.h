@@ -174,12 +174,22 @@ struct LaArgs {
     float* y = nullptr;            // NHWC [B][n][C]: to_out.0 output (before to_out.1's GroupNorm)
     float* stats_out = nullptr;    // GroupNorm(1) partials of y: [B][1][T][2], T = linattn_fused_tiles(n), n_t = linattn_fused_nt(n, C)
     int B = 0, n = 0, C = 0, heads = 4;
+    // whole-module form (linattn_sample.hip): to_out.1's GroupNorm(1) parameters and the module output out = gn(y) + x
+    const float* g2 = nullptr;
+    const float* b2 = nullptr;
+    float eps2 = 1e-5f;
+    float* out = nullptr;
+    float* part = nullptr;         // [B][heads][n][C] scratch: every head's share of to_out.0
 };
 int linattn_fused_init();
 bool linattn_fused_supported(int n, int C, int heads);
 int linattn_fused_tiles(int n);
 float linattn_fused_nt(int n, int C);
 int linattn_fused_launch(const LaArgs& a, hipStream_t s);
+// The whole Residual(PreNorm(LinearAttention)) module in two launches, a workgroup per (sample, head) then per sample (n <= 64 positions)
+int linattn_sample_init();
+bool linattn_sample_supported(int n, int C, int heads);
+int linattn_sample_launch(const LaArgs& a, hipStream_t s);
 // SpatialNonLocalAttention (codecs.py:337-383) for a handful of channels: x NHWC [B][n][C] -> x + out_proj(softmax(rope(q) rope(k)^T) v)
 int rope_attn_launch(const float* x, const float* wq, const float* bq, const float* wk, const float* bk, const float* wv, const float* bv,
                      const float* wo, const float* bo, float* out, int B, int n, int C, int Cr, hipStream_t s);

@@ -1,0 +1,295 @@
+// Residual(PreNorm(LinearAttention)) (unet.py:125-161,250) at the low-resolution levels (n = H*W <= 64 positions) in two launches.
+//
+// At 8x8 / 4x4 the unfused chain (1x1 conv | context | apply | 1x1 conv | finalize) is five launches of a few microseconds of work
+// each, every boundary a ~7 us memory round trip; the arithmetic of the module is 0.2 - 0.4 GFLOP per batch.  The heads of a sample
+// never meet before to_out, so:
+//
+//   la_head   grid (heads, B), 4 waves: GroupNorm(x[b]) into LDS; waves 0..2 compute this head's q / k / v (one 32-column MFMA tile
+//             each, all rows, B operand streamed from global straight into the MFMA register layout) while wave 3 brings the head's
+//             32 rows of to_out.0 into LDS; softmax_d(q) * scale and softmax_n(k) happen in the accumulator registers (lane shuffles);
+//             context = k^T v; o = q . context; the head's share  o . Wout[32h .. 32h+32, :]  of to_out.0 goes to part[b][h].
+//   la_join   grid (B): y = bias + sum_h part[b][h] in registers, GroupNorm(1) (to_out.1) by a two-pass block reduction, + x.
+//
+// A one-launch form with a workgroup per sample was measured first: 24 - 37 us per module, bound by one CU's fp32 matrix pipe
+// (6.3 MFLOP of to_qkv per sample at 256 FLOP/clk = 10 us).  Splitting by head puts a sample on four CUs.
+#include "common.h"
+#include "stats_dev.h"
+
+namespace fc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define FC_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+namespace {
+constexpr int DH = 32, HEADS = 4, HID = HEADS * DH, C3 = 3 * HID, QS = 3 * DH + 1, PS = 33, PF = 16, JT = 512;
+
+__device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// rows [k0, k0 + 2*PF) of a 32-column weight tile into the MFMA B layout (lane: row parity = half, column = l31)
+__device__ __forceinline__ void wfetch(const float* __restrict__ wp, int ldw, int k0, float (&w)[PF]) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) w[u] = wp[(size_t)(k0 + 2 * u) * ldw];
+}
+
+// acc[mt] += A[mt*32 .. +32][0..K) . W[0..K)[32 columns]; A in LDS (row stride lda), W in global; K % (2*PF) == 0; `cur` already
+// holds rows [0, 2*PF).  The next PF loads are in flight while the current PF feed the matrix pipe.
+template <int MT>
+__device__ __forceinline__ void gemm_stream(const float* __restrict__ A, int lda, const float* __restrict__ wp, int ldw, int K, int l31, int half,
+                                            float (&cur)[PF], f32x16 (&acc)[MT]) {
+    float nxt[PF];
+    for (int k0 = 0; k0 < K; k0 += 2 * PF) {
+        const bool more = k0 + 2 * PF < K;
+        if (more) wfetch(wp, ldw, k0 + 2 * PF, nxt);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = FC_MFMA(A[(mt * 32 + l31) * lda + k0 + 2 * u + half], cur[u], acc[mt]);
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) cur[u] = nxt[u];
+        }
+    }
+}
+
+template <int MT>   // MT = ceil(n / 32) row tiles
+__global__ void __launch_bounds__(256) la_head_kernel(const LaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int NP = MT * 32;
+    const int C = a.C, n = a.n, XS = C + 1, WS = C + 32, CT = C >> 5;
+    float* Ab = sm;
+    float* Bb = Ab + C;
+    float* ctxl = Bb + C;            // [32][PS]
+    float* qkv = ctxl + DH * PS;     // [NP][QS]: q | k | v of this head
+    float* os = qkv + NP * QS;       // [NP][PS]
+    float* Wo = os + NP * PS;        // [32][WS]: rows 32h .. 32h+32 of to_out.0
+    float* xs = Wo + DH * WS;        // [NP][XS]
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const float* xb = a.x + (size_t)b * n * C;
+
+    // weights do not depend on anything computed here: first batch in flight before the statistics are even read
+    const float* wp = a.wqkv + (size_t)half * C3 + (wave < 3 ? wave : 0) * HID + h * DH + l31;
+    float cur[PF];
+    if (wave < 3) wfetch(wp, C3, 0, cur);
+
+    float mean, rstd;
+    combine_partials(a.xf, b, 0, &mean, &rstd);
+    for (int c = tid; c < C; c += 256) {
+        const float s = rstd * a.xf.gamma[c];
+        Ab[c] = s;
+        Bb[c] = a.xf.beta[c] - mean * s;
+    }
+    __syncthreads();
+    const int q4 = C >> 2;
+    for (int i = tid; i < NP * q4; i += 256) {
+        const int row = i / q4, c = (i - row * q4) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < n) {
+            v = *reinterpret_cast<const float4*>(xb + (size_t)row * C + c);
+            v.x = Ab[c] * v.x + Bb[c]; v.y = Ab[c + 1] * v.y + Bb[c + 1]; v.z = Ab[c + 2] * v.z + Bb[c + 2]; v.w = Ab[c + 3] * v.w + Bb[c + 3];
+        }
+        float* d = xs + row * XS + c;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+
+    if (wave < 3) {
+        f32x16 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+        gemm_stream<MT>(xs, XS, wp, C3, C, l31, half, cur, acc);
+        if (wave == 0) {          // q: softmax over the head's 32 channels (the 32 lanes of a half-wave), * dim_head^-0.5
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[mt][r];
+                    float m = v;
+                    m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
+                    m = fmaxf(m, __shfl_xor(m, 8)); m = fmaxf(m, __shfl_xor(m, 16));
+                    const float e = __expf(v - m);
+                    float s = e;
+                    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8); s += __shfl_xor(s, 16);
+                    acc[mt][r] = e * (0.17677669529663687f / s);
+                }
+        } else if (wave == 1) {   // k: softmax over the positions = the 16*MT rows here and the 16*MT of lane ^ 32
+            float m = -INFINITY;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) if (mt * 32 + acc_row(r, half) < n) m = fmaxf(m, acc[mt][r]);
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float s = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = (mt * 32 + acc_row(r, half) < n) ? __expf(acc[mt][r] - m) : 0.f;
+                    acc[mt][r] = e;
+                    s += e;
+                }
+            s += __shfl_xor(s, 32);
+            const float f = 1.0f / s;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][r] *= f;
+        }
+        float* dst = qkv + wave * DH + l31;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(mt * 32 + acc_row(r, half)) * QS] = acc[mt][r];
+    } else {
+        const float* wo = a.wout + (size_t)h * DH * C;
+        for (int i = lane; i < DH * q4; i += 64) {
+            const int k = i / q4, c = (i - k * q4) * 4;
+            *reinterpret_cast<float4*>(Wo + k * WS + c) = *reinterpret_cast<const float4*>(wo + (size_t)k * C + c);
+        }
+    }
+    __syncthreads();
+
+    // context[d][e] = sum_n k[n][d] v[n][e]
+    if (wave == 0) {
+        f32x16 c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = 0.f;
+        const float* kp = qkv + DH + l31;
+        const float* vp = qkv + 2 * DH + l31;
+#pragma unroll 4
+        for (int s = 0; s < NP / 2; ++s) c = FC_MFMA(kp[(2 * s + half) * QS], vp[(2 * s + half) * QS], c);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ctxl[acc_row(r, half) * PS + l31] = c[r];
+    }
+    __syncthreads();
+    // o[n][e] = sum_d q[n][d] ctx[d][e]
+    if (wave < MT) {
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.f;
+        const float* qp = qkv + (wave * 32 + l31) * QS;
+#pragma unroll 4
+        for (int s = 0; s < DH / 2; ++s) o = FC_MFMA(qp[2 * s + half], ctxl[(2 * s + half) * PS + l31], o);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) os[(wave * 32 + acc_row(r, half)) * PS + l31] = o[r];
+    }
+    __syncthreads();
+    // this head's share of to_out.0: part[b][h][n][C] = o . Wout[32h .. 32h+32, :]; wave -> channel tiles wave, wave + 4
+    float* pb = a.part + ((size_t)b * HEADS + h) * n * C;
+    for (int ct = wave; ct < CT; ct += 4) {
+        f32x16 y[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[mt][r] = 0.f;
+#pragma unroll 4
+        for (int s = 0; s < DH / 2; ++s) {
+            const float w = Wo[(2 * s + half) * WS + ct * 32 + l31];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) y[mt] = FC_MFMA(os[(mt * 32 + l31) * PS + 2 * s + half], w, y[mt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mt * 32 + acc_row(r, half);
+                if (row < n) pb[(size_t)row * C + ct * 32 + l31] = y[mt][r];
+            }
+    }
+}
+
+__device__ __forceinline__ float block_sum_j(float v, float* red /*[JT/64]*/) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < JT / 64; ++w) s += red[w];
+    return s;
+}
+
+template <int EPT>   // float4's per thread: EPT * JT * 4 >= n * C
+__global__ void __launch_bounds__(JT) la_join_kernel(const LaArgs a) {
+    __shared__ float red[JT / 64];
+    const int b = blockIdx.x, tid = threadIdx.x, C = a.C, total4 = a.n * C / 4;
+    const size_t per = (size_t)a.n * C;
+    const float* pb = a.part + (size_t)b * HEADS * per;
+    float4 v[EPT];
+    float S = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + e * JT;
+        v[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < total4) {
+            const float4 p0 = *reinterpret_cast<const float4*>(pb + (size_t)i * 4), p1 = *reinterpret_cast<const float4*>(pb + per + (size_t)i * 4);
+            const float4 p2 = *reinterpret_cast<const float4*>(pb + 2 * per + (size_t)i * 4), p3 = *reinterpret_cast<const float4*>(pb + 3 * per + (size_t)i * 4);
+            const float4 bi = *reinterpret_cast<const float4*>(a.bout + (i * 4) % C);
+            v[e].x = bi.x + ((p0.x + p1.x) + (p2.x + p3.x)); v[e].y = bi.y + ((p0.y + p1.y) + (p2.y + p3.y));
+            v[e].z = bi.z + ((p0.z + p1.z) + (p2.z + p3.z)); v[e].w = bi.w + ((p0.w + p1.w) + (p2.w + p3.w));
+            S += (v[e].x + v[e].y) + (v[e].z + v[e].w);
+        }
+    }
+    const float cnt = (float)a.n * (float)C;
+    const float mu = block_sum_j(S, red) / cnt;
+    float Q = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+        if (tid + e * JT < total4) {
+            const float dx = v[e].x - mu, dy = v[e].y - mu, dz = v[e].z - mu, dw = v[e].w - mu;
+            Q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+    const float rs = 1.0f / sqrtf(block_sum_j(Q, red) / cnt + a.eps2);
+    const float* xb = a.x + (size_t)b * per;
+    float* ob = a.out + (size_t)b * per;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + e * JT;
+        if (i < total4) {
+            const int c = (i * 4) % C;
+            const float4 g = *reinterpret_cast<const float4*>(a.g2 + c), be = *reinterpret_cast<const float4*>(a.b2 + c);
+            const float4 x = *reinterpret_cast<const float4*>(xb + (size_t)i * 4);
+            float4 o;
+            o.x = ((v[e].x - mu) * rs * g.x + be.x) + x.x; o.y = ((v[e].y - mu) * rs * g.y + be.y) + x.y;
+            o.z = ((v[e].z - mu) * rs * g.z + be.z) + x.z; o.w = ((v[e].w - mu) * rs * g.w + be.w) + x.w;
+            *reinterpret_cast<float4*>(ob + (size_t)i * 4) = o;
+        }
+    }
+}
+
+size_t head_lds(int n, int C) {
+    const int NP = n <= 32 ? 32 : 64;
+    return (2 * (size_t)C + DH * PS + (size_t)NP * QS + (size_t)NP * PS + (size_t)DH * (C + 32) + (size_t)NP * (C + 1)) * sizeof(float);
+}
+}  // namespace
+
+int linattn_sample_init() {
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_head_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_head_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return FC_OK;
+}
+
+bool linattn_sample_supported(int n, int C, int heads) {
+    return heads == HEADS && n >= 1 && n <= 64 && (C % 32) == 0 && C >= 32 && n * C <= 8 * JT * 4 && head_lds(n, C) <= 160 * 1024;
+}
+
+int linattn_sample_launch(const LaArgs& a, hipStream_t s) {
+    if (!linattn_sample_supported(a.n, a.C, a.heads)) return fail(FC_E_SHAPE, "linattn_sample: unsupported shape");
+    if (a.xf.mode != 1 || a.xf.G != 1 || !a.xf.stats) return fail(FC_E_ARG, "linattn_sample: needs GroupNorm(1) statistics of x");
+    if (!a.g2 || !a.b2 || !a.out || !a.part || !a.bout) return fail(FC_E_ARG, "linattn_sample: to_out parameters / scratch / output missing");
+    const size_t lds = head_lds(a.n, a.C);
+    if (a.n <= 32) hipLaunchKernelGGL(la_head_kernel<1>, dim3(HEADS, a.B), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(la_head_kernel<2>, dim3(HEADS, a.B), dim3(256), lds, s, a);
+    const int total4 = a.n * a.C / 4;
+    if (total4 <= JT) hipLaunchKernelGGL(la_join_kernel<1>, dim3(a.B), dim3(JT), 0, s, a);
+    else if (total4 <= 2 * JT) hipLaunchKernelGGL(la_join_kernel<2>, dim3(a.B), dim3(JT), 0, s, a);
+    else if (total4 <= 4 * JT) hipLaunchKernelGGL(la_join_kernel<4>, dim3(a.B), dim3(JT), 0, s, a);
+    else hipLaunchKernelGGL(la_join_kernel<8>, dim3(a.B), dim3(JT), 0, s, a);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+}  // namespace fc

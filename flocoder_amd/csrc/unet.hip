@@ -188,6 +188,9 @@ struct Builder : PlanBuilder {
         // measured (tools/op_table.py, B=64): fused 110 vs 201 us at n=1024, 43 vs 65 us at n=256; at n <= 64 the per-workgroup weight
         // loads dominate and the unfused chain wins (37 vs 67 us at n=16, C=256)
         if (!u->keep_all && !no_fuse && n >= 256 && linattn_fused_supported(n, x.C, heads)) return linattn_fused(p, x, gn1);
+        // n <= 64: a workgroup per (sample, head), then one per sample (linattn_sample.hip): 2 launches instead of 5
+        static const bool no_sample = std::getenv("FLOCODER_AMD_LINATTN_NO_SAMPLE") != nullptr;
+        if (!u->keep_all && !no_fuse && !no_sample && linattn_sample_supported(n, x.C, heads)) return linattn_sample(p, x, gn1);
         Act qkv = act(3 * hid, x.H, x.W), lao = act(hid, x.H, x.W), yb = act(x.C, x.H, x.W), out = act(x.C, x.H, x.W);
         float* ctx = dmalloc((size_t)B * heads * 32 * 32);
         ConvArgs a;
@@ -233,6 +236,22 @@ struct Builder : PlanBuilder {
         f.res = x.p; f.y = out.p; f.HW = n; f.C = x.C;
         if (!err) push([f](const FwdCtx& c, hipStream_t s) { FinalizeArgs g = f; g.B = c.B; return finalize_launch(g, s); }, "finalize");
         pl->named[p] = out; pl->named[p + ".y"] = yb;
+        return out;
+    }
+
+    // the whole module in two launches (linattn_sample.hip)
+    Act linattn_sample(const std::string& p, const Act& x, const Stat& gn1) {
+        const int n = x.H * x.W, heads = u->heads, hid = heads * 32;
+        Act out = act(x.C, x.H, x.W);
+        LaArgs a;
+        a.x = x.p; a.xf = xf_of(gn1, 1, u->R(p + ".fn.norm.weight"), u->R(p + ".fn.norm.bias"));
+        a.wqkv = u->P(p + ".fn.fn.to_qkv.weight"); a.wout = u->P(p + ".fn.fn.to_out.0.weight"); a.bout = u->R(p + ".fn.fn.to_out.0.bias");
+        a.g2 = u->R(p + ".fn.fn.to_out.1.weight"); a.b2 = u->R(p + ".fn.fn.to_out.1.bias"); a.out = out.p;
+        a.n = n; a.C = x.C; a.heads = heads;
+        a.part = dmalloc((size_t)B * heads * n * x.C);
+        const double fl = 2.0 * n * (double)x.C * 3 * hid + 2.0 * 2 * n * 32 * 32 * heads + 2.0 * n * (double)hid * x.C;
+        if (!err) push([a](const FwdCtx& c, hipStream_t s) { LaArgs b = a; b.B = c.B; return linattn_sample_launch(b, s); }, "linattn_sample", fl);
+        pl->named[p] = out;
         return out;
     }
 
@@ -583,6 +602,7 @@ int fc_unet_create(const fc_unet_config* cfg, int device, fc_unet** out) {
     FC_HIP(hipSetDevice(device));
     FC_TRY(conv_init());
     FC_TRY(linattn_fused_init());
+    FC_TRY(linattn_sample_init());
     FC_TRY(u->alloc_device());
     const int half = cfg->dim / 2;
     std::vector<float> fr(half);
