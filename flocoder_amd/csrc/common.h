@@ -190,6 +190,9 @@ int linattn_fused_launch(const LaArgs& a, hipStream_t s);
 int linattn_sample_init();
 bool linattn_sample_supported(int n, int C, int heads);
 int linattn_sample_launch(const LaArgs& a, hipStream_t s);
+// Residual(PreNorm(Attention)) on the same kernels (g2 / b2 unused: to_out has no norm)
+bool attn_sample_supported(int n, int C, int heads);
+int attn_sample_launch(const LaArgs& a, hipStream_t s);
 // SpatialNonLocalAttention (codecs.py:337-383) for a handful of channels: x NHWC [B][n][C] -> x + out_proj(softmax(rope(q) rope(k)^T) v)
 int rope_attn_launch(const float* x, const float* wq, const float* bq, const float* wk, const float* bk, const float* wv, const float* bv,
                      const float* wo, const float* bo, float* out, int B, int n, int C, int Cr, hipStream_t s);

@@ -52,7 +52,7 @@ __device__ __forceinline__ void gemm_stream(const float* __restrict__ A, int lda
     }
 }
 
-template <int MT>   // MT = ceil(n / 32) row tiles
+template <int MT, bool FULL>   // MT = ceil(n / 32) row tiles; FULL: softmax(q k^T) v (Attention, unet.py:99-122) instead of the linear form
 __global__ void __launch_bounds__(256) la_head_kernel(const LaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int NP = MT * 32;
@@ -100,7 +100,14 @@ __global__ void __launch_bounds__(256) la_head_kernel(const LaArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
         gemm_stream<MT>(xs, XS, wp, C3, C, l31, half, cur, acc);
-        if (wave == 0) {          // q: softmax over the head's 32 channels (the 32 lanes of a half-wave), * dim_head^-0.5
+        if (FULL) {
+            if (wave == 0) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][r] *= 0.17677669529663687f;
+            }
+        } else if (wave == 0) {   // q: softmax over the head's 32 channels (the 32 lanes of a half-wave), * dim_head^-0.5
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -151,31 +158,80 @@ __global__ void __launch_bounds__(256) la_head_kernel(const LaArgs a) {
     }
     __syncthreads();
 
-    // context[d][e] = sum_n k[n][d] v[n][e]
-    if (wave == 0) {
-        f32x16 c;
+    if (FULL) {
+        // sim[i][j] = q_i . k_j (q already scaled), softmax over the keys j, o = attn . v; wave -> 32 query rows.  The probabilities
+        // take the place of the x tile (C >= NP, checked on the host).
+        constexpr int PSS = NP + 1;
+        float* ps = xs;
+        if (wave < MT) {
+            f32x16 st[MT];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) c[r] = 0.f;
-        const float* kp = qkv + DH + l31;
-        const float* vp = qkv + 2 * DH + l31;
+            for (int nt = 0; nt < MT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[nt][r] = 0.f;
+            const float* qp = qkv + (wave * 32 + l31) * QS;
 #pragma unroll 4
-        for (int s = 0; s < NP / 2; ++s) c = FC_MFMA(kp[(2 * s + half) * QS], vp[(2 * s + half) * QS], c);
+            for (int s = 0; s < DH / 2; ++s) {
+                const float qa = qp[2 * s + half];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ctxl[acc_row(r, half) * PS + l31] = c[r];
-    }
-    __syncthreads();
-    // o[n][e] = sum_d q[n][d] ctx[d][e]
-    if (wave < MT) {
-        f32x16 o;
+                for (int nt = 0; nt < MT; ++nt) st[nt] = FC_MFMA(qa, qkv[(nt * 32 + l31) * QS + DH + 2 * s + half], st[nt]);
+            }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] = 0.f;
-        const float* qp = qkv + (wave * 32 + l31) * QS;
+            for (int r = 0; r < 16; ++r) {
+                float m = -INFINITY;
+#pragma unroll
+                for (int nt = 0; nt < MT; ++nt) if (nt * 32 + l31 < n) m = fmaxf(m, st[nt][r]);
+                m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
+                m = fmaxf(m, __shfl_xor(m, 8)); m = fmaxf(m, __shfl_xor(m, 16));
+                float e[MT], sum = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < MT; ++nt) { e[nt] = (nt * 32 + l31 < n) ? __expf(st[nt][r] - m) : 0.f; sum += e[nt]; }
+                sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8); sum += __shfl_xor(sum, 16);
+                const float inv = 1.0f / sum;
+#pragma unroll
+                for (int nt = 0; nt < MT; ++nt) ps[(wave * 32 + acc_row(r, half)) * PSS + nt * 32 + l31] = e[nt] * inv;
+            }
+        }
+        __syncthreads();
+        if (wave < MT) {
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.f;
+            const float* pp = ps + (wave * 32 + l31) * PSS;
+            const float* vp = qkv + 2 * DH + l31;
 #pragma unroll 4
-        for (int s = 0; s < DH / 2; ++s) o = FC_MFMA(qp[2 * s + half], ctxl[(2 * s + half) * PS + l31], o);
+            for (int s = 0; s < NP / 2; ++s) o = FC_MFMA(pp[2 * s + half], vp[(2 * s + half) * QS], o);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) os[(wave * 32 + acc_row(r, half)) * PS + l31] = o[r];
+            for (int r = 0; r < 16; ++r) os[(wave * 32 + acc_row(r, half)) * PS + l31] = o[r];
+        }
+        __syncthreads();
+    } else {
+        // context[d][e] = sum_n k[n][d] v[n][e]
+        if (wave == 0) {
+            f32x16 c;
+    #pragma unroll
+            for (int r = 0; r < 16; ++r) c[r] = 0.f;
+            const float* kp = qkv + DH + l31;
+            const float* vp = qkv + 2 * DH + l31;
+    #pragma unroll 4
+            for (int s = 0; s < NP / 2; ++s) c = FC_MFMA(kp[(2 * s + half) * QS], vp[(2 * s + half) * QS], c);
+    #pragma unroll
+            for (int r = 0; r < 16; ++r) ctxl[acc_row(r, half) * PS + l31] = c[r];
+        }
+        __syncthreads();
+        // o[n][e] = sum_d q[n][d] ctx[d][e]
+        if (wave < MT) {
+            f32x16 o;
+    #pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.f;
+            const float* qp = qkv + (wave * 32 + l31) * QS;
+    #pragma unroll 4
+            for (int s = 0; s < DH / 2; ++s) o = FC_MFMA(qp[2 * s + half], ctxl[(2 * s + half) * PS + l31], o);
+    #pragma unroll
+            for (int r = 0; r < 16; ++r) os[(wave * 32 + acc_row(r, half)) * PS + l31] = o[r];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     // this head's share of to_out.0: part[b][h][n][C] = o . Wout[32h .. 32h+32, :]; wave -> channel tiles wave, wave + 4
     float* pb = a.part + ((size_t)b * HEADS + h) * n * C;
     for (int ct = wave; ct < CT; ct += 4) {
@@ -212,7 +268,7 @@ __device__ __forceinline__ float block_sum_j(float v, float* red /*[JT/64]*/) {
     return s;
 }
 
-template <int EPT>   // float4's per thread: EPT * JT * 4 >= n * C
+template <int EPT, bool GN>   // float4's per thread: EPT * JT * 4 >= n * C; GN: to_out.1's GroupNorm(1) before the residual
 __global__ void __launch_bounds__(JT) la_join_kernel(const LaArgs a) {
     __shared__ float red[JT / 64];
     const int b = blockIdx.x, tid = threadIdx.x, C = a.C, total4 = a.n * C / 4;
@@ -233,28 +289,35 @@ __global__ void __launch_bounds__(JT) la_join_kernel(const LaArgs a) {
             S += (v[e].x + v[e].y) + (v[e].z + v[e].w);
         }
     }
-    const float cnt = (float)a.n * (float)C;
-    const float mu = block_sum_j(S, red) / cnt;
-    float Q = 0.f;
+    float mu = 0.f, rs = 1.f;
+    if (GN) {
+        const float cnt = (float)a.n * (float)C;
+        mu = block_sum_j(S, red) / cnt;
+        float Q = 0.f;
 #pragma unroll
-    for (int e = 0; e < EPT; ++e)
-        if (tid + e * JT < total4) {
-            const float dx = v[e].x - mu, dy = v[e].y - mu, dz = v[e].z - mu, dw = v[e].w - mu;
-            Q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-        }
-    const float rs = 1.0f / sqrtf(block_sum_j(Q, red) / cnt + a.eps2);
+        for (int e = 0; e < EPT; ++e)
+            if (tid + e * JT < total4) {
+                const float dx = v[e].x - mu, dy = v[e].y - mu, dz = v[e].z - mu, dw = v[e].w - mu;
+                Q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+        rs = 1.0f / sqrtf(block_sum_j(Q, red) / cnt + a.eps2);
+    }
     const float* xb = a.x + (size_t)b * per;
     float* ob = a.out + (size_t)b * per;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int i = tid + e * JT;
         if (i < total4) {
-            const int c = (i * 4) % C;
-            const float4 g = *reinterpret_cast<const float4*>(a.g2 + c), be = *reinterpret_cast<const float4*>(a.b2 + c);
             const float4 x = *reinterpret_cast<const float4*>(xb + (size_t)i * 4);
             float4 o;
-            o.x = ((v[e].x - mu) * rs * g.x + be.x) + x.x; o.y = ((v[e].y - mu) * rs * g.y + be.y) + x.y;
-            o.z = ((v[e].z - mu) * rs * g.z + be.z) + x.z; o.w = ((v[e].w - mu) * rs * g.w + be.w) + x.w;
+            if (GN) {
+                const int c = (i * 4) % C;
+                const float4 g = *reinterpret_cast<const float4*>(a.g2 + c), be = *reinterpret_cast<const float4*>(a.b2 + c);
+                o.x = ((v[e].x - mu) * rs * g.x + be.x) + x.x; o.y = ((v[e].y - mu) * rs * g.y + be.y) + x.y;
+                o.z = ((v[e].z - mu) * rs * g.z + be.z) + x.z; o.w = ((v[e].w - mu) * rs * g.w + be.w) + x.w;
+            } else {
+                o.x = v[e].x + x.x; o.y = v[e].y + x.y; o.z = v[e].z + x.z; o.w = v[e].w + x.w;
+            }
             *reinterpret_cast<float4*>(ob + (size_t)i * 4) = o;
         }
     }
@@ -266,9 +329,23 @@ size_t head_lds(int n, int C) {
 }
 }  // namespace
 
+template <bool FULL>
+static void launch_pair(const LaArgs& a, hipStream_t s) {
+    const size_t lds = head_lds(a.n, a.C);
+    if (a.n <= 32) hipLaunchKernelGGL((la_head_kernel<1, FULL>), dim3(HEADS, a.B), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((la_head_kernel<2, FULL>), dim3(HEADS, a.B), dim3(256), lds, s, a);
+    const int total4 = a.n * a.C / 4;
+    if (total4 <= JT) hipLaunchKernelGGL((la_join_kernel<1, !FULL>), dim3(a.B), dim3(JT), 0, s, a);
+    else if (total4 <= 2 * JT) hipLaunchKernelGGL((la_join_kernel<2, !FULL>), dim3(a.B), dim3(JT), 0, s, a);
+    else if (total4 <= 4 * JT) hipLaunchKernelGGL((la_join_kernel<4, !FULL>), dim3(a.B), dim3(JT), 0, s, a);
+    else hipLaunchKernelGGL((la_join_kernel<8, !FULL>), dim3(a.B), dim3(JT), 0, s, a);
+}
+
 int linattn_sample_init() {
-    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_head_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_head_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_head_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_head_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_head_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_head_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return FC_OK;
 }
 
@@ -276,18 +353,23 @@ bool linattn_sample_supported(int n, int C, int heads) {
     return heads == HEADS && n >= 1 && n <= 64 && (C % 32) == 0 && C >= 32 && n * C <= 8 * JT * 4 && head_lds(n, C) <= 160 * 1024;
 }
 
+bool attn_sample_supported(int n, int C, int heads) { return linattn_sample_supported(n, C, heads) && C >= (n <= 32 ? 32 : 64); }
+
 int linattn_sample_launch(const LaArgs& a, hipStream_t s) {
     if (!linattn_sample_supported(a.n, a.C, a.heads)) return fail(FC_E_SHAPE, "linattn_sample: unsupported shape");
     if (a.xf.mode != 1 || a.xf.G != 1 || !a.xf.stats) return fail(FC_E_ARG, "linattn_sample: needs GroupNorm(1) statistics of x");
     if (!a.g2 || !a.b2 || !a.out || !a.part || !a.bout) return fail(FC_E_ARG, "linattn_sample: to_out parameters / scratch / output missing");
-    const size_t lds = head_lds(a.n, a.C);
-    if (a.n <= 32) hipLaunchKernelGGL(la_head_kernel<1>, dim3(HEADS, a.B), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(la_head_kernel<2>, dim3(HEADS, a.B), dim3(256), lds, s, a);
-    const int total4 = a.n * a.C / 4;
-    if (total4 <= JT) hipLaunchKernelGGL(la_join_kernel<1>, dim3(a.B), dim3(JT), 0, s, a);
-    else if (total4 <= 2 * JT) hipLaunchKernelGGL(la_join_kernel<2>, dim3(a.B), dim3(JT), 0, s, a);
-    else if (total4 <= 4 * JT) hipLaunchKernelGGL(la_join_kernel<4>, dim3(a.B), dim3(JT), 0, s, a);
-    else hipLaunchKernelGGL(la_join_kernel<8>, dim3(a.B), dim3(JT), 0, s, a);
+    launch_pair<false>(a, s);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+// Residual(PreNorm(Attention)) (unet.py:99-122,262) on the same two kernels: softmax(q k^T) v per head, to_out without a norm
+int attn_sample_launch(const LaArgs& a, hipStream_t s) {
+    if (!attn_sample_supported(a.n, a.C, a.heads)) return fail(FC_E_SHAPE, "attn_sample: unsupported shape");
+    if (a.xf.mode != 1 || a.xf.G != 1 || !a.xf.stats) return fail(FC_E_ARG, "attn_sample: needs GroupNorm(1) statistics of x");
+    if (!a.out || !a.part || !a.bout) return fail(FC_E_ARG, "attn_sample: to_out parameters / scratch / output missing");
+    launch_pair<true>(a, s);
     FC_HIP(hipGetLastError());
     return FC_OK;
 }

@@ -259,6 +259,19 @@ struct Builder : PlanBuilder {
     Act midattn(const Act& x, const Stat& gn1) {
         scope = "mid_attn";
         const int hid = u->heads * 32, n = x.H * x.W, heads = u->heads;
+        static const bool no_sample = std::getenv("FLOCODER_AMD_LINATTN_NO_SAMPLE") != nullptr;
+        if (!u->keep_all && !no_sample && attn_sample_supported(n, x.C, heads)) {    // two launches instead of three (linattn_sample.hip)
+            Act out = act(x.C, x.H, x.W);
+            LaArgs a;
+            a.x = x.p; a.xf = xf_of(gn1, 1, u->R("mid_attn.fn.norm.weight"), u->R("mid_attn.fn.norm.bias"));
+            a.wqkv = u->P("mid_attn.fn.fn.to_qkv.weight"); a.wout = u->P("mid_attn.fn.fn.to_out.weight"); a.bout = u->R("mid_attn.fn.fn.to_out.bias");
+            a.out = out.p; a.n = n; a.C = x.C; a.heads = heads;
+            a.part = dmalloc((size_t)B * heads * n * x.C);
+            const double fl = 2.0 * n * (double)x.C * 3 * hid + 2.0 * 2.0 * n * n * 32 * heads + 2.0 * n * (double)hid * x.C;
+            if (!err) push([a](const FwdCtx& c, hipStream_t s) { LaArgs b = a; b.B = c.B; return attn_sample_launch(b, s); }, "attn_sample", fl);
+            pl->named["mid_attn"] = out;
+            return out;
+        }
         Act qkv = act(3 * hid, x.H, x.W), ao = act(hid, x.H, x.W), out = act(x.C, x.H, x.W);
         ConvArgs a;
         a.s0.p = x.p; a.s0.C = x.C; a.s0.xf = xf_of(gn1, 1, u->R("mid_attn.fn.norm.weight"), u->R("mid_attn.fn.norm.bias"));
