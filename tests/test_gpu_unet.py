@@ -90,6 +90,30 @@ def test_forward_batch_sizes_and_determinism():
         assert err < FWD_TOL, f"B={B}: {err:.3e}\n" + first_bad_tap(model, sd, x, t, {"class_cond": cls}, B)
 
 
+@pytest.mark.parametrize("dim,H,W,B", [(32, 64, 64, 2), (16, 64, 64, 1), (32, 8, 8, 3), (32, 32, 16, 2), (64, 16, 16, 2)])
+def test_forward_latent_sizes_vs_oracle(dim, H, W, B):
+    """Other latent sizes put other attention kernels on the path: 64x64 latents run the bottleneck softmax attention and the
+    8x8 linear attention with two 32-row tiles per head (linattn_sample.hip), 8x8 latents the n = 1 / 4 / 16 forms at C = 32..256,
+    32x16 a non-square level, dim 64 the C = 512 levels (LDS-limit case of the per-head kernel)."""
+    from flocoder_amd.unet import Unet
+    torch.manual_seed(dim + H)
+    m = Unet(dim=dim, dim_mults=(1, 2, 4, 8), channels=4, n_classes=10).eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(H * W + dim)
+    for k, v in sd.items():                      # a fresh Unet has unit norms / zero biases: perturb so that every parameter matters
+        if v.dtype == torch.float32 and v.ndim == 1:
+            sd[k] = v + 0.1 * torch.randn(v.shape, generator=g)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV)
+    x, t = torch.randn(B, 4, H, W, generator=g), torch.rand(B, generator=g) * 999
+    cls = torch.arange(B) % 10
+    ref = fo.unet_forward(sd, x, t, {"class_cond": cls})
+    with torch.no_grad():
+        out = m(x.to(DEV), t.to(DEV), {"class_cond": cls.to(DEV)})
+    err = rel_l2(out.cpu(), ref)
+    assert err < FWD_TOL, f"dim={dim} {H}x{W}: {err:.3e}\n" + first_bad_tap(m, sd, x, t, {"class_cond": cls}, B)
+
+
 def test_rk4_and_euler_trajectories_match_reference_goldens():
     from flocoder_amd import sampling as S
     g = load_golden("g5_trajectories")
