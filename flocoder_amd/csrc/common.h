@@ -107,6 +107,7 @@ struct ConvGeom {  // filled by conv_plan(): what a consumer must know about `st
     int T1 = 0;        // fused tail: slots / count of the GroupNorm(1) partials of the final value
     float n_t1 = 0.f;
     int groups = 0;    // fused tail: arrival counters needed (sample groups)
+    int fin_local = 0; // fused tail: every GroupNorm group of the output lies inside one workgroup's tile (no meeting, no residency condition)
 };
 bool conv_fin_possible(const ConvArgs& a, int tile);   // the fused tail's residency / shape conditions hold for this launch
 int conv_init();

@@ -13,6 +13,7 @@ struct ConvDev {
     int tiles_x, tiles_y, ntiles, nblocks;
     int cpg, cpgt, NPG, rps;     // output-stats geometry
     int gsz, o_fin;              // fused tail: workgroups per sample group, LDS offset of the (mean, rstd) table
+    int fin_local;               // fused tail: the tile holds whole GroupNorm groups -> statistics straight from LDS, nothing to wait for
     int act0, act1, any_xf;
     int o_pixoff, o_pixtb, o_gstat, o_aff, o_patch, o_wl, o_wres, o_red, o_part;
     // pipelined kernel only
@@ -137,7 +138,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
     // thread i <-> (sample tb, column col) sums its column over the sample's 16-row half-blocks, then the cpgt columns of a
     // group -- consecutive lanes of one wave, cpgt a power of two <= 64 -- meet by xor-shuffles; the group's first lane writes
     // (mean_t, M2_t) of this tile's share of group g of sample b.
-    auto emit = [&](float* dst, int G, int cpg, int cpgt, int NPG, bool coherent) {
+    auto emit = [&](float* dst, int G, int cpg, int cpgt, int NPG, bool coherent, float* ltab) {
         const int hb_per = p.rps >> 4;
         const int ncols = min(BN, Cout - n0);
         for (int i0 = 0; i0 < p.TB * BN; i0 += nthr) {
@@ -157,6 +158,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                 const int msub = (p.TB > 1) ? 0 : ty * p.tiles_x + tx;
                 const int T = (p.TB > 1 ? 1 : p.tiles_x * p.tiles_y) * NPG;
                 float* d = dst + ((size_t)(b * G + g) * T + msub * NPG + nsub) * 2;
+                if (ltab) {       // the tile holds the whole group: (mean, rstd) for the tail below, no trip through memory
+                    const int ngt = cpg >= BN ? 1 : BN / cpg;
+                    ltab[2 * (tb * ngt + gl)] = mean;
+                    ltab[2 * (tb * ngt + gl) + 1] = 1.0f / sqrtf((q - s * mean) / n + a.fin.eps);
+                }
                 if (coherent) {   // read by other workgroups of this launch: device-scope stores that bypass the per-XCD L2
                     __hip_atomic_store(d, mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(d + 1, q - s * mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -199,7 +205,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
     conv_stamp(p, 7);
     if (a.stats_out) {
         __syncthreads();
-        emit(a.stats_out, a.Gout, p.cpg, p.cpgt, p.NPG, fin);
+        emit(a.stats_out, a.Gout, p.cpg, p.cpgt, p.NPG, fin && !p.fin_local, (fin && p.fin_local) ? smem + p.o_fin : nullptr);
     }
 
     if (fin) {
@@ -207,42 +213,44 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
         // The exchanged bytes (partials, counter) travel as device-scope relaxed atomics -- sc1 accesses that bypass the
         // non-coherent per-XCD L2 -- ordered by vmcnt(0) + the workgroup barrier; no cache write-back / invalidate, which
         // a release/acquire fence pair would cost every workgroup (measured: 120 us per launch instead of 25).
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            unsigned* c = a.fin.sync + b0 / p.TB;
-            const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned target = (old / (unsigned)p.gsz + 1u) * (unsigned)p.gsz;
-            int spins = 0;
-            while ((int)(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1 << 21)) { if (a.fin.err) *a.fin.err = 1; break; }   // bounded: a residency mistake must not hang the device
-            }
-        }
-        __syncthreads();
-        // (mean, rstd) of the groups this tile's columns belong to, per sample of the tile
         float* tab = smem + p.o_fin;
         const int ngt = p.cpg >= BN ? 1 : BN / p.cpg;
-        const int Tst = (p.TB > 1 ? 1 : p.tiles_x * p.tiles_y) * p.NPG;
-        for (int i = tid; i < p.TB * ngt; i += nthr) {
-            const int tb = i / ngt, gl = i - tb * ngt, b = b0 + tb, g = n0 / p.cpg + gl;
-            float mean = 0.f, rstd = 0.f;
-            if (b < a.B && g < a.Gout) {
-                float* sp = a.stats_out + (size_t)(b * a.Gout + g) * Tst * 2;
-                const float nt_ = (float)(p.rps * p.cpgt);
-                float sm = 0.f;
-                for (int t = 0; t < Tst; ++t) sm += __hip_atomic_load(sp + 2 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                mean = sm / (float)Tst;
-                float m2 = 0.f, dv = 0.f;
-                for (int t = 0; t < Tst; ++t) {
-                    const float d = __hip_atomic_load(sp + 2 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - mean;
-                    m2 += __hip_atomic_load(sp + 2 * t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    dv += d * d;
+        if (!p.fin_local) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                unsigned* c = a.fin.sync + b0 / p.TB;
+                const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned target = (old / (unsigned)p.gsz + 1u) * (unsigned)p.gsz;
+                int spins = 0;
+                while ((int)(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1 << 21)) { if (a.fin.err) *a.fin.err = 1; break; }   // bounded: a residency mistake must not hang the device
                 }
-                rstd = 1.0f / sqrtf((m2 + nt_ * dv) / (nt_ * (float)Tst) + a.fin.eps);
             }
-            tab[2 * i] = mean;
-            tab[2 * i + 1] = rstd;
+            __syncthreads();
+            // (mean, rstd) of the groups this tile's columns belong to, per sample of the tile
+            const int Tst = (p.TB > 1 ? 1 : p.tiles_x * p.tiles_y) * p.NPG;
+            for (int i = tid; i < p.TB * ngt; i += nthr) {
+                const int tb = i / ngt, gl = i - tb * ngt, b = b0 + tb, g = n0 / p.cpg + gl;
+                float mean = 0.f, rstd = 0.f;
+                if (b < a.B && g < a.Gout) {
+                    float* sp = a.stats_out + (size_t)(b * a.Gout + g) * Tst * 2;
+                    const float nt_ = (float)(p.rps * p.cpgt);
+                    float sm = 0.f;
+                    for (int t = 0; t < Tst; ++t) sm += __hip_atomic_load(sp + 2 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    mean = sm / (float)Tst;
+                    float m2 = 0.f, dv = 0.f;
+                    for (int t = 0; t < Tst; ++t) {
+                        const float d = __hip_atomic_load(sp + 2 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - mean;
+                        m2 += __hip_atomic_load(sp + 2 * t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        dv += d * d;
+                    }
+                    rstd = 1.0f / sqrtf((m2 + nt_ * dv) / (nt_ * (float)Tst) + a.fin.eps);
+                }
+                tab[2 * i] = mean;
+                tab[2 * i + 1] = rstd;
+            }
         }
         lds_only_barrier();
         if (owner) {
@@ -272,7 +280,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
             block_sums();
             lds_only_barrier();
             const int cpg1 = Cout, cpgt1 = Cout < BN ? Cout : BN, NPG1 = Cout >= BN ? Cout / BN : 1;
-            emit(a.fin.gn1_out, 1, cpg1, cpgt1, NPG1, false);
+            emit(a.fin.gn1_out, 1, cpg1, cpgt1, NPG1, false, nullptr);
         }
     }
 

@@ -332,7 +332,7 @@ static int conv_geometry(const ConvArgs& a, int tile, bool pipe, ConvDev* d, Con
         p.stamps = conv_stamp_buffer();
         g->tile = tile; g->grid = p.nblocks; g->lds = (size_t)o * sizeof(float);
         if (g->lds > 160 * 1024) return fail(FC_E_SHAPE, "conv: tile does not fit in LDS");
-        p.gsz = 1;
+        p.gsz = 1; p.fin_local = 0;
         if (a.fin.gamma) {   // fused Block tail: shape conditions and, above all, residency of the whole grid
             if (!a.stats_out || a.stats_post || a.out_act || a.add || a.res_out) return fail(FC_E_ARG, "conv: fused tail excludes act / add / res outputs");
             if (a.Cout % t.BN && a.Cout > t.BN) return fail(FC_E_SHAPE, "conv: fused tail needs Cout to fill its column tiles");
@@ -343,7 +343,9 @@ static int conv_geometry(const ConvArgs& a, int tile, bool pipe, ConvDev* d, Con
             g->n_t1 = (float)(p.rps * cpgt1);
             // two 512-thread workgroups share a CU only when both fit in LDS (and the kernels stay under 128 VGPRs: NT = 1 tiles)
             const int per_cu = (g->lds <= 80 * 1024 && t.MTNT == 1 && a.KS <= 3) ? 2 : 1;   // those instantiations stay <= 110 VGPRs
-            if (p.nblocks > conv_cu_count() * per_cu) return fail(FC_E_SHAPE, "conv: fused tail needs the whole grid resident");
+            p.fin_local = g->fin_local = (g->T == 1) ? 1 : 0;   // whole groups per tile: nothing to meet for
+            if (p.fin_local) p.gsz = 1;
+            else if (p.nblocks > conv_cu_count() * per_cu) return fail(FC_E_SHAPE, "conv: fused tail needs the whole grid resident");
         }
         return FC_OK;
     }

@@ -252,7 +252,8 @@ struct PlanBuilder {
     // A convolution whose epilogue finishes the Block: out = SiLU(GroupNorm(conv)) + res, the GroupNorm statistics exchanged between
     // the workgroups of a sample through a counter (ConvFin).  Returns false, emitting nothing, when the launch cannot keep its whole
     // grid resident or the shape is outside the fused tail's conditions -- the caller then emits conv + finalize.
-    bool conv_fin(ConvArgs a, const Act& out, int G, const float* gamma, const float* beta, const float* res, bool want_gn1, Stat* gn1) {
+    bool conv_fin(ConvArgs a, const Act& out, int G, const float* gamma, const float* beta, const float* res, bool want_gn1, Stat* gn1,
+                  bool only_local = false) {
         if (err) return false;
         a.B = B; a.H = out.H; a.W = out.W; a.Cout = out.C; a.out = out.p;
         a.Cin = a.s0.C + a.s1.C;
@@ -261,6 +262,7 @@ struct PlanBuilder {
         a.fin.gamma = gamma; a.fin.beta = beta; a.fin.res = res;
         ConvGeom g;
         if (conv_plan(a, TILE_AUTO, &g) != FC_OK || !g.pipe) return false;
+        if (only_local && !g.fin_local) return false;    // the cross-workgroup meeting costs what the finalize launch costs; the local form is free
         Stat st = stat(G, g.T, g.n_t);
         a.stats_out = st.p;
         if (want_gn1) { *gn1 = stat(1, g.T1, g.n_t1); a.fin.gn1_out = gn1->p; }

@@ -157,8 +157,12 @@ struct Builder : PlanBuilder {
         // in-kernel meeting (four dependent memory round trips) costs what a launch boundary plus the finalize pass cost.  Off
         // unless FLOCODER_AMD_FUSED_TAIL=1 / fc_debug_set_fused_tail(1).
         const float* resp = (cin != cout) ? rb.p : x.p;
-        const bool fused = !u->keep_all && fused_tail_enabled() &&
-                           conv_fin(b, out, G, u->R(p + ".block2.norm.weight"), u->R(p + ".block2.norm.bias"), resp, want_gn1, gn1);
+        // Where a tile holds whole GroupNorm groups (dim 32: the 128-channel blocks at 4x4 and 8x8, 32 channels per group) there is nothing to meet
+        // for and the tail is always fused (FLOCODER_AMD_FUSED_TAIL=0 turns that off too).
+        static const bool no_local = [] { const char* e = std::getenv("FLOCODER_AMD_FUSED_TAIL"); return e && std::string(e) == "0"; }();
+        const bool fused = !u->keep_all && (fused_tail_enabled() || !no_local) &&
+                           conv_fin(b, out, G, u->R(p + ".block2.norm.weight"), u->R(p + ".block2.norm.bias"), resp, want_gn1, gn1,
+                                    !fused_tail_enabled());
         if (!fused) {
             conv(b, h2, G, &st2);
             FinalizeArgs f;
