@@ -314,7 +314,9 @@ static int conv_geometry(const ConvArgs& a, int tile, bool pipe, ConvDev* d, Con
         p.o_patch = o;
         p.patch_stride = align4(p.P * (t.CC + 1));
         p.o_wl = o + 2 * p.patch_stride;
-        p.wl_stride = a.KS * a.KS * t.CC * t.BN + (a.res_out ? t.CC * t.BN : 0);
+        // M32N32K4 at 3x3 loads its weights global -> registers (conv_pipe.hip "DB"): no slab stages in LDS
+        const bool direct_b = (t.WMWN == 1 && t.MTNT == 1 && a.KS == 3);
+        p.wl_stride = direct_b ? 0 : a.KS * a.KS * t.CC * t.BN + (a.res_out ? t.CC * t.BN : 0);
         p.o_wres = 0;
         p.nchunks = cdiv(a.Cin, t.CC);
         // a third weight stage lets slabs run two chunks ahead of the MFMAs; only worth its LDS when there are chunks to run ahead of

@@ -79,6 +79,12 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
     constexpr int NTHR = 256 + 64 * NL, LT = 64 * NL;
     constexpr int BN = 32 * NT * WN, CS = CC + 1, KSTEPS = CC / 2, KPW = KSTEPS / WK, Q = CC / 4, PIXSTEP = LT / Q, KK = KS * KS;
     static_assert(WM * WN * WK == 4, "4 consumer waves per workgroup");
+    // DB ("direct B"): with one 32 x 32 output tile per workgroup every weight element feeds exactly one wave, so staging the slab in
+    // LDS buys no reuse -- it only makes the loaders the pacemaker (stamps at 256->256 @4x4: loaders busy 37 k of the 43 k main-loop
+    // cycles, consumers 43 % of theirs at the chunk barrier).  The consumers then load their K-quarter of the slab from global
+    // straight into the MFMA B register layout (two 128-byte row segments per wave load), one chunk ahead, and the loaders keep
+    // only the input window.
+    constexpr bool DB = (WM * WN == 1 && MT == 1 && NT == 1 && KS == 3);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const ConvArgs& a = p.a;
     float* gstat = smem + p.o_gstat;
@@ -242,8 +248,10 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
             }
         };
         unsigned long long dbg_mem = 0, dbg_store = 0, dbg_bar = 0, dbg_issue = 0, dbg_dma = 0;   // diagnostics: cycles per loader phase
-        dma_weights(0);
-        if (nwb == 3 && nchunks > 1) dma_weights(1);
+        if (!DB) {
+            dma_weights(0);
+            if (nwb == 3 && nchunks > 1) dma_weights(1);
+        }
         gn_tables();
         issue_patch(0);
         wait_vmcnt(0);
@@ -254,10 +262,10 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
             const bool next = g + 1 < nchunks;
             int ahead = 0;
             unsigned long long ta = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-            if (next && nwb == 2) dma_weights(g + 1);
+            if (!DB && next && nwb == 2) dma_weights(g + 1);
             if (next) issue_patch(g + 1);
             unsigned long long tb_ = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-            if (nwb == 3 && g + 2 < nchunks) { dma_weights(g + 2); ahead = my_pieces; }
+            if (!DB && nwb == 3 && g + 2 < nchunks) { dma_weights(g + 2); ahead = my_pieces; }
             unsigned long long t0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
             if (p.stamps) { dbg_issue += tb_ - ta; dbg_dma += t0 - tb_; }
             wait_vmcnt(ahead);                    // window g+1 in registers, slab g+1 landed; slab g+2 stays in flight across the barrier
@@ -283,6 +291,25 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
         const int bbase = half * BN + wn * NT * 32 + l31;
         const int kk0 = wk * KPW;
         unsigned long long dbg_cbar = 0;
+        constexpr int NB = DB ? KK * KPW : 1, NR = DB ? KPW : 1;
+        float wcur[NB], wnxt[NB], rcur[NR], rnxt[NR];
+        const int ncol = n0 + l31;
+        const bool colok = ncol < Cout;                 // a column beyond Cout reads the zero block with zero strides
+        const float* wq = colok ? a.w + (size_t)b0 * a.w_batch_stride + ncol : p.zeros16;
+        const float* rq = (colok && has_res) ? a.res_w + ncol : p.zeros16;
+        const size_t wcs = colok ? (size_t)Cout : 0, wts = colok ? (size_t)Cin * Cout : 0;
+        auto fetch_w = [&](int i, float (&w)[NB], float (&r)[NR]) {   // this wave's rows of chunk i: channel c of every tap (+ res_conv row)
+#pragma unroll
+            for (int kk = 0; kk < KPW; ++kk) {
+                int c = i * CC + 2 * (kk0 + kk) + half;
+                c = c < Cin ? c : Cin - 1;               // past the Cin tail the window holds zeros: any finite weight will do
+                const float* q = wq + (size_t)c * wcs;
+#pragma unroll
+                for (int tap = 0; tap < KK; ++tap) w[tap * KPW + kk] = q[(size_t)tap * wts];
+                if (has_res) r[kk] = rq[(size_t)c * wcs];
+            }
+        };
+        if (DB) fetch_w(0, wcur, rcur);
         conv_stamp(p, 1);
         gn_tables();
         __syncthreads();        // stage 0 ready
@@ -290,6 +317,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
         for (int i = 0; i < nchunks; ++i) {
             const float* patch = patch0 + (i & 1) * p.patch_stride;
             const float* wl = wl0 + (i % p.nwb) * p.wl_stride + bbase;
+            if (DB && i + 1 < nchunks) fetch_w(i + 1, wnxt, rnxt);
 #pragma unroll
             for (int tap = 0; tap < KK; ++tap) {
                 const int tapoff = ((tap / KS) * PW + (tap % KS)) * CS;
@@ -300,7 +328,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) av[mt] = patch[abase[mt] + tapoff + k];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bv[nt] = wl[(tap * CC + k) * BN + nt * 32];
+                    for (int nt = 0; nt < NT; ++nt) bv[nt] = DB ? wcur[tap * KPW + kk] : wl[(tap * CC + k) * BN + nt * 32];
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -317,7 +345,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) av[mt] = patch[abase[mt] + tapoff + k];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bv[nt] = wl[(KK * CC + k) * BN + nt * 32];
+                    for (int nt = 0; nt < NT; ++nt) bv[nt] = DB ? rcur[kk] : wl[(KK * CC + k) * BN + nt * 32];
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -326,7 +354,15 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
                 }
             }
             unsigned long long t0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-            __syncthreads();    // stage i consumed; stage i+1 (if any) ready
+            if (DB) {
+                loader_handover();                       // not __syncthreads(): its vmcnt(0) would wait for the slab prefetched above
+#pragma unroll
+                for (int j = 0; j < NB; ++j) wcur[j] = wnxt[j];
+#pragma unroll
+                for (int j = 0; j < NR; ++j) rcur[j] = rnxt[j];
+            } else {
+                __syncthreads();    // stage i consumed; stage i+1 (if any) ready
+            }
             if (p.stamps) dbg_cbar += __builtin_amdgcn_s_memtime() - t0;
         }
         if (p.stamps && lane == 0) p.stamps[((size_t)blockIdx.x * 8 + wave8) * 16 + 11] = dbg_cbar;
