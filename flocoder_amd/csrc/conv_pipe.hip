@@ -252,9 +252,19 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
             dma_weights(0);
             if (nwb == 3 && nchunks > 1) dma_weights(1);
         }
+        {   // window 0 does not depend on the tables: request it first, so that its round trip overlaps theirs.  Ordinary loads --
+            // the compiler must see them pending across gn_tables() (hidden loads are only safe in straight-line code).
+            const int c = q4;
+            const bool live = c < Cin, first = c < C0;
+            const float* base = first ? a.s0.p + c : a.s1.p + (c - C0);
+            const int Cs = first ? C0 : C1;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                if (k >= nk) break;
+                pv[k] = *reinterpret_cast<const f32x4*>((live && e_po[k] >= 0) ? base + (size_t)e_po[k] * Cs : p.zeros16);
+            }
+        }
         gn_tables();
-        issue_patch(0);
-        wait_vmcnt(0);
         store_patch(0);
         conv_stamp(p, 3);
         loader_handover();                        // stage 0 ready
