@@ -50,6 +50,7 @@ struct TapeItem { int kind, idx; };   // 0 ResRec, 1 LinRec, 2 MidRec, 3 ConvRec
 struct Plan {                 // one launch plan + activation arena for up to maxB rows
     int maxB = 0, H = 0, W = 0;
     std::vector<Op> ops;
+    int side_ops = 0, join_at = 0;   // ops [0, side_ops) depend on nothing the ops [side_ops, join_at) produce or read: they may run beside them
     std::vector<std::string> op_kernel, op_what;  // parallel to ops: kernel family, reference module it serves
     std::vector<double> op_flops;                  // algorithmic FLOPs per sample of that launch
     std::vector<void*> allocs;

@@ -146,6 +146,7 @@ struct Builder : PlanBuilder {
             a.res_w = u->P(p + ".res_conv.weight"); a.res_b = u->R(p + ".res_conv.bias"); a.res_out = rb.p;
         }
         conv(a, h1, G, &st1);
+        if (pl->join_at == 0) pl->join_at = (int)pl->ops.size();   // first reader of the scale / shift table
         ConvArgs b;
         b.s0.p = h1.p; b.s0.C = cout;
         b.s0.xf = xf_of(st1, 2, u->R(p + ".block1.norm.weight"), u->R(p + ".block1.norm.bias"), pl->ss + u->ss_off.at(p), u->S);
@@ -381,6 +382,7 @@ static int build_plan(fc_unet* u, Plan* pl, int maxB, int H, int W) {
         float* ss = pl->ss;
         b.scope = "resblock.mlp";
         b.push([=](const FwdCtx& cx, hipStream_t s) { return ss_launch(te, wt, sb, ss, cx.B, td, S, s); }, "ss", 2.0 * (double)td * S);
+        pl->side_ops = (int)pl->ops.size();   // the conditioning chain reads only time / class ids: it runs beside init_conv and the first conv1
     }
 
     // -- init_conv (unet.py:295) and mask fusion (unet.py:298-305) --
@@ -569,8 +571,24 @@ static FwdCtx slice_ctx(const FwdCtx& c, int r0, int n, size_t sample_floats) {
     return k;
 }
 
+// one chain: the conditioning MLPs (time / class embedding -> every block's scale and shift) on the second stream, joined before
+// the first conv2; inside a captured step this becomes a parallel branch of the graph
+static int run_single(fc_unet* u, const Plan& pl, const FwdCtx& c, hipStream_t s) {
+    static const bool no_side = std::getenv("FLOCODER_AMD_NO_SIDE") != nullptr;
+    const int ns = pl.side_ops, nj = pl.join_at;
+    if (no_side || ns <= 0 || nj <= ns || !u->stream2) return run_plan(pl, c, s);
+    FC_HIP(hipEventRecord(u->ev_fork, s));
+    FC_HIP(hipStreamWaitEvent(u->stream2, u->ev_fork, 0));
+    for (int i = 0; i < ns; ++i) FC_TRY(pl.ops[i](c, u->stream2));
+    FC_HIP(hipEventRecord(u->ev_join, u->stream2));
+    for (int i = ns; i < nj; ++i) FC_TRY(pl.ops[i](c, s));
+    FC_HIP(hipStreamWaitEvent(s, u->ev_join, 0));
+    for (size_t i = nj; i < pl.ops.size(); ++i) FC_TRY(pl.ops[i](c, s));
+    return FC_OK;
+}
+
 static int run_forward(fc_unet* u, const FwdCtx& c, hipStream_t s) {
-    if (u->nchains < 2 || c.B < 2) return run_plan(u->plan[0], c, s);
+    if (u->nchains < 2 || c.B < 2) return run_single(u, u->plan[0], c, s);
     // two chains: with CFG the conditional and the unconditional rows, otherwise the two halves of the batch
     const int r0 = (c.null_from > 0 && c.null_from < c.B) ? c.null_from : (c.B + 1) / 2;
     if (r0 > u->plan[0].maxB || c.B - r0 > u->plan[1].maxB) return fail(FC_E_STATE, "unet: chain plans too small for this batch");
