@@ -21,9 +21,10 @@ def family(name):
     if m:
         a = [x.strip() for x in m.group(1).split(",")]
         return TILES.get(tuple(a[:5]), name)
-    m = re.match(r"(?:void )?fc::(\w+?)_kernel", name)
+    m = re.search(r"(\w+?)_kernel", name)
     fam = m.group(1) if m else name
-    return {"la_ctx_fast": "linattn_fused", "la_apply_fast": "linattn_fused", "la_ctx": "linattn_fused", "la_apply": "linattn_fused"}.get(fam, fam)
+    return {"la_ctx_fast": "linattn_fused", "la_apply_fast": "linattn_fused", "la_ctx": "linattn_fused", "la_apply": "linattn_fused",
+            "la_head": "attn_heads", "la_join": "attn_heads", "cond_hidden": "temb", "cond_out": "temb"}.get(fam, fam)
 
 
 def load(path, counter):
