@@ -155,6 +155,7 @@ struct TembArgs {
     float* t_out = nullptr;            // [B][td]
     int B = 0, dim = 0, td = 0;
 };
+int temb_init();
 // h, c1: [B][td] scratch for the two hidden layers
 int temb_launch(const TembArgs& a, float* h, float* c1, hipStream_t s);
 // ss[b][j] = sum_i silu(t[b][i]) * wt[i][j] + bias[j]   for the concatenation of every ResnetBlock.mlp

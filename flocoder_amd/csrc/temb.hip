@@ -148,13 +148,14 @@ __global__ void ss_kernel(const float* __restrict__ t, const float* __restrict__
 static int cond_lds(int td, size_t* lds) {
     *lds = ((size_t)td * kCondSB + 4 * kCondSB * 64) * sizeof(float);
     if (*lds > 160 * 1024) return fail(FC_E_SHAPE, "temb: time_dim too large for the LDS-resident conditioning kernels");
-    static bool once = false;
-    if (!once) {
-        FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cond_hidden_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cond_out_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ss_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        once = true;
-    }
+    return FC_OK;
+}
+
+// once per process, before any launch or graph capture (large `dim`: more than the default 64 KiB of dynamic LDS)
+int temb_init() {
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cond_hidden_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cond_out_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ss_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return FC_OK;
 }
 

@@ -638,6 +638,7 @@ int fc_unet_create(const fc_unet_config* cfg, int device, fc_unet** out) {
     FC_TRY(conv_init());
     FC_TRY(linattn_fused_init());
     FC_TRY(linattn_sample_init());
+    FC_TRY(temb_init());
     FC_TRY(u->alloc_device());
     const int half = cfg->dim / 2;
     std::vector<float> fr(half);
