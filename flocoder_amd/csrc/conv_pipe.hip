@@ -116,6 +116,28 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
     auto gn_tables = [&]() {
       if (p.any_xf) {
         const int G0 = a.s0.xf.mode ? a.s0.xf.G : 0, G1 = a.s1.xf.mode ? a.s1.xf.G : 0;
+        // second-phase operands (gamma, beta, FiLM scale / shift of this thread's first (sample, channel) entry) are requested
+        // together with the statistics: one memory round trip for the two tables instead of two dependent ones
+        float pg = 1.f, pbt = 0.f, psc = 0.f, psh = 0.f;
+        bool p_on = false, p_ss = false;
+        int p_gs = 0;
+        if (tid < p.TB * Cin) {
+            const int tb = tid / Cin, c = tid - tb * Cin, b = b0 + tb;
+            const bool first = c < C0;
+            const SrcXform& xf = first ? a.s0.xf : a.s1.xf;
+            if (b < a.B && xf.mode) {
+                const int cs = first ? c : c - C0, Cs = first ? C0 : C1;
+                p_on = true;
+                p_gs = 2 * ((first ? 0 : p.TB * G0) + tb * xf.G + cs / (Cs / xf.G));
+                pg = xf.gamma[cs];
+                pbt = xf.beta[cs];
+                if (xf.ss) {
+                    p_ss = true;
+                    psc = xf.ss[(size_t)b * xf.ss_stride + cs];
+                    psh = xf.ss[(size_t)b * xf.ss_stride + Cs + cs];
+                }
+            }
+        }
         for (int i = tid; i < p.TB * (G0 + G1); i += NTHR) {
             const bool first = i < p.TB * G0;
             const SrcXform& xf = first ? a.s0.xf : a.s1.xf;
@@ -135,7 +157,20 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
             gstat[2 * i + 1] = rstd;
         }
         __syncthreads();
-        for (int i = tid; i < p.TB * Cin; i += NTHR) {
+        if (tid < p.TB * Cin) {
+            float A = 1.f, Bv = 0.f;
+            if (p_on) {
+                A = gstat[p_gs + 1] * pg;
+                Bv = pbt - gstat[p_gs] * A;
+                if (p_ss) {
+                    const float sc = psc + 1.0f;
+                    A *= sc;
+                    Bv = Bv * sc + psh;
+                }
+            }
+            aff[tid] = make_float2(A, Bv);
+        }
+        for (int i = tid + NTHR; i < p.TB * Cin; i += NTHR) {
             const int tb = i / Cin, c = i - tb * Cin, b = b0 + tb;
             float A = 1.f, Bv = 0.f;
             const bool first = c < C0;
