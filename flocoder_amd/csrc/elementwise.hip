@@ -18,6 +18,32 @@ __global__ void __launch_bounds__(256) finalize_kernel(const FinalizeArgs a, int
     float* Br = Ar + (a.xf_res.mode ? a.C : 0);
     __shared__ float red[4];
     const int b = blockIdx.y, tid = threadIdx.x;
+    const int per = a.HW * a.C / bps;  // elements of this block (multiple of 4)
+    const size_t base = (size_t)b * a.HW * a.C + (size_t)blockIdx.x * per;
+    const bool act = a.xf.mode == 2 && !a.act_after_add, act2 = a.act_after_add != 0, nres = a.xf_res.mode != 0;
+    // Nothing below depends on an earlier load except through the two tables, so everything is requested up front: the first NPF
+    // rounds of h / res and this thread's gamma / beta / FiLM entries travel together with the statistics -- one memory round trip
+    // instead of three dependent ones (statistics -> affine operands -> data) for a kernel that lives 5 us.
+    constexpr int NPF = 4;
+    float4 hv[NPF], rv[NPF];
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) {
+        const int i = 4 * tid + 1024 * k;
+        hv[k] = rv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < per) {
+            hv[k] = *reinterpret_cast<const float4*>(a.h + base + i);
+            if (a.res) rv[k] = *reinterpret_cast<const float4*>(a.res + base + i);
+        }
+    }
+    float pg = 1.f, pb = 0.f, psc = 0.f, psh = 0.f;
+    if (tid < a.C) {
+        pg = a.xf.gamma[tid];
+        pb = a.xf.beta[tid];
+        if (a.xf.ss) {
+            psc = a.xf.ss[(size_t)b * a.xf.ss_stride + tid];
+            psh = a.xf.ss[(size_t)b * a.xf.ss_stride + a.C + tid];
+        }
+    }
     for (int g = tid; g < a.xf.G; g += 256) combine_partials(a.xf, b, g, &gm[2 * g], &gm[2 * g + 1]);
     if (a.xf_res.mode)
         for (int g = tid; g < a.xf_res.G; g += 256) combine_partials(a.xf_res, b, g, &gr[2 * g], &gr[2 * g + 1]);
@@ -33,11 +59,12 @@ __global__ void __launch_bounds__(256) finalize_kernel(const FinalizeArgs a, int
     const int cpg = a.C / a.xf.G;
     for (int c = tid; c < a.C; c += 256) {
         const int g = c / cpg;
-        float s = gm[2 * g + 1] * a.xf.gamma[c];
-        float t = a.xf.beta[c] - gm[2 * g] * s;
+        const bool pre = c == tid;
+        float s = gm[2 * g + 1] * (pre ? pg : a.xf.gamma[c]);
+        float t = (pre ? pb : a.xf.beta[c]) - gm[2 * g] * s;
         if (a.xf.ss) {
-            const float sc = a.xf.ss[(size_t)b * a.xf.ss_stride + c] + 1.0f;
-            const float sh = a.xf.ss[(size_t)b * a.xf.ss_stride + a.C + c];
+            const float sc = (pre ? psc : a.xf.ss[(size_t)b * a.xf.ss_stride + c]) + 1.0f;
+            const float sh = pre ? psh : a.xf.ss[(size_t)b * a.xf.ss_stride + a.C + c];
             s *= sc;
             t = t * sc + sh;
         }
@@ -45,20 +72,15 @@ __global__ void __launch_bounds__(256) finalize_kernel(const FinalizeArgs a, int
         Bv[c] = t;
     }
     __syncthreads();
-    const int per = a.HW * a.C / bps;  // elements of this block (multiple of 4)
-    const size_t base = (size_t)b * a.HW * a.C + (size_t)blockIdx.x * per;
-    const bool act = a.xf.mode == 2 && !a.act_after_add, act2 = a.act_after_add != 0, nres = a.xf_res.mode != 0;
     float s = 0.f, q = 0.f;
-    for (int i = 4 * tid; i < per; i += 1024) {
+    auto finish = [&](int i, float4 v, float4 r) {
         const int c = (int)((blockIdx.x * (size_t)per + i) % a.C);
-        float4 v = *reinterpret_cast<const float4*>(a.h + base + i);
         v.x = A[c] * v.x + Bv[c];
         v.y = A[c + 1] * v.y + Bv[c + 1];
         v.z = A[c + 2] * v.z + Bv[c + 2];
         v.w = A[c + 3] * v.w + Bv[c + 3];
         if (act) { v.x = silu_e(v.x); v.y = silu_e(v.y); v.z = silu_e(v.z); v.w = silu_e(v.w); }
         if (a.res) {
-            float4 r = *reinterpret_cast<const float4*>(a.res + base + i);
             if (nres) { r.x = Ar[c] * r.x + Br[c]; r.y = Ar[c + 1] * r.y + Br[c + 1]; r.z = Ar[c + 2] * r.z + Br[c + 2]; r.w = Ar[c + 3] * r.w + Br[c + 3]; }
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
         }
@@ -66,6 +88,17 @@ __global__ void __launch_bounds__(256) finalize_kernel(const FinalizeArgs a, int
         *reinterpret_cast<float4*>(a.y + base + i) = v;
         s += (v.x + v.y) + (v.z + v.w);
         q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    };
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) {
+        const int i = 4 * tid + 1024 * k;
+        if (i < per) finish(i, hv[k], rv[k]);
+    }
+    for (int i = 4 * tid + 1024 * NPF; i < per; i += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(a.h + base + i);
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.res) r = *reinterpret_cast<const float4*>(a.res + base + i);
+        finish(i, v, r);
     }
     if (a.stats_out) {
         const float S = block_sum_lds(s, red);    // LDS-only barriers: the output stores above stay in flight
