@@ -10,21 +10,23 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 
 // ---- batched form -------------------------------------------------------------------------------------------------------------
 // One sample per workgroup made every CU pull the whole weight matrix through its own L1 (3.25 MB at 64 B/clk = 21 us at dim 128,
-// and 64x the L2 traffic).  Here a workgroup owns 64 output columns for SB samples: 256 threads = 64 columns x 4 K-quarters (one
-// wave per quarter), the SB input vectors sit in LDS as [k][SB] so that one weight load feeds SB FMAs off two broadcast
-// ds_read_b128, and the four partial sums meet in LDS.  Weight bytes through an L1 drop by SB, the dependent-load chain by 4.
-constexpr int kCondSB = 8;
+// and 64x the L2 traffic).  Here a workgroup owns 64 output columns for SB samples: 512 threads = 64 columns x 8 K-splits (one
+// wave per split), the SB input vectors sit in LDS as [k][SB] so that one weight load feeds SB FMAs off two broadcast
+// ds_read_b128, and the eight partial sums meet in LDS.  Inside a sampler step these kernels find their weights cold (a whole
+// forward's traffic has passed through the L2 since the last use), so what matters is the number of DEPENDENT load rounds per
+// wave: 32 rows are requested at a time, which makes it one or two rounds at dim 32 (was eight of 8 rows on four waves).
+constexpr int kCondSB = 8, kCondKS = 8, kCondThreads = 64 * kCondKS, kCondPF = 32;
 
 template <int SB>
 __device__ __forceinline__ void dense_rows(const float* __restrict__ xs, const float* __restrict__ wt, int ld, int j, int k0, int k1,
                                            float (&acc)[SB]) {
     int k = k0;
-    for (; k + 8 <= k1; k += 8) {
-        float w[8];
+    for (; k + kCondPF <= k1; k += kCondPF) {
+        float w[kCondPF];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) w[u] = wt[(size_t)(k + u) * ld + j];
+        for (int u = 0; u < kCondPF; ++u) w[u] = wt[(size_t)(k + u) * ld + j];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < kCondPF; ++u) {
             const float4* xv = reinterpret_cast<const float4*>(xs + (size_t)(k + u) * SB);
 #pragma unroll
             for (int q = 0; q < SB / 4; ++q) {
@@ -33,6 +35,15 @@ __device__ __forceinline__ void dense_rows(const float* __restrict__ xs, const f
             }
         }
     }
+    for (; k + 4 <= k1; k += 4) {
+        float w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = wt[(size_t)(k + u) * ld + j];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < SB; ++q) acc[q] += xs[(size_t)(k + u) * SB + q] * w[u];
+    }
     for (; k < k1; ++k) {
         const float w = wt[(size_t)k * ld + j];
 #pragma unroll
@@ -40,25 +51,26 @@ __device__ __forceinline__ void dense_rows(const float* __restrict__ xs, const f
     }
 }
 
-// K rows split over the 4 waves in contiguous quarters (rounded up to whole rows)
+// K rows split over the waves in contiguous parts (rounded up to whole rows)
 __device__ __forceinline__ void k_range(int K, int wave, int& k0, int& k1) {
-    const int per = (K + 3) >> 2;
+    const int per = (K + kCondKS - 1) / kCondKS;
     k0 = min(K, wave * per);
     k1 = min(K, k0 + per);
 }
 
-// sum the 4 waves' partials: red[wave][SB][64]; afterwards thread (wave, lane) owns samples {wave, wave + 4} of column lane
+// sum the waves' partials in wave order: red[wave][SB][64]; afterwards thread (wave, lane) owns sample `wave` of column `lane`
 template <int SB>
-__device__ __forceinline__ void meet(float* red, const float (&acc)[SB], int wave, int lane, float (&out)[SB / 4]) {
+__device__ __forceinline__ float meet(float* red, const float (&acc)[SB], int wave, int lane) {
+    static_assert(SB == kCondKS, "one sample per wave after the meeting");
 #pragma unroll
     for (int q = 0; q < SB; ++q) red[(wave * SB + q) * 64 + lane] = acc[q];
     __syncthreads();
+    float s[kCondKS];
 #pragma unroll
-    for (int r = 0; r < SB / 4; ++r) {
-        const int q = wave + 4 * r;
-        out[r] = (red[(0 * SB + q) * 64 + lane] + red[(1 * SB + q) * 64 + lane]) + (red[(2 * SB + q) * 64 + lane] + red[(3 * SB + q) * 64 + lane]);
-    }
+    for (int w = 0; w < kCondKS; ++w) s[w] = red[(w * SB + wave) * 64 + lane];
+    const float out = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     __syncthreads();
+    return out;
 }
 
 __device__ __forceinline__ long class_of(const TembArgs& a, int b) {
@@ -69,15 +81,15 @@ __device__ __forceinline__ long class_of(const TembArgs& a, int b) {
 }
 
 // grid (ceil(td/64), ceil(B/SB), 1 or 2): z = 0 -> h = gelu(W1 sinemb(t) + b1), z = 1 -> c1 = gelu(CW1 emb[class] + cb1)
-__global__ void __launch_bounds__(256) cond_hidden_kernel(const TembArgs a, float* __restrict__ h, float* __restrict__ c1) {
+__global__ void __launch_bounds__(kCondThreads) cond_hidden_kernel(const TembArgs a, float* __restrict__ h, float* __restrict__ c1) {
     constexpr int SB = kCondSB;
-    extern __shared__ float sm[];   // xs[K][SB] | red[4][SB][64]
+    extern __shared__ float sm[];   // xs[2 td][SB] | red[KS][SB][64]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, b0 = blockIdx.y * SB;
     const bool cls = blockIdx.z == 1;
     const int K = cls ? a.td : a.dim, half = a.dim / 2;
     float* xs = sm;
-    float* red = sm + (size_t)a.td * SB;
-    for (int i = tid; i < K * SB; i += 256) {
+    float* red = sm + (size_t)2 * a.td * SB;
+    for (int i = tid; i < K * SB; i += kCondThreads) {
         const int k = i / SB, q = i % SB, b = b0 + q;
         float v = 0.f;
         if (b < a.B) {
@@ -98,46 +110,43 @@ __global__ void __launch_bounds__(256) cond_hidden_kernel(const TembArgs a, floa
     int k0, k1;
     k_range(K, wave, k0, k1);
     dense_rows<SB>(xs, cls ? a.cw1t : a.w1t, a.td, jj, k0, k1, acc);
-    float o[SB / 4];
-    meet<SB>(red, acc, wave, lane, o);
-    if (j >= a.td) return;
-    const float bias = cls ? a.cb1[j] : a.b1[j];
-#pragma unroll
-    for (int r = 0; r < SB / 4; ++r) {
-        const int b = b0 + wave + 4 * r;
-        if (b < a.B) (cls ? c1 : h)[(size_t)b * a.td + j] = gelu_erf(bias + o[r]);
-    }
+    const float o = meet<SB>(red, acc, wave, lane);
+    const int b = b0 + wave;
+    if (j < a.td && b < a.B) (cls ? c1 : h)[(size_t)b * a.td + j] = gelu_erf((cls ? a.cb1[j] : a.b1[j]) + o);
 }
 
-// grid (ceil(td/64), ceil(B/SB)): t_out = (b2 + W2 h) + (cb2 + CW2 c1 where the sample has a class)
-__global__ void __launch_bounds__(256) cond_out_kernel(const TembArgs a, const float* __restrict__ h, const float* __restrict__ c1, int with_class) {
+// grid (ceil(td/64), ceil(B/SB)): t_out = b2 + W2 h (+ cb2 + CW2 c1 where the sample has a class), the two products as ONE sweep
+// over the stacked rows [h ; c1] . [W2 ; CW2] -- a sample without a class contributes exact zeros
+__global__ void __launch_bounds__(kCondThreads) cond_out_kernel(const TembArgs a, const float* __restrict__ h, const float* __restrict__ c1, int with_class) {
     constexpr int SB = kCondSB;
-    extern __shared__ float sm[];   // xs[td][SB] | red[4][SB][64]
+    extern __shared__ float sm[];   // xs[2 td][SB] | red[KS][SB][64]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, b0 = blockIdx.y * SB, td = a.td;
     float* xs = sm;
-    float* red = sm + (size_t)td * SB;
+    float* red = sm + (size_t)2 * td * SB;
+    const int K = with_class ? 2 * td : td;
+    for (int i = tid; i < K * SB; i += kCondThreads) {
+        const int k = i / SB, b = b0 + i % SB;
+        float v = 0.f;
+        if (b < a.B) {
+            if (k < td) v = h[(size_t)b * td + k];
+            else if (class_of(a, b) >= 0) v = c1[(size_t)b * td + (k - td)];
+        }
+        xs[i] = v;
+    }
+    __syncthreads();
     const int j = blockIdx.x * 64 + lane, jj = min(j, td - 1);
     int k0, k1;
-    k_range(td, wave, k0, k1);
-    float ot[SB / 4], oc[SB / 4];
-    for (int pass = 0; pass < (with_class ? 2 : 1); ++pass) {
-        const float* src = pass ? c1 : h;
-        for (int i = tid; i < td * SB; i += 256) {
-            const int k = i / SB, b = b0 + i % SB;
-            xs[i] = b < a.B ? src[(size_t)b * td + k] : 0.f;
-        }
-        __syncthreads();
-        float acc[SB] = {};
-        dense_rows<SB>(xs, pass ? a.cw2t : a.w2t, td, jj, k0, k1, acc);
-        meet<SB>(red, acc, wave, lane, pass ? oc : ot);
-    }
-    if (j >= td) return;
-#pragma unroll
-    for (int r = 0; r < SB / 4; ++r) {
-        const int b = b0 + wave + 4 * r;
-        if (b >= a.B) continue;
-        float s = a.b2[j] + ot[r];
-        if (with_class && class_of(a, b) >= 0) s += a.cb2[j] + oc[r];
+    k_range(K, wave, k0, k1);
+    float acc[SB] = {};
+    // rows [k0, k1) of the stacked matrix: the part below td from W2, the part above from CW2
+    const int ka = min(k1, td), kb = max(k0, td);
+    if (k0 < ka) dense_rows<SB>(xs, a.w2t, td, jj, k0, ka, acc);
+    if (kb < k1) dense_rows<SB>(xs + (size_t)td * SB, a.cw2t, td, jj, kb - td, k1 - td, acc);
+    const float o = meet<SB>(red, acc, wave, lane);
+    const int b = b0 + wave;
+    if (j < td && b < a.B) {
+        float s = a.b2[j] + o;
+        if (with_class && class_of(a, b) >= 0) s += a.cb2[j];
         a.t_out[(size_t)b * td + j] = s;
     }
 }
@@ -146,7 +155,7 @@ __global__ void ss_kernel(const float* __restrict__ t, const float* __restrict__
                           int B, int td, int S);
 
 static int cond_lds(int td, size_t* lds) {
-    *lds = ((size_t)td * kCondSB + 4 * kCondSB * 64) * sizeof(float);
+    *lds = ((size_t)2 * td * kCondSB + kCondKS * kCondSB * 64) * sizeof(float);
     if (*lds > 160 * 1024) return fail(FC_E_SHAPE, "temb: time_dim too large for the LDS-resident conditioning kernels");
     return FC_OK;
 }
@@ -165,21 +174,21 @@ int temb_launch(const TembArgs& a, float* h, float* c1, hipStream_t s) {
     size_t lds;
     FC_TRY(cond_lds(a.td, &lds));
     const dim3 grid(cdiv(a.td, 64), cdiv(a.B, kCondSB), with_class ? 2 : 1);
-    hipLaunchKernelGGL(cond_hidden_kernel, grid, dim3(256), lds, s, a, h, c1);
-    hipLaunchKernelGGL(cond_out_kernel, dim3(grid.x, grid.y), dim3(256), lds, s, a, h, c1, with_class);
+    hipLaunchKernelGGL(cond_hidden_kernel, grid, dim3(kCondThreads), lds, s, a, h, c1);
+    hipLaunchKernelGGL(cond_out_kernel, dim3(grid.x, grid.y), dim3(kCondThreads), lds, s, a, h, c1, with_class);
     FC_HIP(hipGetLastError());
     return FC_OK;
 }
 
 // grid (ceil(S/64), ceil(B/SB)): ss[b][j] = bias[j] + sum_i silu(t[b][i]) wt[i][j]
-__global__ void __launch_bounds__(256) ss_kernel(const float* __restrict__ t, const float* __restrict__ wt, const float* __restrict__ bias,
-                                                 float* __restrict__ ss, int B, int td, int S) {
+__global__ void __launch_bounds__(kCondThreads) ss_kernel(const float* __restrict__ t, const float* __restrict__ wt, const float* __restrict__ bias,
+                                                          float* __restrict__ ss, int B, int td, int S) {
     constexpr int SB = kCondSB;
-    extern __shared__ float sm[];   // xs[td][SB] | red[4][SB][64]
+    extern __shared__ float sm[];   // xs[2 td][SB] | red[KS][SB][64]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, b0 = blockIdx.y * SB;
     float* xs = sm;
-    float* red = sm + (size_t)td * SB;
-    for (int i = tid; i < td * SB; i += 256) {
+    float* red = sm + (size_t)2 * td * SB;
+    for (int i = tid; i < td * SB; i += kCondThreads) {
         const int k = i / SB, b = b0 + i % SB;
         const float v = b < B ? t[(size_t)b * td + k] : 0.f;
         xs[i] = v / (1.0f + expf(-v));
@@ -190,20 +199,15 @@ __global__ void __launch_bounds__(256) ss_kernel(const float* __restrict__ t, co
     int k0, k1;
     k_range(td, wave, k0, k1);
     dense_rows<SB>(xs, wt, S, jj, k0, k1, acc);
-    float o[SB / 4];
-    meet<SB>(red, acc, wave, lane, o);
-    if (j >= S) return;
-#pragma unroll
-    for (int r = 0; r < SB / 4; ++r) {
-        const int b = b0 + wave + 4 * r;
-        if (b < B) ss[(size_t)b * S + j] = bias[j] + o[r];
-    }
+    const float o = meet<SB>(red, acc, wave, lane);
+    const int b = b0 + wave;
+    if (j < S && b < B) ss[(size_t)b * S + j] = bias[j] + o;
 }
 
 int ss_launch(const float* t, const float* wt, const float* bias, float* ss, int B, int td, int S, hipStream_t s) {
     size_t lds;
     FC_TRY(cond_lds(td, &lds));
-    hipLaunchKernelGGL(ss_kernel, dim3(cdiv(S, 64), cdiv(B, kCondSB)), dim3(256), lds, s, t, wt, bias, ss, B, td, S);
+    hipLaunchKernelGGL(ss_kernel, dim3(cdiv(S, 64), cdiv(B, kCondSB)), dim3(kCondThreads), lds, s, t, wt, bias, ss, B, td, S);
     FC_HIP(hipGetLastError());
     return FC_OK;
 }
