@@ -135,8 +135,20 @@ int gn_fold_launch(const float* in, float* out, int B, int G, int T, float n_t, 
 
 int init_conv_launch(const float* x_nchw, int x_batch_mod, const float* w /*[Cin][Cout]*/, const float* bias, float* out_nhwc,
                      int B, int Cin, int HW, int Cout, hipStream_t s);
+// Legacy Euler step folded into final_conv (sampling.py:43-48): y += v * dt from the kernel that produces v, and block 0 publishes the
+// next interval's time exactly as ode_time_launch would (reads ts[*step], writes tvec, advances the counter)
+struct EulerTail {
+    float* y = nullptr;            // NCHW state, updated in place; null = plain final_conv
+    float dt = 0.f;
+    int* step = nullptr;
+    const float* ts = nullptr;
+    float t_scale = 1.f;
+    float* sc = nullptr;
+    float* tvec = nullptr;
+    int rows = 0;
+};
 int final_conv_launch(const float* x_nhwc, const float* w /*[Cin][Cout]*/, const float* bias, float* out_nchw, int B, int Cin,
-                      int HW, int Cout, hipStream_t s);
+                      int HW, int Cout, const EulerTail& tail, hipStream_t s);
 int nchw_to_nhwc_launch(const float* src, float* dst, int B, int C, int HW, int Cpad, int src_batch_mod, hipStream_t s);
 int nhwc_to_nchw_launch(const float* src, float* dst, int B, int C, int HW, int Cpad, hipStream_t s);
 // nn.PixelShuffle(2) on NHWC: src [B][H][W][4C] (channel c*4 + i*2 + j) -> dst [B][2H][2W][C]

@@ -208,9 +208,10 @@ int init_conv_launch(const float* x, int bmod, const float* w, const float* bias
     return FC_OK;
 }
 
-// final_conv (unet.py:286,372): 1x1 conv reading NHWC, writing the NCHW boundary tensor.
+// final_conv (unet.py:286,372): 1x1 conv reading NHWC, writing the NCHW boundary tensor -- or, inside the legacy Euler integrator,
+// applying y += v * dt (one rounding per operation, as sampling.py:47 does) and publishing the next interval's time.
 __global__ void __launch_bounds__(256) final_conv_kernel(const float* x, const float* w, const float* bias, float* out, int B, int Cin,
-                                                         int HW, int Cout) {
+                                                         int HW, int Cout, const EulerTail e) {
     extern __shared__ float wsm[];  // [Cin][Cout] + [Cout]
     for (int i = threadIdx.x; i < Cin * Cout; i += 256) wsm[i] = w[i];
     for (int i = threadIdx.x; i < Cout; i += 256) wsm[Cin * Cout + i] = bias ? bias[i] : 0.f;
@@ -234,17 +235,34 @@ __global__ void __launch_bounds__(256) final_conv_kernel(const float* x, const f
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (co0 + j < Cout) out[((size_t)b * Cout + co0 + j) * HW + pix] = acc[j];
+                if (co0 + j < Cout) {
+                    const size_t o = ((size_t)b * Cout + co0 + j) * HW + pix;
+                    if (e.y) e.y[o] = __fadd_rn(e.y[o], __fmul_rn(acc[j], e.dt));    // x + pred * dt
+                    else out[o] = acc[j];
+                }
         }
+    }
+    if (e.y && blockIdx.x == 0) {   // what ode_time_kernel does at the head of a step, for the step that follows
+        const int i = *e.step;
+        const float t = e.ts[i];
+        __syncthreads();            // everyone has read the counter before it moves
+        if (threadIdx.x == 0) {
+            e.sc[0] = t;
+            e.sc[1] = 0.f;
+            *e.step = i + 1;
+        }
+        const float tv = __fmul_rn(t, e.t_scale);
+        for (int r = threadIdx.x; r < e.rows; r += 256) e.tvec[r] = tv;
     }
 }
 
-int final_conv_launch(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int HW, int Cout, hipStream_t s) {
+int final_conv_launch(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int HW, int Cout, const EulerTail& tail,
+                      hipStream_t s) {
     if (Cin & 3) return fail(FC_E_SHAPE, "final_conv: Cin must be a multiple of 4");
     const size_t total = (size_t)B * HW;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(final_conv_kernel, dim3(grid), dim3(256), (size_t)(Cin * Cout + Cout) * sizeof(float), s, x, w, bias, out, B,
-                       Cin, HW, Cout);
+                       Cin, HW, Cout, tail);
     FC_HIP(hipGetLastError());
     return FC_OK;
 }

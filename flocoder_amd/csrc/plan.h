@@ -35,6 +35,7 @@ struct FwdCtx {             // per-call inputs of one forward
     float* grads = nullptr;            // backward only: flat parameter gradients, table layout
     float* dx_out = nullptr;           // backward only, optional: NCHW gradient of the input x
     float* dmask_out = nullptr;        // backward only, optional: NCHW gradient of the mask
+    EulerTail euler;                   // integrator only: the Euler update rides in final_conv
 };
 using Op = std::function<int(const FwdCtx&, hipStream_t)>;
 

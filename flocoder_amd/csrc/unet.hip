@@ -520,7 +520,7 @@ static int build_plan(fc_unet* u, Plan* pl, int maxB, int H, int W) {
     {
         const float *xp = x.p, *w = u->P("final_conv.weight"), *bias = u->R("final_conv.bias");
         b.scope = "final_conv";
-        b.push([=](const FwdCtx& cx, hipStream_t s) { return final_conv_launch(xp, w, bias, cx.out, cx.B, dim, HW, ch, s); }, "final_conv", 2.0 * HW * dim * ch);
+        b.push([=](const FwdCtx& cx, hipStream_t s) { return final_conv_launch(xp, w, bias, cx.out, cx.B, dim, HW, ch, cx.euler, s); }, "final_conv", 2.0 * HW * dim * ch);
     }
     if (b.err) return b.err;
     pl->maxB = maxB; pl->H = H; pl->W = W;
@@ -802,6 +802,12 @@ double fc_unet_flops_per_sample(const fc_unet* u) { return u ? u->plan[0].flops 
 static uint32_t fbits(float f) { uint32_t v; std::memcpy(&v, &f, 4); return v; }
 
 // enqueue one integration step on `s` (captured into a graph by the caller)
+// Legacy Euler without CFG on one chain: the step needs nothing outside the plan (fc_unet_integrate publishes the first time)
+static bool euler_tail_ok(const fc_unet* u, int method, bool cfg_on) {
+    static const bool off = std::getenv("FLOCODER_AMD_NO_EULER_TAIL") != nullptr;
+    return !off && method == FC_METHOD_EULER && !cfg_on && u->nchains < 2;
+}
+
 static int enqueue_step(fc_unet* u, int method, int B, bool cfg_on, float cfg, float dt_euler, float t_scale, bool has_ids, int mask_mode,
                         hipStream_t s) {
     const int rows = cfg_on ? 2 * B : B, n = B * u->cfg.channels * u->H * u->W;
@@ -809,6 +815,12 @@ static int enqueue_step(fc_unet* u, int method, int B, bool cfg_on, float cfg, f
     c.x_mod = B; c.time = u->tvec; c.ids = has_ids ? u->ids_own : nullptr; c.ids_mod = B; c.null_from = cfg_on ? B : 0;
     c.mask = mask_mode ? u->mask_own : nullptr; c.mask_fuse = mask_mode == 1;
     c.out = u->v2; c.B = rows;
+    if (euler_tail_ok(u, method, cfg_on)) {   // the update and the next interval's time ride in final_conv: no launches around the plan
+        c.x = u->y;
+        c.euler.y = u->y; c.euler.dt = dt_euler; c.euler.step = u->step; c.euler.ts = u->ts_dev; c.euler.t_scale = t_scale;
+        c.euler.sc = u->sc; c.euler.tvec = u->tvec; c.euler.rows = rows;
+        return run_forward(u, c, s);
+    }
     FC_TRY(ode_time_launch(u->step, u->ts_dev, t_scale, method == FC_METHOD_RK4, u->sc, u->tvec, rows, s));
     if (method == FC_METHOD_EULER) {
         c.x = u->y;
@@ -839,10 +851,10 @@ int fc_unet_integrate(fc_unet* u, int method, float* x_dev, int B, int H, int W,
     const int n_steps = method == FC_METHOD_RK4 ? n_points - 1 : n_points;
     hipStream_t caller = static_cast<hipStream_t>(stream), s = u->stream;
     FC_HIP(hipSetDevice(u->device));
-    if (n_points > u->ts_cap) {  // grows only when a longer grid than ever before arrives
+    if (n_points + 1 > u->ts_cap) {  // grows only when a longer grid than ever before arrives
         FC_HIP(hipStreamSynchronize(s));
         if (u->ts_dev) FC_HIP(hipFree(u->ts_dev));
-        u->ts_cap = n_points < 1024 ? 1024 : n_points;
+        u->ts_cap = n_points < 1024 ? 1024 : n_points + 1;   // + 1: the fused Euler tail reads one entry past the grid after the last step
         FC_HIP(hipMalloc(reinterpret_cast<void**>(&u->ts_dev), u->ts_cap * sizeof(float)));
         for (auto& kv : u->graphs) (void)hipGraphExecDestroy(kv.second);
         u->graphs.clear();  // captured graphs hold the old ts pointer
@@ -858,6 +870,8 @@ int fc_unet_integrate(fc_unet* u, int method, float* x_dev, int B, int H, int W,
     if (has_ids) FC_HIP(hipMemcpyAsync(u->ids_own, ids, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
     if (mask_mode) FC_HIP(hipMemcpyAsync(u->mask_own, mask, nbytes, hipMemcpyDeviceToDevice, s));
 
+    if (euler_tail_ok(u, method, cfg_on))   // time of the first interval; every step publishes its successor's
+        FC_TRY(ode_time_launch(u->step, u->ts_dev, t_scale, 0, u->sc, u->tvec, rows, s));
     static const bool no_graph = std::getenv("FLOCODER_AMD_NO_GRAPH") != nullptr;
     if (no_graph) {
         for (int i = 0; i < n_steps; ++i) FC_TRY(enqueue_step(u, method, B, cfg_on, cfg_strength, dt_euler, t_scale, has_ids, mask_mode, s));
