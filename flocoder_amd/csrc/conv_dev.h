@@ -54,7 +54,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 template <int WM, int WN, int WK, int MT, int NT>
 __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT][NT], f32x16 (&accr)[MT][NT], float* smem, int tid, int lane,
                                               int wave, int b0, int y0, int x0, int n0, int tx, int ty, bool active = true,
-                                              int nthr = 256) {
+                                              int nthr = 256, const float* pre = nullptr) {
+    // `pre` (optional, 4*NT floats in the caller's registers): bias | res_conv bias | tail gamma | tail beta of this lane's columns,
+    // requested before the main loop -- loaded here they are a cold miss on the epilogue's critical path (~2 k cycles per launch).
     // `active` = this wave holds accumulators (false for the loader waves of the producer/consumer kernel, which only
     // take part in the barriers and the statistics reduction); `nthr` = threads in the workgroup.
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
@@ -183,7 +185,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
             for (int nt = 0; nt < NT; ++nt) {
                 const int ncol = (wn * NT + nt) * 32 + l31, n = n0 + ncol;
                 const bool nok = n < Cout;
-                const float bias = (a.bias && nok) ? a.bias[n] : 0.f;
+                const float bias = pre ? pre[nt] : ((a.bias && nok) ? a.bias[n] : 0.f);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mt][nt][r] += bias;
                 if (a.stats_post) {   // statistics of the FINAL value (activation and residual included): pre-norm resnets (SD-VAE)
@@ -262,7 +264,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                     const int ncol = (wn * NT + nt) * 32 + l31, n = n0 + ncol;
                     const bool nok = n < Cout;
                     const int gl = p.cpg >= BN ? 0 : ncol / p.cpg;
-                    const float gam = nok ? a.fin.gamma[n] : 0.f, bet = nok ? a.fin.beta[n] : 0.f;
+                    const float gam = pre ? pre[2 * NT + nt] : (nok ? a.fin.gamma[n] : 0.f), bet = pre ? pre[3 * NT + nt] : (nok ? a.fin.beta[n] : 0.f);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -321,7 +323,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                 for (int r = 0; r < 16; ++r)
                     if (pix[r] >= 0) op[(size_t)pix[r] * Cout] = acc[mt][nt][r];
                 if (has_res) {
-                    const float rbias = a.res_b ? a.res_b[n] : 0.f;
+                    const float rbias = pre ? pre[NT + nt] : (a.res_b ? a.res_b[n] : 0.f);
                     float* rp = a.res_out + n;
 #pragma unroll
                     for (int r = 0; r < 16; ++r)

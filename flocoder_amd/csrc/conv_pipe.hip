@@ -200,6 +200,21 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[mt][nt][r] = 0.f; accr[mt][nt][r] = 0.f; }
 
+    float pre[4 * NT];   // epilogue operands of this lane's columns (conv_dev.h): requested now, used after the last chunk
+#pragma unroll
+    for (int i = 0; i < 4 * NT; ++i) pre[i] = 0.f;
+    if (consumer) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = n0 + (wn * NT + nt) * 32 + l31;
+            if (n < Cout) {
+                if (a.bias) pre[nt] = a.bias[n];
+                if (has_res && a.res_b) pre[NT + nt] = a.res_b[n];
+                if (a.fin.gamma) { pre[2 * NT + nt] = a.fin.gamma[n]; pre[3 * NT + nt] = a.fin.beta[n]; }
+            }
+        }
+    }
+
     if (!consumer) {
         // =========================================== LOADERS ===========================================
         const float* wbase = a.w + (size_t)b0 * a.w_batch_stride;
@@ -413,7 +428,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
         if (p.stamps && lane == 0) p.stamps[((size_t)blockIdx.x * 8 + wave8) * 16 + 11] = dbg_cbar;
         conv_stamp(p, 5);
     }
-    conv_epilogue<WM, WN, WK, MT, NT>(p, acc, accr, smem, tid, lane, wave, b0, y0, x0, n0, tx, ty, consumer, NTHR);
+    conv_epilogue<WM, WN, WK, MT, NT>(p, acc, accr, smem, tid, lane, wave, b0, y0, x0, n0, tx, ty, consumer, NTHR, pre);
 }
 
 // ---------------------------------------------------------------------------------------------------
