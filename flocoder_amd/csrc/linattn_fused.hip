@@ -311,18 +311,22 @@ __global__ void __launch_bounds__(256) la_ctx_fast_kernel(const LaArgs a) {
     float* mz = sct + 128;              // [4][2][32]
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int nblk = (a.n + 31) >> 5;
+    // every cold operand is requested before anything is waited for: first x tile, statistics, norm parameters, weights
     float4 pre[NQ];
     if (wave < nblk) fetch_x<NQ>(a, b, wave * 32, lane, pre);
-    float mean, rstd;
-    combine_partials(a.xf, b, 0, &mean, &rstd);
-    for (int c = tid; c < C; c += 256) {
-        const float s = rstd * a.xf.gamma[c];
-        Ab[c] = s;
-        Bb[c] = a.xf.beta[c] - mean * s;
-    }
+    PartPre pp;
+    partials_request(a.xf, b, 0, pp);
+    const float pg = tid < C ? a.xf.gamma[tid] : 0.f, pbt = tid < C ? a.xf.beta[tid] : 0.f;   // C <= 64 < 256 threads
     for (int i = tid; i < C * 64; i += 256) {
         const int c = i >> 6, j = i & 63;
         Wl[i] = a.wqkv[(size_t)c * LC3 + (j < 32 ? LHID + h * LDH + j : 2 * LHID + h * LDH + (j - 32))];
+    }
+    float mean, rstd;
+    partials_finish(a.xf, b, 0, pp, &mean, &rstd);
+    if (tid < C) {
+        const float s = rstd * pg;
+        Ab[tid] = s;
+        Bb[tid] = pbt - mean * s;
     }
     __syncthreads();
     float* xw = xt + wave * 32 * XS;
@@ -411,15 +415,15 @@ __global__ void __launch_bounds__(256) la_apply_fast_kernel(const LaArgs a, int 
     __shared__ float red[4];
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int ntiles = (a.n + 127) >> 7;
+    // every cold operand is requested before anything is waited for: x tile, statistics, norm parameters, to_out bias, weights, context
     float4 pre[NQ];
     fetch_x<NQ>(a, b, blockIdx.x * 128 + wave * 32, lane, pre);
-    float mean, rstd;
-    combine_partials(a.xf, b, 0, &mean, &rstd);
-    for (int c = tid; c < C; c += 256) {
-        const float s = rstd * a.xf.gamma[c];
-        Ab[c] = s;
-        Bb[c] = a.xf.beta[c] - mean * s;
-    }
+    PartPre pp;
+    partials_request(a.xf, b, 0, pp);
+    const float pg = tid < C ? a.xf.gamma[tid] : 0.f, pbt = tid < C ? a.xf.beta[tid] : 0.f;   // C <= 64 < 256 threads
+    float pbias[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) pbias[ct] = (ct * 32 + l31 < C && a.bout) ? a.bout[ct * 32 + l31] : 0.f;
     for (int i = tid; i < C * (LHID / 4); i += 256) {
         const int cc = i / (LHID / 4), j = (i - cc * (LHID / 4)) * 4;
         *reinterpret_cast<float4*>(Wq + cc * LHID + j) = *reinterpret_cast<const float4*>(a.wqkv + (size_t)cc * LC3 + j);
@@ -429,6 +433,15 @@ __global__ void __launch_bounds__(256) la_apply_fast_kernel(const LaArgs a, int 
         Wo[i] = c < C ? a.wout[(size_t)k * C + c] : 0.f;
     }
     for (int i = tid; i < LHEADS * LDH * LDH; i += 256) ctxl[(i >> 5) * PS + (i & 31)] = a.ctx[(size_t)b * LHEADS * LDH * LDH + i];
+    {
+        float mean, rstd;
+        partials_finish(a.xf, b, 0, pp, &mean, &rstd);
+        if (tid < C) {
+            const float s = rstd * pg;
+            Ab[tid] = s;
+            Bb[tid] = pbt - mean * s;
+        }
+    }
     __syncthreads();
     float* xw = xt + wave * 32 * XS;
     const float scale = 0.17677669529663687f;
@@ -498,7 +511,7 @@ __global__ void __launch_bounds__(256) la_apply_fast_kernel(const LaArgs a, int 
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const int c = ct * 32 + l31;
-            const float bias = (c < C && a.bout) ? a.bout[c] : 0.f;
+            const float bias = pbias[ct];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = y[ct][r] + bias;

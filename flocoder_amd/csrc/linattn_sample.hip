@@ -274,13 +274,20 @@ __global__ void __launch_bounds__(JT) la_join_kernel(const LaArgs a) {
     const int b = blockIdx.x, tid = threadIdx.x, C = a.C, total4 = a.n * C / 4;
     const size_t per = (size_t)a.n * C;
     const float* pb = a.part + (size_t)b * HEADS * per;
-    float4 v[EPT];
+    const float* xb = a.x + (size_t)b * per;
+    float* ob = a.out + (size_t)b * per;
+    float4 v[EPT], xv[EPT], gv[EPT], bev[EPT];   // residual and norm parameters requested with the shares: nothing cold after the reductions
     float S = 0.f;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int i = tid + e * JT;
-        v[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        v[e] = xv[e] = gv[e] = bev[e] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < total4) {
+            xv[e] = *reinterpret_cast<const float4*>(xb + (size_t)i * 4);
+            if (GN) {
+                gv[e] = *reinterpret_cast<const float4*>(a.g2 + (i * 4) % C);
+                bev[e] = *reinterpret_cast<const float4*>(a.b2 + (i * 4) % C);
+            }
             const float4 p0 = *reinterpret_cast<const float4*>(pb + (size_t)i * 4), p1 = *reinterpret_cast<const float4*>(pb + per + (size_t)i * 4);
             const float4 p2 = *reinterpret_cast<const float4*>(pb + 2 * per + (size_t)i * 4), p3 = *reinterpret_cast<const float4*>(pb + 3 * per + (size_t)i * 4);
             const float4 bi = *reinterpret_cast<const float4*>(a.bout + (i * 4) % C);
@@ -302,17 +309,14 @@ __global__ void __launch_bounds__(JT) la_join_kernel(const LaArgs a) {
             }
         rs = 1.0f / sqrtf(block_sum_j(Q, red) / cnt + a.eps2);
     }
-    const float* xb = a.x + (size_t)b * per;
-    float* ob = a.out + (size_t)b * per;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int i = tid + e * JT;
         if (i < total4) {
-            const float4 x = *reinterpret_cast<const float4*>(xb + (size_t)i * 4);
+            const float4 x = xv[e];
             float4 o;
             if (GN) {
-                const int c = (i * 4) % C;
-                const float4 g = *reinterpret_cast<const float4*>(a.g2 + c), be = *reinterpret_cast<const float4*>(a.b2 + c);
+                const float4 g = gv[e], be = bev[e];
                 o.x = ((v[e].x - mu) * rs * g.x + be.x) + x.x; o.y = ((v[e].y - mu) * rs * g.y + be.y) + x.y;
                 o.z = ((v[e].z - mu) * rs * g.z + be.z) + x.z; o.w = ((v[e].w - mu) * rs * g.w + be.w) + x.w;
             } else {

@@ -46,6 +46,44 @@ __device__ __forceinline__ void combine_partials(const SrcXform& xf, int b, int 
     *rstd_out = 1.0f / sqrtf(var + xf.eps);
 }
 
+// The same in two halves for kernels whose prologue has other cold loads to request: request() only issues the loads of the
+// first kPartPre partial pairs (a following block of loads then shares their round trip), finish() does the arithmetic of
+// combine_partials in the same order (slots beyond kPartPre, rare, are read there).
+constexpr int kPartPre = 8;
+struct PartPre { float m[kPartPre], q[kPartPre]; };
+__device__ __forceinline__ void partials_request(const SrcXform& xf, int b, int g, PartPre& r) {
+    const float* sp = xf.stats + (size_t)(b * xf.G + g) * xf.T * 2;
+#pragma unroll
+    for (int t = 0; t < kPartPre; ++t) {
+        r.m[t] = t < xf.T ? sp[2 * t] : 0.f;
+        r.q[t] = t < xf.T ? sp[2 * t + 1] : 0.f;
+    }
+}
+__device__ __forceinline__ void partials_finish(const SrcXform& xf, int b, int g, const PartPre& r, float* mean_out, float* rstd_out) {
+    const float* sp = xf.stats + (size_t)(b * xf.G + g) * xf.T * 2;
+    float sm = 0.f;
+#pragma unroll
+    for (int t = 0; t < kPartPre; ++t) if (t < xf.T) sm += r.m[t];
+    for (int t = kPartPre; t < xf.T; ++t) sm += sp[2 * t];
+    const float mean = sm / (float)xf.T;
+    float m2 = 0.f, dv = 0.f;
+#pragma unroll
+    for (int t = 0; t < kPartPre; ++t)
+        if (t < xf.T) {
+            const float d = r.m[t] - mean;
+            m2 += r.q[t];
+            dv += d * d;
+        }
+    for (int t = kPartPre; t < xf.T; ++t) {
+        const float d = sp[2 * t] - mean;
+        m2 += sp[2 * t + 1];
+        dv += d * d;
+    }
+    const float var = (m2 + xf.n_t * dv) / (xf.n_t * (float)xf.T);
+    *mean_out = mean;
+    *rstd_out = 1.0f / sqrtf(var + xf.eps);
+}
+
 __device__ __forceinline__ float silu_grad_e(float z) {   // d/dz [z sigmoid(z)]
     const float s = 1.0f / (1.0f + __expf(-z));
     return s * (1.0f + z * (1.0f - s));
