@@ -21,7 +21,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define FC_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 namespace {
-constexpr int DH = 32, HEADS = 4, HID = HEADS * DH, C3 = 3 * HID, QS = 3 * DH + 1, PS = 33, PF = 16, JT = 512;
+constexpr int DH = 32, HEADS = 4, HID = HEADS * DH, C3 = 3 * HID, QS = 3 * DH + 1, PS = 33, PF = 16, JT = 512, XPT = 16;
 
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
@@ -67,29 +67,54 @@ __global__ void __launch_bounds__(256) la_head_kernel(const LaArgs a) {
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const float* xb = a.x + (size_t)b * n * C;
 
-    // weights do not depend on anything computed here: first batch in flight before the statistics are even read
+    // Nothing requested here depends on anything computed here, and inside a sampler step all of it is cold: the first round of
+    // weights, the x tile and the norm parameters are in flight before the statistics are read -- one memory round trip for the
+    // whole prologue instead of four dependent ones.
     const float* wp = a.wqkv + (size_t)half * C3 + (wave < 3 ? wave : 0) * HID + h * DH + l31;
     float cur[PF];
     if (wave < 3) wfetch(wp, C3, 0, cur);
-
+    const int q4 = C >> 2, nx = n * q4;            // float4's of the (unpadded) x tile: at most XPT per thread
+    float4 xr[XPT];
+#pragma unroll
+    for (int k = 0; k < XPT; ++k) {
+        const int i = tid + 256 * k;
+        xr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < nx) xr[k] = *reinterpret_cast<const float4*>(xb + (size_t)i * 4);
+    }
+    float pg[2], pbt[2];                           // C <= 512: two channels per thread
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int c = tid + 256 * k;
+        pg[k] = c < C ? a.xf.gamma[c] : 0.f;
+        pbt[k] = c < C ? a.xf.beta[c] : 0.f;
+    }
     float mean, rstd;
     combine_partials(a.xf, b, 0, &mean, &rstd);
-    for (int c = tid; c < C; c += 256) {
-        const float s = rstd * a.xf.gamma[c];
-        Ab[c] = s;
-        Bb[c] = a.xf.beta[c] - mean * s;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int c = tid + 256 * k;
+        if (c < C) {
+            const float sc = rstd * pg[k];
+            Ab[c] = sc;
+            Bb[c] = pbt[k] - mean * sc;
+        }
+    }
+    for (int i = tid + nx; i < NP * q4; i += 256) {     // padding rows
+        const int row = i / q4, c = (i - row * q4) * 4;
+        float* d = xs + row * XS + c;
+        d[0] = 0.f; d[1] = 0.f; d[2] = 0.f; d[3] = 0.f;
     }
     __syncthreads();
-    const int q4 = C >> 2;
-    for (int i = tid; i < NP * q4; i += 256) {
-        const int row = i / q4, c = (i - row * q4) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < n) {
-            v = *reinterpret_cast<const float4*>(xb + (size_t)row * C + c);
+#pragma unroll
+    for (int k = 0; k < XPT; ++k) {
+        const int i = tid + 256 * k;
+        if (i < nx) {
+            const int row = i / q4, c = (i - row * q4) * 4;
+            float4 v = xr[k];
             v.x = Ab[c] * v.x + Bb[c]; v.y = Ab[c + 1] * v.y + Bb[c + 1]; v.z = Ab[c + 2] * v.z + Bb[c + 2]; v.w = Ab[c + 3] * v.w + Bb[c + 3];
+            float* d = xs + row * XS + c;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
-        float* d = xs + row * XS + c;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
     __syncthreads();
 
@@ -150,10 +175,23 @@ __global__ void __launch_bounds__(256) la_head_kernel(const LaArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) dst[(mt * 32 + acc_row(r, half)) * QS] = acc[mt][r];
     } else {
+        // the head's 32 rows of to_out.0, sixteen 16-byte loads in flight per lane (a load -> store loop here was 32 dependent cold
+        // round trips, 26 k cycles, and the whole workgroup waited for it at the barrier below)
         const float* wo = a.wout + (size_t)h * DH * C;
-        for (int i = lane; i < DH * q4; i += 64) {
-            const int k = i / q4, c = (i - k * q4) * 4;
-            *reinterpret_cast<float4*>(Wo + k * WS + c) = *reinterpret_cast<const float4*>(wo + (size_t)k * C + c);
+        const int tot = DH * q4;
+        for (int i0 = lane; i0 < tot; i0 += 64 * 16) {
+            float4 wv[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int i = i0 + 64 * k;
+                wv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < tot) { const int r = i / q4, c = (i - r * q4) * 4; wv[k] = *reinterpret_cast<const float4*>(wo + (size_t)r * C + c); }
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int i = i0 + 64 * k;
+                if (i < tot) { const int r = i / q4, c = (i - r * q4) * 4; *reinterpret_cast<float4*>(Wo + r * WS + c) = wv[k]; }
+            }
         }
     }
     __syncthreads();
@@ -354,7 +392,8 @@ int linattn_sample_init() {
 }
 
 bool linattn_sample_supported(int n, int C, int heads) {
-    return heads == HEADS && n >= 1 && n <= 64 && (C % 32) == 0 && C >= 32 && n * C <= 8 * JT * 4 && head_lds(n, C) <= 160 * 1024;
+    return heads == HEADS && n >= 1 && n <= 64 && (C % 32) == 0 && C >= 32 && C <= 512 && n * C <= 8 * JT * 4 && n * C <= XPT * 256 * 4 &&
+           head_lds(n, C) <= 160 * 1024;
 }
 
 bool attn_sample_supported(int n, int C, int heads) { return linattn_sample_supported(n, C, heads) && C >= (n <= 32 ? 32 : 64); }
