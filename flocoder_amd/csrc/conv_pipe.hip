@@ -17,6 +17,7 @@
 // A loader thread's patch elements are the same pixels for every chunk (only the channel base moves): their source
 // offsets live in registers and the per-(sample, channel) affine table is built once for all Cin.
 #include "conv_dev.h"
+#include "stats_dev.h"
 
 namespace fc {
 
@@ -144,15 +145,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
             const int j = first ? i : i - p.TB * G0;
             const int tb = j / xf.G, g = j - tb * xf.G, b = b0 + tb;
             float mean = 0.f, rstd = 0.f;
-            if (b < a.B) {
-                const float* sp = xf.stats + (size_t)(b * xf.G + g) * xf.T * 2;
-                float sm = 0.f;
-                for (int t = 0; t < xf.T; ++t) sm += sp[2 * t];
-                mean = sm / (float)xf.T;
-                float m2 = 0.f, dv = 0.f;
-                for (int t = 0; t < xf.T; ++t) { const float d = sp[2 * t] - mean; m2 += sp[2 * t + 1]; dv += d * d; }
-                rstd = 1.0f / sqrtf((m2 + xf.n_t * dv) / (xf.n_t * (float)xf.T) + xf.eps);
-            }
+            if (b < a.B) combine_partials(xf, b, g, &mean, &rstd);   // all partial pairs requested at once (stats_dev.h)
             gstat[2 * i] = mean;
             gstat[2 * i + 1] = rstd;
         }

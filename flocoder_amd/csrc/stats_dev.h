@@ -29,26 +29,9 @@ __device__ __forceinline__ float block_sum_lds(float v, float* red /*[4]*/) {   
     return red[0] + red[1] + red[2] + red[3];
 }
 
-// combine T equal-count (mean, M2) partials of group g of sample b
-__device__ __forceinline__ void combine_partials(const SrcXform& xf, int b, int g, float* mean_out, float* rstd_out) {
-    const float* sp = xf.stats + (size_t)(b * xf.G + g) * xf.T * 2;
-    float sm = 0.f;
-    for (int t = 0; t < xf.T; ++t) sm += sp[2 * t];
-    const float mean = sm / (float)xf.T;
-    float m2 = 0.f, dv = 0.f;
-    for (int t = 0; t < xf.T; ++t) {
-        const float d = sp[2 * t] - mean;
-        m2 += sp[2 * t + 1];
-        dv += d * d;
-    }
-    const float var = (m2 + xf.n_t * dv) / (xf.n_t * (float)xf.T);
-    *mean_out = mean;
-    *rstd_out = 1.0f / sqrtf(var + xf.eps);
-}
-
-// The same in two halves for kernels whose prologue has other cold loads to request: request() only issues the loads of the
-// first kPartPre partial pairs (a following block of loads then shares their round trip), finish() does the arithmetic of
-// combine_partials in the same order (slots beyond kPartPre, rare, are read there).
+// (mean, M2) partials of a GroupNorm group in two halves: request() only issues the loads of the first kPartPre partial pairs (a
+// following block of loads then shares their round trip), finish() combines T equal-count partials in slot order (slots beyond
+// kPartPre, rare, are read there).
 constexpr int kPartPre = 8;
 struct PartPre { float m[kPartPre], q[kPartPre]; };
 __device__ __forceinline__ void partials_request(const SrcXform& xf, int b, int g, PartPre& r) {
@@ -82,6 +65,15 @@ __device__ __forceinline__ void partials_finish(const SrcXform& xf, int b, int g
     const float var = (m2 + xf.n_t * dv) / (xf.n_t * (float)xf.T);
     *mean_out = mean;
     *rstd_out = 1.0f / sqrtf(var + xf.eps);
+}
+
+// combine T equal-count (mean, M2) partials of group g of sample b.  All (up to kPartPre) partial pairs are requested before the
+// first one is used: written as `for t < T: sum += sp[2 t]` the loads become T dependent round trips (the trip count is a run-time
+// value, so the compiler keeps the loop), twice over -- several microseconds at the head of every kernel that normalises its input.
+__device__ __forceinline__ void combine_partials(const SrcXform& xf, int b, int g, float* mean_out, float* rstd_out) {
+    PartPre r;
+    partials_request(xf, b, g, r);
+    partials_finish(xf, b, g, r, mean_out, rstd_out);
 }
 
 __device__ __forceinline__ float silu_grad_e(float z) {   // d/dz [z sigmoid(z)]
