@@ -148,8 +148,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
             const bool live = i < p.TB * BN;
             const int tb = live ? i / BN : 0, col = live ? i - tb * BN : 0;
             float s = 0.f, q = 0.f;
-            if (live)
+            if (live) {
+#pragma unroll 8
                 for (int h = 0; h < hb_per; ++h) { s += partS[(tb * hb_per + h) * BN + col]; q += partQ[(tb * hb_per + h) * BN + col]; }
+            }
             for (int o = cpgt >> 1; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
             const int b = b0 + tb;
             if (live && (col & (cpgt - 1)) == 0 && col < ncols && b < a.B) {

@@ -89,7 +89,8 @@ __global__ void __launch_bounds__(kCondThreads) cond_hidden_kernel(const TembArg
     const int K = cls ? a.td : a.dim, half = a.dim / 2;
     float* xs = sm;
     float* red = sm + (size_t)2 * a.td * SB;
-    for (int i = tid; i < K * SB; i += kCondThreads) {
+#pragma unroll 4
+    for (int i = tid; i < K * SB; i += kCondThreads) {   // unrolled: the staged loads are cold, a rolled loop is one round trip per pass
         const int k = i / SB, q = i % SB, b = b0 + q;
         float v = 0.f;
         if (b < a.B) {
@@ -124,7 +125,8 @@ __global__ void __launch_bounds__(kCondThreads) cond_out_kernel(const TembArgs a
     float* xs = sm;
     float* red = sm + (size_t)2 * td * SB;
     const int K = with_class ? 2 * td : td;
-    for (int i = tid; i < K * SB; i += kCondThreads) {
+#pragma unroll 4
+    for (int i = tid; i < K * SB; i += kCondThreads) {   // unrolled: the staged loads are cold, a rolled loop is one round trip per pass
         const int k = i / SB, b = b0 + i % SB;
         float v = 0.f;
         if (b < a.B) {
@@ -188,6 +190,7 @@ __global__ void __launch_bounds__(kCondThreads) ss_kernel(const float* __restric
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, b0 = blockIdx.y * SB;
     float* xs = sm;
     float* red = sm + (size_t)2 * td * SB;
+#pragma unroll 4
     for (int i = tid; i < td * SB; i += kCondThreads) {
         const int k = i / SB, b = b0 + i % SB;
         const float v = b < B ? t[(size_t)b * td + k] : 0.f;
