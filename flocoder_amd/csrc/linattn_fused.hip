@@ -317,10 +317,17 @@ __global__ void __launch_bounds__(256) la_ctx_fast_kernel(const LaArgs a) {
     PartPre pp;
     partials_request(a.xf, b, 0, pp);
     const float pg = tid < C ? a.xf.gamma[tid] : 0.f, pbt = tid < C ? a.xf.beta[tid] : 0.f;   // C <= 64 < 256 threads
-    for (int i = tid; i < C * 64; i += 256) {
-        const int c = i >> 6, j = i & 63;
-        Wl[i] = a.wqkv[(size_t)c * LC3 + (j < 32 ? LHID + h * LDH + j : 2 * LHID + h * LDH + (j - 32))];
+    // explicit registers: written as a load -> LDS store loop the compiler waits for every load before the next (ISA: vmcnt(0) per
+    // iteration) -- dependent cold round trips at the head of the kernel
+    constexpr int NWL = C / 4;
+    float wl[NWL];
+#pragma unroll
+    for (int k = 0; k < NWL; ++k) {
+        const int i = tid + 256 * k, c = i >> 6, j = i & 63;
+        wl[k] = a.wqkv[(size_t)c * LC3 + (j < 32 ? LHID + h * LDH + j : 2 * LHID + h * LDH + (j - 32))];
     }
+#pragma unroll
+    for (int k = 0; k < NWL; ++k) Wl[tid + 256 * k] = wl[k];
     float mean, rstd;
     partials_finish(a.xf, b, 0, pp, &mean, &rstd);
     if (tid < C) {
@@ -424,15 +431,36 @@ __global__ void __launch_bounds__(256) la_apply_fast_kernel(const LaArgs a, int 
     float pbias[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) pbias[ct] = (ct * 32 + l31 < C && a.bout) ? a.bout[ct * 32 + l31] : 0.f;
-    for (int i = tid; i < C * (LHID / 4); i += 256) {
-        const int cc = i / (LHID / 4), j = (i - cc * (LHID / 4)) * 4;
-        *reinterpret_cast<float4*>(Wq + cc * LHID + j) = *reinterpret_cast<const float4*>(a.wqkv + (size_t)cc * LC3 + j);
+    // Wq, Wout and the context into explicit registers first, LDS after: as load -> store loops they were 4 + 8 + 16 dependent round
+    // trips (ISA: s_waitcnt vmcnt(0) inside each loop), about half of this kernel's 30 us inside a sampler step
+    constexpr int NWO = WO / 2;
+    float4 wq[NQ], cx[4];
+    float wo[NWO];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        const int i = tid + 256 * k, cc = i / (LHID / 4), j = (i - cc * (LHID / 4)) * 4;
+        wq[k] = *reinterpret_cast<const float4*>(a.wqkv + (size_t)cc * LC3 + j);
     }
-    for (int i = tid; i < LHID * WO; i += 256) {
-        const int k = i / WO, c = i - k * WO;
-        Wo[i] = c < C ? a.wout[(size_t)k * C + c] : 0.f;
+#pragma unroll
+    for (int k = 0; k < NWO; ++k) {
+        const int i = tid + 256 * k, kk = i / WO, c = i - kk * WO;
+        wo[k] = c < C ? a.wout[(size_t)kk * C + c] : 0.f;
     }
-    for (int i = tid; i < LHEADS * LDH * LDH; i += 256) ctxl[(i >> 5) * PS + (i & 31)] = a.ctx[(size_t)b * LHEADS * LDH * LDH + i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cx[k] = *reinterpret_cast<const float4*>(a.ctx + (size_t)b * LHEADS * LDH * LDH + 4 * (tid + 256 * k));
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        const int i = tid + 256 * k, cc = i / (LHID / 4), j = (i - cc * (LHID / 4)) * 4;
+        *reinterpret_cast<float4*>(Wq + cc * LHID + j) = wq[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NWO; ++k) Wo[tid + 256 * k] = wo[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = 4 * (tid + 256 * k);
+        float* d = ctxl + (i >> 5) * PS + (i & 31);
+        d[0] = cx[k].x; d[1] = cx[k].y; d[2] = cx[k].z; d[3] = cx[k].w;
+    }
     {
         float mean, rstd;
         partials_finish(a.xf, b, 0, pp, &mean, &rstd);
