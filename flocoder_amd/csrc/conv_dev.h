@@ -106,6 +106,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
         }
     }
 
+    // pixel index (b * H + y) * W + x of accumulator row r of M tile mt in this lane, or -1 for a sample beyond B
+    auto pix_of = [&](int mt, int r) {
+        const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int tw = m & (TW - 1), th = (m >> p.TWl) & (TH - 1), tb = m >> (p.TWl + p.THl);
+        const int b = b0 + tb;
+        return b < a.B ? (b * a.H + y0 + th) * a.W + x0 + tw : -1;
+    };
     conv_stamp(p, 6);
     const bool owner = active && (wk == 0);
     const bool fin = a.fin.gamma != nullptr;
@@ -191,15 +198,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mt][nt][r] += bias;
                 if (a.stats_post) {   // statistics of the FINAL value (activation and residual included): pre-norm resnets (SD-VAE)
+                    // all sixteen residual values requested before the first is used (row by row it was sixteen dependent round trips)
+                    float ad[16];
+                    const bool addp = a.add && nok;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        const int tw = m & (TW - 1), th = (m >> p.TWl) & (TH - 1), tb = m >> (p.TWl + p.THl);
-                        const int b = b0 + tb;
+                        const int px = pix_of(mt, r);
+                        ad[r] = (addp && px >= 0) ? a.add[(size_t)px * Cout + n] : 0.f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
                         float v = acc[mt][nt][r];
                         if (a.out_act) v = silu_f(v);
-                        if (a.add && nok && b < a.B) v += a.add[((size_t)(b * a.H + y0 + th) * a.W + x0 + tw) * Cout + n];
-                        acc[mt][nt][r] = v;
+                        acc[mt][nt][r] = v + ad[r];
                     }
                 }
             }
@@ -267,16 +278,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                     const bool nok = n < Cout;
                     const int gl = p.cpg >= BN ? 0 : ncol / p.cpg;
                     const float gam = pre ? pre[2 * NT + nt] : (nok ? a.fin.gamma[n] : 0.f), bet = pre ? pre[3 * NT + nt] : (nok ? a.fin.beta[n] : 0.f);
+                    float rs[16];   // residual: all sixteen rows requested before the first is used
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int px = pix_of(mt, r);
+                        rs[r] = (a.fin.res && nok && px >= 0) ? a.fin.res[(size_t)px * Cout + n] : 0.f;
+                    }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        const int tw = m & (TW - 1), th = (m >> p.TWl) & (TH - 1), tb = m >> (p.TWl + p.THl);
-                        const int b = b0 + tb;
+                        const int tb = m >> (p.TWl + p.THl);
                         const float mean = tab[2 * (tb * ngt + gl)], rstd = tab[2 * (tb * ngt + gl) + 1];
                         const float A = rstd * gam;
-                        float v = silu_f(A * acc[mt][nt][r] + (bet - mean * A));
-                        if (a.fin.res && nok && b < a.B) v += a.fin.res[((size_t)(b * a.H + y0 + th) * a.W + x0 + tw) * Cout + n];
-                        acc[mt][nt][r] = (nok && b < a.B) ? v : 0.f;
+                        const float v = silu_f(A * acc[mt][nt][r] + (bet - mean * A)) + rs[r];
+                        acc[mt][nt][r] = (nok && b0 + tb < a.B) ? v : 0.f;
                     }
                 }
         }
@@ -300,12 +315,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
         for (int mt = 0; mt < MT; ++mt) {
             int pix[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int tw = m & (TW - 1), th = (m >> p.TWl) & (TH - 1), tb = m >> (p.TWl + p.THl);
-                const int b = b0 + tb;
-                pix[r] = b < a.B ? (b * a.H + y0 + th) * a.W + x0 + tw : -1;
-            }
+            for (int r = 0; r < 16; ++r) pix[r] = pix_of(mt, r);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int ncol = (wn * NT + nt) * 32 + l31, n = n0 + ncol;
