@@ -256,10 +256,77 @@ __global__ void __launch_bounds__(256) final_conv_kernel(const float* x, const f
     }
 }
 
+// The usual shapes (Cout <= 4 latent channels, Cin = dim a compile-time constant): one pixel per thread with its whole input row and
+// its state values requested up front.  In the generic kernel above the channel loop stays rolled with a wait per 16-byte load
+// (run-time Cin), eight dependent cold round trips per pixel inside a sampler step.
+template <int CIN>
+__global__ void __launch_bounds__(256) final_conv_small_kernel(const float* x, const float* w, const float* bias, float* out, int B, int HW,
+                                                               int Cout, const EulerTail e) {
+    __shared__ float wsm[CIN * 4 + 4];
+    const size_t total = (size_t)B * HW, i = blockIdx.x * 256ull + threadIdx.x;
+    float4 xv[CIN / 4];
+    float yv[4] = {0.f, 0.f, 0.f, 0.f};
+    const int pix = (int)(i % HW), b = (int)(i / HW);
+    if (i < total) {
+#pragma unroll
+        for (int k = 0; k < CIN / 4; ++k) xv[k] = *reinterpret_cast<const float4*>(x + i * CIN + 4 * k);
+        if (e.y) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (j < Cout) yv[j] = e.y[((size_t)b * Cout + j) * HW + pix];
+        }
+    }
+    for (int k = threadIdx.x; k < CIN * 4; k += 256) wsm[k] = (k & 3) < Cout ? w[(k >> 2) * Cout + (k & 3)] : 0.f;   // [CIN][4]
+    if (threadIdx.x < 4) wsm[CIN * 4 + threadIdx.x] = (bias && (int)threadIdx.x < Cout) ? bias[threadIdx.x] : 0.f;
+    __syncthreads();
+    if (i < total) {
+        float acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = wsm[CIN * 4 + j];
+#pragma unroll
+        for (int k = 0; k < CIN / 4; ++k) {
+            const float xs[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] += xs[q] * wsm[(4 * k + q) * 4 + j];   // same order as the generic kernel: ci ascending
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < Cout) {
+                const size_t o = ((size_t)b * Cout + j) * HW + pix;
+                if (e.y) e.y[o] = __fadd_rn(yv[j], __fmul_rn(acc[j], e.dt));    // x + pred * dt
+                else out[o] = acc[j];
+            }
+    }
+    if (e.y && blockIdx.x == 0) {   // what ode_time_kernel does at the head of a step, for the step that follows
+        const int s = *e.step;
+        const float t = e.ts[s];
+        __syncthreads();            // everyone has read the counter before it moves
+        if (threadIdx.x == 0) {
+            e.sc[0] = t;
+            e.sc[1] = 0.f;
+            *e.step = s + 1;
+        }
+        const float tv = __fmul_rn(t, e.t_scale);
+        for (int r = threadIdx.x; r < e.rows; r += 256) e.tvec[r] = tv;
+    }
+}
+
 int final_conv_launch(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int HW, int Cout, const EulerTail& tail,
                       hipStream_t s) {
     if (Cin & 3) return fail(FC_E_SHAPE, "final_conv: Cin must be a multiple of 4");
     const size_t total = (size_t)B * HW;
+    if (Cout <= 4 && total < (1ull << 31) && (Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64)) {
+        const dim3 g((unsigned)((total + 255) / 256));
+        switch (Cin) {
+            case 8: hipLaunchKernelGGL(final_conv_small_kernel<8>, g, dim3(256), 0, s, x, w, bias, out, B, HW, Cout, tail); break;
+            case 16: hipLaunchKernelGGL(final_conv_small_kernel<16>, g, dim3(256), 0, s, x, w, bias, out, B, HW, Cout, tail); break;
+            case 32: hipLaunchKernelGGL(final_conv_small_kernel<32>, g, dim3(256), 0, s, x, w, bias, out, B, HW, Cout, tail); break;
+            default: hipLaunchKernelGGL(final_conv_small_kernel<64>, g, dim3(256), 0, s, x, w, bias, out, B, HW, Cout, tail); break;
+        }
+        FC_HIP(hipGetLastError());
+        return FC_OK;
+    }
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(final_conv_kernel, dim3(grid), dim3(256), (size_t)(Cin * Cout + Cout) * sizeof(float), s, x, w, bias, out, B,
                        Cin, HW, Cout, tail);
