@@ -16,6 +16,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // forward's traffic has passed through the L2 since the last use), so what matters is the number of DEPENDENT load rounds per
 // wave: 32 rows are requested at a time, which makes it one or two rounds at dim 32 (was eight of 8 rows on four waves).
 constexpr int kCondSB = 8, kCondKS = 8, kCondThreads = 64 * kCondKS, kCondPF = 32;
+static_assert(kCondThreads % kCondSB == 0, "a thread stages one sample");
 
 template <int SB>
 __device__ __forceinline__ void dense_rows(const float* __restrict__ xs, const float* __restrict__ wt, int ld, int j, int k0, int k1,
@@ -80,6 +81,26 @@ __device__ __forceinline__ long class_of(const TembArgs& a, int b) {
     return cid >= a.n_classes ? -1 : cid;
 }
 
+// Stage n values into LDS, eight requests in flight per thread: xs[i] = post(*src(i)) (src(i) == nullptr: 0).  Written as a plain
+// `for (i = tid; i < n; i += T) xs[i] = f(global[..])` loop the compiler waits for every load before the next one (tools/isa_audit.py).
+template <class Src, class Post>
+__device__ __forceinline__ void stage8(float* xs, int n, int tid, Src src, Post post) {
+    for (int i0 = tid; i0 < n; i0 += 8 * kCondThreads) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * kCondThreads;
+            const float* p = i < n ? src(i) : nullptr;
+            v[u] = p ? *p : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * kCondThreads;
+            if (i < n) xs[i] = post(v[u]);
+        }
+    }
+}
+
 // grid (ceil(td/64), ceil(B/SB), 1 or 2): z = 0 -> h = gelu(W1 sinemb(t) + b1), z = 1 -> c1 = gelu(CW1 emb[class] + cb1)
 __global__ void __launch_bounds__(kCondThreads) cond_hidden_kernel(const TembArgs a, float* __restrict__ h, float* __restrict__ c1) {
     constexpr int SB = kCondSB;
@@ -89,21 +110,18 @@ __global__ void __launch_bounds__(kCondThreads) cond_hidden_kernel(const TembArg
     const int K = cls ? a.td : a.dim, half = a.dim / 2;
     float* xs = sm;
     float* red = sm + (size_t)2 * a.td * SB;
-#pragma unroll 4
-    for (int i = tid; i < K * SB; i += kCondThreads) {   // unrolled: the staged loads are cold, a rolled loop is one round trip per pass
-        const int k = i / SB, q = i % SB, b = b0 + q;
-        float v = 0.f;
-        if (b < a.B) {
-            if (cls) {
-                const long cid = class_of(a, b);
-                if (cid >= 0) v = a.emb[(size_t)cid * a.td + k];
-            } else {
-                const int kk = k < half ? k : k - half;
-                const float arg = a.time[b] * a.freqs[kk];   // table built on the host exactly as unet.py:26-27 does
-                v = k < half ? sinf(arg) : cosf(arg);
-            }
+    const int myb = b0 + tid % SB;              // this thread's sample, the same in every pass (kCondThreads % SB == 0)
+    if (cls) {
+        const long cid = class_of(a, myb);      // read once: inside the staging loop every staged load waited for an id load
+        const float* erow = a.emb + (size_t)(cid >= 0 ? cid : 0) * a.td;
+        stage8(xs, K * SB, tid, [&](int i) -> const float* { return cid >= 0 ? erow + i / SB : nullptr; }, [](float v) { return v; });
+    } else {
+        const float tb = myb < a.B ? a.time[myb] : 0.f;
+        for (int i = tid; i < K * SB; i += kCondThreads) {
+            const int k = i / SB, kk = k < half ? k : k - half;
+            const float arg = tb * a.freqs[kk];   // table built on the host exactly as unet.py:26-27 does
+            xs[i] = myb < a.B ? (k < half ? sinf(arg) : cosf(arg)) : 0.f;
         }
-        xs[i] = v;
     }
     __syncthreads();
     const int j = blockIdx.x * 64 + lane, jj = min(j, a.td - 1);
@@ -125,16 +143,17 @@ __global__ void __launch_bounds__(kCondThreads) cond_out_kernel(const TembArgs a
     float* xs = sm;
     float* red = sm + (size_t)2 * td * SB;
     const int K = with_class ? 2 * td : td;
-#pragma unroll 4
-    for (int i = tid; i < K * SB; i += kCondThreads) {   // unrolled: the staged loads are cold, a rolled loop is one round trip per pass
-        const int k = i / SB, b = b0 + i % SB;
-        float v = 0.f;
-        if (b < a.B) {
-            if (k < td) v = h[(size_t)b * td + k];
-            else if (class_of(a, b) >= 0) v = c1[(size_t)b * td + (k - td)];
-        }
-        xs[i] = v;
-    }
+    const int myb = b0 + tid % SB;                                         // this thread's sample, the same in every pass
+    const bool my_class = with_class && class_of(a, myb) >= 0;
+    const float* hrow = h + (size_t)min(myb, a.B - 1) * td;
+    const float* crow = c1 + (size_t)min(myb, a.B - 1) * td;
+    stage8(xs, K * SB, tid,
+           [&](int i) -> const float* {
+               const int k = i / SB;
+               if (myb >= a.B || !(k < td || my_class)) return nullptr;
+               return k < td ? hrow + k : crow + (k - td);
+           },
+           [](float v) { return v; });
     __syncthreads();
     const int j = blockIdx.x * 64 + lane, jj = min(j, td - 1);
     int k0, k1;
@@ -190,12 +209,10 @@ __global__ void __launch_bounds__(kCondThreads) ss_kernel(const float* __restric
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, b0 = blockIdx.y * SB;
     float* xs = sm;
     float* red = sm + (size_t)2 * td * SB;
-#pragma unroll 4
-    for (int i = tid; i < td * SB; i += kCondThreads) {
-        const int k = i / SB, b = b0 + i % SB;
-        const float v = b < B ? t[(size_t)b * td + k] : 0.f;
-        xs[i] = v / (1.0f + expf(-v));
-    }
+    const int myb = b0 + tid % SB;              // this thread's sample, the same in every pass
+    const float* trow = t + (size_t)min(myb, B - 1) * td;
+    stage8(xs, td * SB, tid, [&](int i) -> const float* { return myb < B ? trow + i / SB : nullptr; },
+           [](float v) { return v / (1.0f + expf(-v)); });
     __syncthreads();
     const int j = blockIdx.x * 64 + lane, jj = min(j, S - 1);
     float acc[SB] = {};
