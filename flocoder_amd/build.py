@@ -30,10 +30,11 @@ def _headers_mtime():
     return max(os.path.getmtime(h) for h in hs)
 
 
-def _compile(src: str, force: bool) -> str:
+def _compile(src: str, force: bool, built: list) -> str:
     obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
     stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), _headers_mtime())
     if stale:
+        built.append(src)
         cmd = [HIPCC, *FLAGS, "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -43,19 +44,28 @@ def _compile(src: str, force: bool) -> str:
     return obj
 
 
+LAST_BUILD = {"rebuilt": 0, "units": 0, "linked": False}
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile what is stale (everything with ``force``) and link.  ``LAST_BUILD`` records how many units were really compiled, so a
+    caller can tell a build from a cache hit."""
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = _sources()
+    built: list = []
     with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force), srcs))
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
+        objs = list(ex.map(lambda s: _compile(s, force, built), srcs))
+    relink = force or bool(built) or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs)
+    LAST_BUILD.update(rebuilt=len(built), units=len(srcs), linked=relink)
+    if relink:
         cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     if verbose:
-        print(f"[flocoder_amd.build] {LIB} ({os.path.getsize(LIB) / 1e6:.2f} MB)")
+        print(f"[flocoder_amd.build] rebuilt {len(built)}/{len(srcs)} units, {'linked' if relink else 'link up to date'}: "
+              f"{LIB} ({os.path.getsize(LIB) / 1e6:.2f} MB)")
     return LIB
 
 

@@ -145,6 +145,10 @@ class SD_VAE_Wrapper(nn.Module):
         self._synced = None
 
     # ---- native object
+    def mark_dirty(self) -> None:
+        """Re-upload the weights on the next use (for writes that bypass the (data_ptr, _version) key, e.g. ``p.data.copy_``)."""
+        self._synced = None
+
     def _native(self, device):
         lib = B.lib()
         if self._handle is None or self._handle_device != device:
@@ -351,6 +355,10 @@ class VQVAE(nn.Module):
         self.register_buffer('codebook_usage', torch.zeros(codebook_levels, vq_num_embeddings))
         self.usage_count = 0
         self._handle, self._handle_device, self._synced = None, None, None
+
+    def mark_dirty(self) -> None:
+        """Re-upload the weights on the next use (for writes that bypass the (data_ptr, _version) key, e.g. ``p.data.copy_``)."""
+        self._synced = None
 
     def _native(self, device):
         lib = B.lib()

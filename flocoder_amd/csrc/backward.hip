@@ -584,13 +584,16 @@ int sin_emb_launch(const float* time, const float* freqs, float* e, int B, int d
     FC_HIP(hipGetLastError());
     return FC_OK;
 }
-__global__ void __launch_bounds__(256) gather_rows_kernel(const float* table, const int64_t* ids, float* out, int B, int D) {
+// An id outside [0, R) contributes nothing, exactly as the forward treats it (temb.hip class_of): no out-of-bounds read, forward and
+// backward agree.  (The host mirror raises IndexError for such ids before they get here, as nn.Embedding does upstream.)
+__global__ void __launch_bounds__(256) gather_rows_kernel(const float* table, const int64_t* ids, float* out, int B, int D, int R) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= B * D) return;
-    out[t] = table[(size_t)ids[t / D] * D + t % D];
+    const int64_t id = ids[t / D];
+    out[t] = (id >= 0 && id < R) ? table[(size_t)id * D + t % D] : 0.f;
 }
-int gather_rows_launch(const float* table, const int64_t* ids, float* out, int B, int D, hipStream_t s) {
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(B * D, 256)), dim3(256), 0, s, table, ids, out, B, D);
+int gather_rows_launch(const float* table, const int64_t* ids, float* out, int B, int D, int R, hipStream_t s) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(B * D, 256)), dim3(256), 0, s, table, ids, out, B, D, R);
     FC_HIP(hipGetLastError());
     return FC_OK;
 }

@@ -52,6 +52,14 @@ __global__ void __launch_bounds__(64) ot_sweep_kernel(const float* dist, int B, 
             const int oj = __shfl_xor(bj, o);
             if (ov < best || (ov == best && oj < bj)) { best = ov; bj = oj; }
         }
+        if (bj == 0x7fffffff) {   // no finite minimum in this row (NaN / inf distances): take the first unused column, keep perm a permutation
+            for (int q = 0; q < per; ++q) {
+                const int j = q * 64 + lane;
+                if (j < B && !((used >> q) & 1ull)) { bj = j; break; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const int oj = __shfl_xor(bj, o); bj = oj < bj ? oj : bj; }
+        }
         if ((bj & 63) == lane) used |= 1ull << (bj >> 6);
         if (lane == 0) perm[i] = bj;
     }

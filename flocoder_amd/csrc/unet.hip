@@ -706,6 +706,7 @@ int fc_unet_reserve(fc_unet* u, int max_batch, int height, int width) {
     FC_HIP(hipSetDevice(u->device));
     FC_HIP(hipDeviceSynchronize());
     free_plan(u);
+    u->arena_touched(0);
     static const int want_chains = [] { const char* e = std::getenv("FLOCODER_AMD_CHAINS"); return e ? std::atoi(e) : 1; }();   // measured: 2 half-batch chains 404 vs 1 chain 446 samples/s (profiles/r01_c_*)
     u->nchains = (want_chains >= 2 && max_batch >= 2) ? 2 : 1;
     const int rows0 = u->nchains == 2 ? (max_batch + 1) / 2 : max_batch;
@@ -735,8 +736,11 @@ int fc_unet_forward(fc_unet* u, const float* x, const float* time, const int64_t
     c.mask = u->cfg.mask_cond ? mask : nullptr;
     c.mask_fuse = (c.mask && !mask_is_ones) ? 1 : 0;
     c.out = out; c.B = B;
+    u->arena_touched(u->keep_all ? B : 0);
     return run_forward(u, c, static_cast<hipStream_t>(stream));
 }
+
+uint64_t fc_unet_arena_serial(const fc_unet* u) { return u ? u->arena_serial : 0; }
 
 // Time every launch of the current plan on its own: each op is enqueued `repeats` times back to back between two
 // events on `stream` (ops are idempotent: they only read their inputs), so host launch gaps do not pollute kernels
@@ -746,6 +750,7 @@ int fc_unet_profile_ops(fc_unet* u, int batch, int repeats, float* ms_out, int n
     FC_TRY(check_ready(u, batch, u->H, u->W));
     const Plan& pl0 = u->plan[0];
     if (batch > pl0.maxB) batch = pl0.maxB;   // ops are timed on chain 0's plan, at the rows one chain carries
+    u->arena_touched(0);
     const int n = (int)pl0.ops.size();
     if (n_out < n) return fail(FC_E_ARG, "fc_unet_profile_ops: output array too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -849,6 +854,7 @@ int fc_unet_integrate(fc_unet* u, int method, float* x_dev, int B, int H, int W,
     const bool cfg_on = has_ids && cfg_strength != 0.0f;   // sampling.py:69
     const int rows = cfg_on ? 2 * B : B;
     FC_TRY(check_ready(u, rows, H, W));
+    u->arena_touched(0);
     const int mask_mode = (mask && u->cfg.mask_cond) ? (mask_is_ones ? 2 : 1) : 0;
     const int n_steps = method == FC_METHOD_RK4 ? n_points - 1 : n_points;
     hipStream_t caller = static_cast<hipStream_t>(stream), s = u->stream;

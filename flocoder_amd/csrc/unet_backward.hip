@@ -479,7 +479,7 @@ int build_backward(fc_unet* u) {
                           c3w = b.off("class_cond_mlp.3.weight"), c3b = b.off("class_cond_mlp.3.bias");
             b.push([=](const FwdCtx& cx, hipStream_t s) -> int {
                 if (!cx.ids) return FC_OK;    // no conditioning this step: these parameters get no gradient (left zero, the optimiser skips them)
-                FC_TRY(gather_rows_launch(E, cx.ids, e, cx.B, td, s));
+                FC_TRY(gather_rows_launch(E, cx.ids, e, cx.B, td, ncls, s));
                 FC_TRY(dense_fwd_launch(e, 0, cw1, cb1, cz1, cx.B, td, td, s));
                 FC_TRY(dense_bwd_w_launch(dT, td, cz1, 1, cx.grads + c3w, cx.grads + c3b, cx.B, td, td, s));
                 FC_TRY(dense_bwd_x_launch(dT, td, cw3, 0, 0, cz1, 1, dcz1, 0, cx.B, td, td, s));
@@ -529,6 +529,9 @@ int fc_unet_backward_ex(fc_unet* u, const float* x, const float* time, const int
     if (u->bwd.maxB < B || u->bwd.H != H || u->bwd.W != W || u->plan[0].maxB < B) return fail(FC_E_STATE, "unet: no backward plan for this shape; call fc_unet_train_reserve");
     if (numel != u->raw_numel) return fail(FC_E_ARG, "fc_unet_backward: gradient vector must have " + std::to_string(u->raw_numel) + " floats (padded table layout)");
     if (!u->loaded) return fail(FC_E_STATE, "unet: weights not loaded");
+    if (u->arena_train_rows != B)
+        return fail(FC_E_STATE, "fc_unet_backward: the activation arena does not hold a training forward of this batch (another forward, an "
+                                "integration, a profile run or a re-plan came in between); run fc_unet_forward after fc_unet_train_reserve again first");
     hipStream_t s = static_cast<hipStream_t>(stream);
     FC_HIP(hipSetDevice(u->device));
     if (u->dgrad_version != u->param_version) {     // data-gradient operands follow the parameters

@@ -43,4 +43,12 @@ struct fc_unet : fc::ParamStore {
     uint64_t param_version = 0, dgrad_version = ~0ull;
     int64_t class_lo = 0, class_hi = 0;       // [lo, hi) of class_cond_mlp.* in the flat table
 
+    // What the activation arena currently holds.  fc_unet_backward_ex reads the activations the LAST forward left there, so every
+    // entry point that writes the arena moves `arena_serial`; `arena_train_rows` > 0 only after a forward on the keep-everything
+    // (training) plan with that many rows.  A backward that does not follow such a forward fails with FC_E_STATE instead of
+    // producing gradients from someone else's activations.
+    uint64_t arena_serial = 0;
+    int arena_train_rows = 0;
+    void arena_touched(int train_rows) { ++arena_serial; arena_train_rows = train_rows; }
+
 };

@@ -1,5 +1,6 @@
 """Pre-encoded latent datasets: host-side mirror of ``flocoder/data.py``'s ``PreEncodedDataset`` /
-``InfiniteDataset`` (data.py:287-384; writer preencode_data.py:130-156) plus a packed single-file format.
+``InfiniteDataset`` (data.py:287-384; writer preencode_data.py:130-156), written against the behaviour fixture g11 pins, plus a packed
+single-file format.
 
 The reference stores ONE ``torch.save`` file per latent (a tensor ``[C,h,w]``, or a dict ``{target_latents, source_latents,
 mask_pixels(bool)}`` for inpainting) under numeric class directories and reads them back with 12 DataLoader workers -- a
@@ -29,106 +30,99 @@ MAGIC, VERSION, HEADER = b"FCLATENT", 1, 64
 _HDR = "<IIQIIIIII"
 
 
-def fast_scandir(dir: str, ext: list):
-    """data.py:17-43: recursive scandir, files with one of the extensions ``ext``; (subfolders, files) in scan order."""
-    subfolders, files = [], []
-    ext = ['.' + x if x[0] != '.' else x for x in ext]
-    try:
-        for f in os.scandir(dir):
-            try:
-                if f.is_dir():
-                    subfolders.append(f.path)
-                elif f.is_file() and os.path.splitext(f.name)[1].lower() in ext:
-                    files.append(f.path)
-            except OSError:
-                pass
-    except OSError:
-        pass
-    for d in list(subfolders):
-        sf, f = fast_scandir(d, ext)
-        subfolders.extend(sf)
-        files.extend(f)
-    return subfolders, files
+def _latent_files(root: Path) -> List[Path]:
+    """All ``*.pt`` files (extension compared case-insensitively) at any depth below ``root``, in sorted path order.  The reference
+    walks with ``os.scandir`` and keeps the file system's enumeration order (data.py:17-43); which file gets which label does not
+    depend on that order, and a sorted list makes ``pack_latents`` reproducible."""
+    found = []
+    for dirpath, dirnames, filenames in os.walk(root, onerror=lambda e: None):
+        dirnames.sort()
+        found += [Path(dirpath, f) for f in sorted(filenames) if os.path.splitext(f)[1].lower() == ".pt"]
+    return found
 
 
 class PreEncodedDataset(Dataset):
-    """data.py:311-384.  Numeric sub-directories are classes -- indexed by their position in PATH-SORTED order (so '10' sorts
-    before '2', as upstream: ``sorted(class_dirs)`` sorts Path objects, data.py:330) -- unless ``n_classes == 0``; otherwise
-    every ``.pt`` below ``data_dir`` gets label 0.  Items: ``(tensor | dict, LongTensor scalar)``."""
+    """One ``torch.save`` file per latent, as the reference's pre-encoder writes them (reader: data.py:311-384).
+
+    Behaviour pinned by fixture g11 (the reference class on the same tree):
+      * sub-directories whose names are all digits are classes.  A class's label is its POSITION among those directories sorted as
+        paths -- lexicographic, so "10" comes before "2" -- not its numeric value; ``class_to_idx`` maps the numeric name to it.
+      * ``n_classes=0`` switches class handling off: every file is labelled 0.  Without class directories the same happens; files are
+        then taken from the sub-directories if there are any, else from ``data_dir`` itself.
+      * an item is ``(payload, label)`` with ``payload`` whatever the file holds (a ``[C,h,w]`` tensor, or the inpainting dict) and
+        ``label`` a 0-d int64 tensor; items are memoised up to ``max_cache_items`` and then replaced at random, one in a hundred.
+      * an unreadable file yields zeros shaped like a cached payload (``[4,16,16]`` when nothing is cached) with label 0 instead of
+        raising, so a damaged sample does not end a long training run.
+    """
 
     def __init__(self, data_dir, max_cache_items=10000, n_classes=None):
-        data_dir = os.path.expanduser(data_dir)
-        self.data_dir = Path(data_dir)
-        print(f"PreEncodedDataset: loading from {data_dir}")
-        class_dirs = [d for d in self.data_dir.iterdir() if d.is_dir() and d.name.isdigit()]
-        self.files, self._labels = [], []
-        self.has_classes = len(class_dirs) > 0
-        if n_classes is not None and n_classes == 0:
-            self.has_classes = False
+        self.data_dir = Path(os.path.expanduser(str(data_dir)))
+        children = [d for d in self.data_dir.iterdir() if d.is_dir()]
+        numbered = sorted(d for d in children if d.name.isdigit())
+        self.has_classes = bool(numbered) and n_classes != 0
+        self.files: List[Path] = []
+        self._labels: List[int] = []
         if self.has_classes:
-            self.n_classes = len(class_dirs)
-            self.class_to_idx = {int(d.name): i for i, d in enumerate(sorted(class_dirs))}
-            for class_dir in sorted(class_dirs):
-                class_idx = self.class_to_idx[int(class_dir.name)]
-                _, class_files = fast_scandir(str(class_dir), ['pt'])
-                self.files.extend([Path(f) for f in class_files])
-                self._labels.extend([class_idx] * len(class_files))
+            self.n_classes = len(numbered)
+            self.class_to_idx = {int(d.name): pos for pos, d in enumerate(numbered)}
+            for pos, d in enumerate(numbered):
+                mine = _latent_files(d)
+                self.files += mine
+                self._labels += [pos] * len(mine)
         else:
-            subdirs = [d for d in self.data_dir.iterdir() if d.is_dir()]
-            if subdirs:
-                for subdir in subdirs:
-                    _, subdir_files = fast_scandir(str(subdir), ['pt'])
-                    self.files.extend([Path(f) for f in subdir_files])
-            else:
-                _, flat_files = fast_scandir(str(self.data_dir), ['pt'])
-                self.files = [Path(f) for f in flat_files]
             self.n_classes = 0
+            for top in (children if children else [self.data_dir]):
+                self.files += _latent_files(top)
             self._labels = [0] * len(self.files)
         self.actual_len = len(self.files)
-        self.cache = {}
         self.max_cache_items = max_cache_items
-        print(f"Found {self.actual_len} samples" + (f" across {self.n_classes} classes" if self.has_classes else ""))
+        self.cache = {}
+        print(f"PreEncodedDataset({self.data_dir}): {self.actual_len} latents" + (f", {self.n_classes} classes" if self.has_classes else ""))
 
     def __len__(self):
         return self.actual_len
 
+    def _remember(self, idx, item):
+        if len(self.cache) < self.max_cache_items:
+            self.cache[idx] = item
+        elif self.cache and random.random() < 0.01:
+            self.cache.pop(random.choice(list(self.cache)))
+            self.cache[idx] = item
+
     def __getitem__(self, idx):
-        if idx in self.cache:
-            return self.cache[idx]
-        file_path, class_idx = self.files[idx], self._labels[idx]
+        hit = self.cache.get(idx)
+        if hit is not None:
+            return hit
+        path = self.files[idx]
         try:
-            encoded = torch.load(file_path, map_location='cpu')
-            item = (encoded, torch.tensor(class_idx, dtype=torch.long))
-            if len(self.cache) < self.max_cache_items:
-                self.cache[idx] = item
-            elif random.random() < 0.01:
-                del self.cache[random.choice(list(self.cache.keys()))]
-                self.cache[idx] = item
-            return item
-        except Exception as e:                                  # upstream swallows unreadable files the same way (data.py:378-383)
-            print(f"Error loading {file_path}: {e}")
-            fallback = next(iter(self.cache.values()))[0] if self.cache else torch.zeros(4, 16, 16)
-            return torch.zeros_like(fallback), torch.tensor(0)
+            payload = torch.load(path, map_location='cpu')
+        except Exception as exc:
+            print(f"PreEncodedDataset: cannot read {path} ({exc}); substituting zeros")
+            like = next(iter(self.cache.values()))[0] if self.cache else torch.zeros(4, 16, 16)
+            return torch.zeros_like(like), torch.tensor(0)
+        item = (payload, torch.tensor(self._labels[idx], dtype=torch.long))
+        self._remember(idx, item)
+        return item
 
 
 class InfiniteDataset(IterableDataset):
-    """data.py:287-308: endless uniform sampling from a map-style dataset."""
+    """Endless stream of uniformly drawn items of a map-style dataset (data.py:287-308); the wrapped dataset's plain data attributes
+    (``n_classes``, ``has_classes``, ...) are visible on the wrapper, which is how the training script reads them."""
 
     def __init__(self, base_dataset, shuffle=True):
         super().__init__()
+        if not shuffle:
+            raise AssertionError("InfiniteDataset only supports shuffle=True for now")
         self.dataset = base_dataset
-        self.actual_len = len(self.dataset)
-        assert shuffle, "InfiniteDataset only supports shuffle=True for now"
-        for attr in dir(base_dataset):
-            if not attr.startswith('__') and not callable(getattr(base_dataset, attr)) and not hasattr(self, attr):
-                try:
-                    setattr(self, attr, getattr(base_dataset, attr))
-                except (AttributeError, TypeError):
-                    pass
+        self.actual_len = len(base_dataset)
+        for name, value in vars(base_dataset).items():
+            if not name.startswith('__') and not callable(value) and not hasattr(self, name):
+                setattr(self, name, value)
 
     def __iter__(self):
+        n = self.actual_len
         while True:
-            yield self.dataset[random.randint(0, self.actual_len - 1)]
+            yield self.dataset[random.randrange(n)]
 
 
 # ------------------------------------------------------------------------------------------------ packed format

@@ -56,6 +56,11 @@ def broadcast_weights(module: torch.nn.Module, src: int = 0) -> int:
         n = t.numel()
         t.copy_(flat[off:off + n].view_as(t))
         off += n
+    # the writes above go through ``.data`` and move neither data_ptr nor the version counter: a module that already ran once
+    # (its weights packed inside the library) must be told to upload again
+    for m in module.modules():
+        if hasattr(m, "mark_dirty"):
+            m.mark_dirty()
     return flat.numel() * 4
 
 

@@ -156,28 +156,32 @@ def ldcfg(config, key, default=None, supply_defaults=False, debug=False, verbose
 
 
 def keep_recent_files(keep=5, directory='checkpoints', pattern='*.pt'):
-    """general.py:77-81."""
-    files = sorted(Path(directory).glob(pattern), key=lambda p: p.stat().st_mtime, reverse=True)
-    for f in files[keep:]:
-        f.unlink()
+    """Disk-fill guard of the checkpoint directory (general.py:77-81): of the files matching ``pattern`` only the ``keep`` most
+    recently modified survive."""
+    by_age = sorted(Path(directory).glob(pattern), key=os.path.getmtime)
+    for stale in by_age[:max(0, len(by_age) - keep)]:
+        stale.unlink()
 
 
 def save_checkpoint(model, epoch=None, optimizer=None, keep=5, prefix="vqgan", ckpt_dir='checkpoints', config=None):
-    """general.py:120-137 -- same dict layout ({model_state_dict, epoch, optimizer_state_dict, config}) and file names."""
+    """Write ``{ckpt_dir}/{prefix}[_{epoch}].pt`` after pruning older ``{prefix}*.pt`` files (general.py:120-137).  The file is the dict
+    the reference's loaders expect (generate_samples.py:76-108): ``model_state_dict`` always, ``epoch`` / ``optimizer_state_dict`` /
+    ``config`` when given.  Returns the path written."""
     keep_recent_files(keep=keep, directory=ckpt_dir, pattern=f'{prefix}*.pt')
-    ckpt_path = f'{ckpt_dir}/{prefix}.pt'
-    save_dict = {'model_state_dict': model.state_dict()}
+    payload = {'model_state_dict': model.state_dict()}
+    name = prefix
     if epoch is not None:
-        ckpt_path = ckpt_path.replace('.pt', f'_{epoch}.pt')
-        save_dict['epoch'] = epoch
+        payload['epoch'] = epoch
+        name = f'{prefix}_{epoch}'
     if optimizer is not None:
-        save_dict['optimizer_state_dict'] = optimizer.state_dict()
+        payload['optimizer_state_dict'] = optimizer.state_dict()
     if config is not None:
-        save_dict['config'] = _unwrap(config) if isinstance(config, dict) else config
+        payload['config'] = _unwrap(config) if isinstance(config, dict) else config
     os.makedirs(ckpt_dir, exist_ok=True)
-    torch.save(save_dict, ckpt_path)
-    print(f"Checkpoint saved to {ckpt_path}")
-    return ckpt_path
+    target = f'{ckpt_dir}/{name}.pt'
+    torch.save(payload, target)
+    print(f"Checkpoint saved to {target}")
+    return target
 
 
 def load_flow_model(vmodel_path: str, config, device, n_classes: Optional[int] = None):

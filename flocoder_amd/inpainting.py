@@ -71,6 +71,10 @@ class MaskEncoder(nn.Module):
             node.register_parameter(leaf, p)
         self._handle, self._handle_device, self._synced = None, None, None
 
+    def mark_dirty(self) -> None:
+        """Re-upload the weights on the next use (for writes that bypass the (data_ptr, _version) key, e.g. ``p.data.copy_``)."""
+        self._synced = None
+
     def _native(self, device):
         lib = B.lib()
         if self._handle is None or self._handle_device != device:

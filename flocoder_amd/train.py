@@ -47,16 +47,29 @@ class EMA:
                     self.shadow[name] = self.decay * self.shadow[name] + (1.0 - self.decay) * param.data
 
     def eval(self):
-        for name, param in self.model.named_parameters():
-            if param.requires_grad:
-                self.backup[name] = param.data.clone()
-                param.data.copy_(self.shadow[name])
+        """Averaged weights into the model (train_flow.py:56-63).  Written with ``param.copy_`` under no_grad so the tensor version
+        moves, and the model is told explicitly as well: the library keeps its own packed copy of the weights and must re-upload."""
+        with torch.no_grad():
+            for name, param in self.model.named_parameters():
+                if param.requires_grad:
+                    self.backup[name] = param.detach().clone()
+                    param.copy_(self.shadow[name])
+        _mark_dirty(self.model)
 
     def train(self):
-        for name, param in self.model.named_parameters():
-            if param.requires_grad:
-                param.data.copy_(self.backup[name])
-                self.backup[name] = None
+        """Live weights back (train_flow.py:65-71)."""
+        with torch.no_grad():
+            for name, param in self.model.named_parameters():
+                if param.requires_grad:
+                    param.copy_(self.backup[name])
+                    self.backup[name] = None
+        _mark_dirty(self.model)
+
+
+def _mark_dirty(module) -> None:
+    for m in module.modules():
+        if hasattr(m, "mark_dirty"):
+            m.mark_dirty()
 
 
 def batch_to_data(batch, device, pre_encoded=True, mask_encoder=None, epoch=None, curriculum_epochs=10, extend_epochs=20,
@@ -121,6 +134,8 @@ class FlowTrainer:
         self.pg = process_group
         dist = torch.distributed
         self.distributed = (dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1) if distributed is None else distributed
+        # the 10 % conditioning drop (train_flow.py:343-345) is drawn from a generator every rank seeds alike, so replicas drop together
+        self._drop_rng = random.Random(0x5EED) if self.distributed else random
         model.train()
         model.sync_flat()
 
@@ -180,6 +195,23 @@ class FlowTrainer:
         run(pos, n, self.step_main, True)
         self.model.sync_flat()
 
+    # ---- data-parallel agreement -------------------------------------------------------------------------------------
+    def _agree(self, present: Dict[str, bool]) -> Dict[str, bool]:
+        """Replicas must take the SAME Adam decisions.  Which parameter groups received a gradient is a per-rank fact (one rank may
+        have dropped its conditioning, another not); Adam over a group on one rank but not the other would let parameters, moments
+        and step counters drift apart for good.  So: a group is stepped everywhere if ANY rank produced a gradient for it (DDP's
+        zero-gradient-but-stepped semantics) -- one MAX all-reduce of three flags -- and a rank that had none contributes zeros."""
+        if not self.distributed:
+            return present
+        keys = sorted(self._groups)
+        for k in keys:
+            lo, hi = self._groups[k]
+            if hi > lo and not present[k]:
+                self.grads[lo:hi].zero_()
+        flags = torch.tensor([float(present[k]) for k in keys], device=self.device)
+        torch.distributed.all_reduce(flags, op=torch.distributed.ReduceOp.MAX, group=self.pg)
+        return {k: bool(v) for k, v in zip(keys, flags.tolist())}
+
     # ---- the step -------------------------------------------------------------------------------------------------
     def step(self, source, target, cond=None, u: Optional[torch.Tensor] = None):
         """train_flow.py:346-397 for one batch: returns the loss as a 0-d device tensor (no host sync)."""
@@ -201,13 +233,15 @@ class FlowTrainer:
             cls = None
         if cls is not None:
             cls = cls.to(dev, torch.int64).contiguous()
+            self.model.check_class_ids(cls)
         x, v_target = self.interpolate(source, target, t)
         loss, _ = self.loss_and_grads(x, t, cls, v_target, mask)
         loss = loss.clone()
+        fused = mask is not None and not bool(torch.allclose(mask, torch.ones_like(mask)))    # unet.py:301 (host sync, as upstream)
+        present = self._agree({"class": cls is not None, "inject": mask is not None, "fusion": fused})
         if self.distributed:                                     # DDP semantics: average the gradients over ranks
             average_gradients(self.grads, self.pg)
-        fused = mask is not None and not bool(torch.allclose(mask, torch.ones_like(mask)))    # unet.py:301 (host sync, as upstream)
-        self.optimizer_step(has_class_grads=cls is not None, has_mask_grads=mask is not None, has_fusion_grads=fused)
+        self.optimizer_step(has_class_grads=present["class"], has_mask_grads=present["inject"], has_fusion_grads=present["fusion"])
         return loss
 
     # ---- inpainting: the MaskEncoder trains with the U-Net (train_flow.py:312-318,361-395) ----------------------------------
@@ -275,6 +309,8 @@ class FlowTrainer:
                 B.check(lib.fc_mse_loss_grad(B.ptr(y), B.ptr(want), B.ptr(dy), self._me_scal.data_ptr(), self._ws.data_ptr(), y.numel(), st))
                 me.backward_native(pix, dy, self.me_grads, accumulate=True)
                 loss = loss + self._me_scal[0]
+            fused = mask is not None and not bool(torch.allclose(mask, torch.ones_like(mask)))
+            present = self._agree({"class": cls is not None, "inject": mask is not None, "fusion": fused})
             if self.distributed:
                 average_gradients(self.grads, self.pg)
                 average_gradients(self.me_grads, self.pg)
@@ -285,8 +321,7 @@ class FlowTrainer:
             B.check(lib.fc_grad_clip_coef(self.me_grads.data_ptr(), nm, None, 0, 1e30, self._me_scal.data_ptr() + 4, self._ws.data_ptr(), st))
             c1 = self._scal[2]
             self._me_scal[2] = c1 * torch.clamp(self.me_max_norm / (c1 * self._me_scal[1] + 1e-6), max=1.0)
-        fused = mask is not None and not bool(torch.allclose(mask, torch.ones_like(mask)))
-        self._adam_all(has_class_grads=cls is not None, has_mask_grads=mask is not None, has_fusion_grads=fused)
+        self._adam_all(has_class_grads=present["class"], has_mask_grads=present["inject"], has_fusion_grads=present["fusion"])
         self.me_step += 1
         b1, b2 = self.betas
         B.check(lib.fc_adam_ema_step(self.me_params.data_ptr(), self.me_grads.data_ptr(), self.me_m.data_ptr(), self.me_v.data_ptr(),
@@ -302,10 +337,10 @@ class FlowTrainer:
         if getattr(self, "me", None) is not None and isinstance(data, dict) and 'mask_pixels' in data:
             target = data['target_latents'].to(self.device)
             return self.inpaint_step(data['source_latents'], target, data['mask_pixels'].float(), class_cond=batch[1],
-                                     drop_cond=random.random() < cfg_drop, ot=True)
+                                     drop_cond=self._drop_rng.random() < cfg_drop, ot=True)
         source, target, class_cond, mask_cond, _ = batch_to_data(batch, self.device, True, mask_encoder, epoch=epoch, blank_latents=blank_latents)
         cond = {'class_cond': class_cond, 'mask_cond': mask_cond}
-        if random.random() < cfg_drop:
+        if self._drop_rng.random() < cfg_drop:
             cond = None
             source = torch.randn_like(source)
         return self.step(source, target, cond)

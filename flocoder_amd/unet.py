@@ -63,7 +63,9 @@ class _UnetFunction(torch.autograd.Function):
         ctx.model, ctx.cls = model, cls
         ctx.save_for_backward(x, time, mask if mask is not None else x.new_empty(0))
         ctx.has_mask = mask is not None
-        return model._forward_native(x, time, cls, mask, train=True)
+        out = model._forward_native(x, time, cls, mask, train=True)
+        ctx.serial = model.arena_serial()
+        return out
 
     @staticmethod
     def backward(ctx, d_out):
@@ -71,6 +73,10 @@ class _UnetFunction(torch.autograd.Function):
         model = ctx.model
         mask = mask if ctx.has_mask else None
         need_dx, need_dm = ctx.needs_input_grad[1], ctx.has_mask and ctx.needs_input_grad[4]
+        if model.arena_serial() != ctx.serial:
+            # the library keeps ONE activation arena per model and something wrote it since this graph's forward (a second
+            # micro-batch, a validation / sampler call, a re-plan): bring this forward's activations back before differentiating
+            model._forward_native(x, time, ctx.cls, mask, train=True)
         flat, dx, dm = model.backward_native(x, time, ctx.cls, d_out, mask=mask, want_dx=need_dx, want_dmask=need_dm)
         grads = []
         for name, shape, off in model._table:
@@ -153,6 +159,11 @@ class Unet(nn.Module):
     def _version(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
+    def mark_dirty(self) -> None:
+        """Force a re-upload of the parameters on the next use.  Needed after writes the (data_ptr, _version) key cannot see:
+        ``param.data.copy_(...)`` changes neither (the reference's EMA swaps weights that way, train_flow.py:56-71)."""
+        self._synced_version = None
+
     # ------------------------------------------------------------------ native object
     def _native(self, device: torch.device):
         lib = B.lib()
@@ -182,6 +193,10 @@ class Unet(nn.Module):
             self._release()
         except Exception:
             pass
+
+    def arena_serial(self) -> int:
+        """Counter of writes to the library's activation arena (fc_unet_arena_serial)."""
+        return int(B.lib().fc_unet_arena_serial(self._handle)) if self._handle else 0
 
     def reserve(self, rows: int, height: int, width: int, device=None) -> None:
         """Build the launch plan / activation arena for up to `rows` U-Net rows (a CFG sampler needs 2x batch)."""
@@ -221,6 +236,15 @@ class Unet(nn.Module):
             raise AttributeError("Non-dict cond signals are dead in the reference; use cond={'class_cond': ids}")
         return cond.get("class_cond"), cond.get("mask_cond")
 
+    def check_class_ids(self, cls: Optional[torch.Tensor]) -> None:
+        """nn.Embedding raises IndexError for an id outside [0, n_classes) (unet.py:205,313); the kernels would silently treat such a
+        row as unconditional, so the host mirror raises like the reference.  One small host sync per call."""
+        if cls is None or cls.numel() == 0:
+            return
+        lo, hi = (int(v) for v in torch.stack((cls.min(), cls.max())).tolist())
+        if lo < 0 or hi >= self._cfg.n_classes:
+            raise IndexError(f"class_cond ids must lie in [0, {self._cfg.n_classes}); got min {lo}, max {hi}")
+
     def forward(self, x: torch.Tensor, time: torch.Tensor, cond=None) -> torch.Tensor:
         if not x.is_cuda:
             raise RuntimeError("flocoder_amd.Unet runs on MI355X (gfx950) only; there is no CPU path "
@@ -238,6 +262,9 @@ class Unet(nn.Module):
             cls = None                                            # hasattr(self,'class_cond_mlp') is False, unet.py:315
         if cls is not None:
             cls = cls.to(device=dev, dtype=torch.int64).contiguous()
+            if cls.shape != (bsz,):
+                raise ValueError("class_cond must have shape [batch]")
+            self.check_class_ids(cls)
         if mask is not None and not self._cfg.mask_cond:
             mask = None                                           # hasattr(self,'mask_fusion_conv') is False, unet.py:298
         if mask is not None:
@@ -322,10 +349,15 @@ class Unet(nn.Module):
             class_ids = None
         if class_ids is not None:
             class_ids = class_ids.to(device=dev, dtype=torch.int64).contiguous()
+            if class_ids.shape != (bsz,):
+                raise ValueError("class ids must have shape [batch]")
+            self.check_class_ids(class_ids)
         if mask is not None and not self._cfg.mask_cond:
             mask = None
         if mask is not None:
             mask = mask.to(device=dev, dtype=torch.float32).contiguous()
+            if mask.shape != x.shape:
+                raise ValueError("mask_cond must have the shape of x")
         rows = bsz * (2 if (class_ids is not None and cfg_strength) else 1)
         hnd = self._native(dev)
         B.check(B.lib().fc_unet_reserve(hnd, rows, h, w))

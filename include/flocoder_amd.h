@@ -159,6 +159,12 @@ int fc_unet_backward(fc_unet* u, const float* x_dev, const float* time_dev, cons
 int fc_unet_backward_ex(fc_unet* u, const float* x_dev, const float* time_dev, const int64_t* class_ids_dev, const float* mask_dev,
                         int mask_is_ones, const float* d_out_dev, float* grads_flat_dev, int64_t numel, float* dx_out_dev,
                         float* dmask_out_dev, int batch, int height, int width, void* stream);
+/* The backward reads the activations the last training forward left in the handle's single arena.  Every call that writes the arena
+ * (fc_unet_forward, fc_unet_integrate, fc_unet_profile_ops, a re-plan by fc_unet_reserve) moves this counter; a caller that keeps
+ * several forwards in flight (autograd with two micro-batches, gradient accumulation) compares the value it saw after ITS forward
+ * with the current one and re-runs the forward when they differ.  fc_unet_backward[_ex] itself fails with FC_E_STATE when the
+ * arena does not hold a training forward of `batch` rows.  (loss.backward() over a graph built earlier, train_flow.py:358-371.) */
+uint64_t fc_unet_arena_serial(const fc_unet* u);
 /* [lo, hi) of class_cond_mlp.* inside the flat table (0,0 without classes). */
 int fc_unet_class_param_range(const fc_unet* u, int64_t* lo, int64_t* hi);
 /* x = (1-t) source + t target ; v* = target - source   (train_flow.py:350-353), t per sample. */
