@@ -221,6 +221,29 @@ class SD_VAE_Wrapper(nn.Module):
     def flops_per_sample(self, decode=True) -> float:
         return float(B.lib().fc_vae_flops_per_sample(self._handle, int(decode))) if self._handle else 0.0
 
+    def plan_ops(self, decode=True):
+        """(kernel family, reference module, algorithmic FLOPs per sample) of every launch of the current decode / encode plan."""
+        lib, h = B.lib(), self._handle
+        out = []
+        for i in range(lib.fc_vae_plan_launches(h, int(decode)) if h else 0):
+            k, m, f = C.c_char_p(), C.c_char_p(), C.c_double()
+            B.check(lib.fc_vae_op_info(h, int(decode), i, C.byref(k), C.byref(m), C.byref(f)))
+            out.append((k.value.decode(), m.value.decode(), f.value))
+        return out
+
+    def plan_kernels(self, decode=True):
+        return [k for k, _, _ in self.plan_ops(decode)]
+
+    def profile_ops(self, inp: torch.Tensor, out: torch.Tensor, decode=True, repeats: int = 5):
+        """Per-launch device milliseconds of the decode (or encode) plan for the batch ``inp`` -> ``out`` (bench.py's live
+        roofline measurement for the codec).  Run decode()/encode() at this batch first so the plan exists."""
+        lib, h = B.lib(), self._handle
+        ops = self.plan_ops(decode)
+        ms = (C.c_float * len(ops))()
+        B.check(lib.fc_vae_profile_ops(h, int(decode), B.ptr(inp.contiguous()), B.ptr(out), inp.shape[0], repeats, ms, len(ops),
+                                       B.current_stream(inp.device)))
+        return [dict(kernel=k, module=m, flops_per_sample=f, ms=float(ms[i]), rows=inp.shape[0]) for i, (k, m, f) in enumerate(ops)]
+
 
 class _NoiseInjectionParams(nn.Module):
     """Parameter holder for NoiseInjection (codecs.py:217-241): a no-op at noise_strength 0, which is all the flow path uses;

@@ -92,3 +92,18 @@ def test_time_grids_match_reference_bitwise():
         S.warp_time(torch.zeros(1), s=-0.1)
     e = S.euler_time_grid(64)
     assert e.dtype == torch.float32 and abs(float(e[0]) - 1e-3) < 1e-9 and float(e[-1]) < 1.0
+
+
+def test_bench_starts_its_own_ranks_and_refuses_without_gpus():
+    """`python bench.py --gpus N` called plainly must not die with "launch with torch.distributed.run": the parent spawns the ranks
+    itself (bench.launch_ranks) and never touches the GPU.  On a box with fewer GPUs than N it says so and exits 2."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("multi-GPU node: the real launch is the driver's scaling run")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FLOCODER_AMD_SINGLE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "--gpus 2 but this node shows" in r.stderr, (r.returncode, r.stderr[-500:])
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "torch.distributed.run" in src and "launch_ranks" in src

@@ -93,3 +93,41 @@ def test_gradient_averaging_world2_gloo():
     want = (torch.arange(1000, dtype=torch.float32) * 1.5).tolist()
     assert res[0][1] == res[1][1] == 4
     assert res[0][2] == want and res[1][2] == want
+
+
+def _agree_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import types
+    import torch.distributed as dist
+    from flocoder_amd import dist as fdist
+    from flocoder_amd.train import FlowTrainer
+    fdist.init(backend="gloo")
+    # the trainer's agreement step on a stand-in that carries exactly the state it touches (the real object needs a GPU)
+    t = types.SimpleNamespace(distributed=True, pg=None, device=torch.device("cpu"),
+                              _groups={"class": (10, 20), "fusion": (30, 40), "inject": (0, 0)},
+                              grads=torch.full((50,), float(rank + 1)))
+    # rank 0 trained WITH class conditioning, rank 1 dropped it (cond=None); nobody had a mask
+    present = FlowTrainer._agree(t, {"class": rank == 0, "fusion": False, "inject": False})
+    fdist.average_gradients(t.grads)
+    q.put((rank, present, t.grads.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replicas_agree_on_adam_groups_world2_gloo():
+    """One rank drops its conditioning, the other does not: both must step class_cond_mlp.* (any-rank-has-a-gradient), and the rank
+    without one must contribute zeros -- not last step's leftovers -- to the average (flocoder_amd.train.FlowTrainer._agree)."""
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_agree_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, p0, g0), (_, p1, g1) = res
+    assert p0 == p1 == {"class": True, "fusion": False, "inject": False}
+    assert g0 == g1                                              # identical averaged gradients -> identical Adam updates
+    assert g0[0] == g0[45] == 1.5 and g0[15] == 0.5              # class range: (1 + 0) / 2 -- rank 1's stale 2.0 was zeroed first
+    assert g0[35] == 0.0                                         # a group nobody had: zeros everywhere, and Adam skips it on every rank

@@ -50,6 +50,10 @@ def gn_ref(y, groups):
     (9, 16, 32, 1, 1, 3, 1),
     (5, 32, 96, 1, 1, 1, 0),
     (3, 64, 32, 2, 2, 1, 0),
+    # codec-sized images: the shapes the 256-row tile (M256N64, pipelined kernel only) is chosen for by the SD-VAE plans
+    (2, 128, 128, 64, 64, 3, 1),
+    (1, 256, 64, 32, 32, 1, 0),
+    (2, 64, 192, 32, 32, 3, 1),
 ])
 def test_conv_tiles(tile, shape):
     from flocoder_amd._ops import conv_debug
