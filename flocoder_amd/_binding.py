@@ -98,6 +98,8 @@ SIGNATURES = {
     "fc_mask_encoder_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "fc_mask_encoder_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "fc_mask_blend": (_i, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "fc_sinkhorn_divergence": (_i, [_vp, _vp, _i, _i, _i64, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                               _pi, _vp]),
     "fc_ot_pairing": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _vp]),
 }
 

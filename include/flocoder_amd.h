@@ -270,6 +270,17 @@ int fc_mask_blend(const float* source_dev, const float* mask_dev, const float* n
 int fc_ot_pairing(const float* source_dev, const float* target_dev, int batch, int64_t dim, float* dist_ws_dev,
                   int64_t* perm_out_dev, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Parity metrics  (replace flocoder/metrics.py:40-54 sinkhorn_loss: geomloss SamplesLoss("sinkhorn", p=2, blur=0.05))
+ * ---------------------------------------------------------------------------------------------- */
+/* Debiased Sinkhorn divergence S_eps(x, y) between the point clouds x_dev [n][dim] and y_dev [m][dim] (fp32, uniform weights),
+ * cost |x-y|^2/2, eps-scaling from diameter^2 down to blur^2 by factors scaling^2 (geomloss's tensorized algorithm, restated:
+ * PARITY UNPINNED, the package is absent).  diameter <= 0: computed from the data as geomloss does.  Results on the host
+ * (the call synchronises `stream`): *value_out_host, the diameter used, the number of eps steps.  n, m <= 8192. */
+int fc_sinkhorn_divergence(const float* x_dev, const float* y_dev, int n, int m, int64_t dim, double blur, double scaling,
+                           double diameter, double* value_out_host, double* diameter_out_host, int* iterations_out_host,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif
