@@ -70,7 +70,8 @@ struct ConvFin {
     float eps = 1e-5f;
     const float* res = nullptr;     // NHWC [B][H][W][Cout] residual or null
     float* gn1_out = nullptr;       // optional GroupNorm(1) partials of the final value: [B][1][T1][2]
-    unsigned* sync = nullptr;       // one arrival counter per sample group (never reset: targets advance by the group size)
+    unsigned* sync = nullptr;       // one arrival counter per sample group, never reset: arrival number / group size + 1 = this launch's epoch
+    unsigned long long* gran = nullptr;   // [B][G][T][2] tagged granules {epoch << 32 | float bits}: the partials AS the hand-off (no flag, no fence)
     int* err = nullptr;             // set to 1 if a wait ever times out
 };
 
@@ -133,11 +134,24 @@ int gn_stats_launch(const float* x_nhwc, float* stats /*[B][G][1][2]*/, int B, i
 // [B][G][T][2] partials of n_t elements each -> [B][G][1][2] covering n_t*T elements
 int gn_fold_launch(const float* in, float* out, int B, int G, int T, float n_t, hipStream_t s);
 
-int init_conv_launch(const float* x_nchw, int x_batch_mod, const float* w /*[Cin][Cout]*/, const float* bias, float* out_nhwc,
+// Conditioning of every U-Net evaluation of an integration, computed up front (fc_unet_integrate): the time grid is known before
+// the first step, so the sinusoid -> time MLP (+ class MLP) -> 19 FiLM projections chain (unet.py:310-316,79-82) runs ONCE over all
+// (evaluation, row) pairs instead of as three launches at the head of each of the 64..396 forwards.  `all` holds
+// [evaluation][row][S] scale / shift rows; init_conv, the first launch of a forward, copies evaluation *evalc's slice into the plan's
+// table, and final_conv, the last one, advances *evalc.
+struct CondFetch {
+    const float* all = nullptr;    // null: the per-forward conditioning launches run as usual
+    const int* evalc = nullptr;
+    float* dst = nullptr;
+    int n4 = 0;                    // float4 elements per evaluation (rows * S / 4)
+};
+
+int init_conv_launch(const CondFetch& fetch, const float* x_nchw, int x_batch_mod, const float* w /*[Cin][Cout]*/, const float* bias, float* out_nhwc,
                      int B, int Cin, int HW, int Cout, hipStream_t s);
 // Legacy Euler step folded into final_conv (sampling.py:43-48): y += v * dt from the kernel that produces v, and block 0 publishes the
 // next interval's time exactly as ode_time_launch would (reads ts[*step], writes tvec, advances the counter)
 struct EulerTail {
+    int* evalc = nullptr;          // evaluation counter of the integrator (advanced by every final_conv), or null
     float* y = nullptr;            // NCHW state, updated in place; null = plain final_conv
     float dt = 0.f;
     int* step = nullptr;
@@ -160,6 +174,8 @@ struct TembArgs {
     const int64_t* class_ids = nullptr;  // [B] or null; id < 0 -> no class term
     int class_batch_mod = 0;           // ids index = b % mod (CFG second half passes null_from)
     int null_from = 0;                 // rows >= null_from get no class embedding (CFG), 0 = off
+    int rows_per_eval = 0;             // > 0: row b is row b % rows_per_eval of evaluation b / rows_per_eval (all evaluations of an
+                                       // integration in one launch): time[b / rows_per_eval], class / null_from taken within the evaluation
     const float* freqs = nullptr;      // [dim/2] exp(-k ln(1e4)/(dim/2-1))
     const float *w1t, *b1, *w2t, *b2;  // time_mlp.1 [dim][td], time_mlp.3 [td][td]  (transposed: [in][out])
     const float *emb, *cw1t, *cb1, *cw2t, *cb2;  // class_cond_mlp.{0,1,3}
@@ -218,6 +234,7 @@ int attn_small_launch(const float* qkv, float* out, int B, int n, int heads, hip
 // interval in flight.  All arithmetic is fp32 in the reference's operation order (sampling.py:43-48,74),
 // with FMA contraction disabled, so a step is reproducible against the CPU oracle to rounding.
 // First kernel of a step: reads ts[*step], publishes sc/tvec, then advances the counter.
+int ode_all_times_launch(const float* ts, int n_steps, int rk4, float t_scale, float* tv_out, hipStream_t s);
 int ode_time_launch(int* step, const float* ts, float t_scale, int rk4, float* sc, float* tvec, int rows, hipStream_t s);
 // v = cfg_on ? v_nc + cfg*(v_c - v_nc) : v   with v2 = [v_c ; v_nc] (n elements each)
 int ode_euler_update_launch(float* x, const float* v2, int n, int cfg_on, float cfg, float dt, hipStream_t s);

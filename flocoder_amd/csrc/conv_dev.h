@@ -6,6 +6,8 @@
 namespace fc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(1))) unsigned long long gu64;   // global-address-space words for in-launch hand-offs (never flat)
+typedef __attribute__((address_space(1))) unsigned gu32;
 
 struct ConvDev {
     ConvArgs a;
@@ -16,6 +18,10 @@ struct ConvDev {
     int fin_local;               // fused tail: the tile holds whole GroupNorm groups -> statistics straight from LDS, nothing to wait for
     int act0, act1, any_xf;
     int o_pixoff, o_pixtb, o_gstat, o_aff, o_patch, o_wl, o_wres, o_red, o_part;
+    int txl, tyl;                // log2 of tiles_x / tiles_y (both powers of two)
+    unsigned magic_nt;           // ceil(2^32 / ntiles) (0: ntiles == 1, or the grid is too large for the 16-bit fast path: divide)
+    int loader_prio;             // s_setprio level of the loader waves (the younger half of the workgroup loses issue arbitration to the MFMA waves otherwise)
+    int o_epoch, o_gran;         // fused tail: LDS word holding this launch's epoch (outside the aliased region); gathered partials
     // pipelined kernel only
     const float* zeros16;        // 16 zero bytes in global memory: source of out-of-range LDS-DMA lanes
     int patch_stride, wl_stride; // floats between the two pipeline stages of each buffer
@@ -49,6 +55,39 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+
+// The kernel's parameter block, read through the VECTOR memory path: every lane loads one dword of the kernarg segment (three
+// coalesced loads in flight at once), fields are then picked out with v_readlane.  Taken as `const ConvDev p` the compiler fetches the
+// ~130 dwords with scalar loads, runs out of SGPRs, and the prologue becomes two dozen dependent s_load -> s_waitcnt round trips with
+// v_writelane spills in between (1100 instructions before the first global load in the ISA of the M128N32 instantiation: 2-3 k cycles
+// of every launch).  Pointers are re-tagged as global so the loads / stores through them stay global_* (not flat_*).
+template <class T>
+__device__ __forceinline__ T* as_global(T* q) {
+    typedef __attribute__((address_space(1))) T* gp;
+    return (T*)(gp)(size_t)q;
+}
+__device__ __forceinline__ void conv_params_from_lanes(ConvDev& p) {
+    constexpr int ND = (int)(sizeof(ConvDev) / 4);
+    static_assert(sizeof(ConvDev) % 4 == 0 && ND <= 256, "ConvDev must fit four lane-loads");
+    const unsigned* ka = (const unsigned*)as_global((const unsigned*)__builtin_amdgcn_kernarg_segment_ptr());
+    const int lane = threadIdx.x & 63;
+    unsigned w[(ND + 63) / 64];
+#pragma unroll
+    for (int j = 0; j < (ND + 63) / 64; ++j) w[j] = (64 * j + lane < ND) ? ka[64 * j + lane] : 0u;
+    unsigned* d = reinterpret_cast<unsigned*>(&p);
+#pragma unroll
+    for (int i = 0; i < ND; ++i) d[i] = __builtin_amdgcn_readlane(w[i / 64], i % 64);
+    ConvArgs& a = p.a;
+    a.s0.p = as_global(a.s0.p); a.s0.xf.stats = as_global(a.s0.xf.stats); a.s0.xf.gamma = as_global(a.s0.xf.gamma);
+    a.s0.xf.beta = as_global(a.s0.xf.beta); a.s0.xf.ss = as_global(a.s0.xf.ss);
+    a.s1.p = as_global(a.s1.p); a.s1.xf.stats = as_global(a.s1.xf.stats); a.s1.xf.gamma = as_global(a.s1.xf.gamma);
+    a.s1.xf.beta = as_global(a.s1.xf.beta); a.s1.xf.ss = as_global(a.s1.xf.ss);
+    a.w = as_global(a.w); a.bias = as_global(a.bias); a.out = as_global(a.out); a.add = as_global(a.add);
+    a.stats_out = as_global(a.stats_out); a.res_w = as_global(a.res_w); a.res_b = as_global(a.res_b); a.res_out = as_global(a.res_out);
+    a.fin.gamma = as_global(a.fin.gamma); a.fin.beta = as_global(a.fin.beta); a.fin.res = as_global(a.fin.res);
+    a.fin.gn1_out = as_global(a.fin.gn1_out); a.fin.sync = as_global(a.fin.sync); a.fin.gran = as_global(a.fin.gran); a.fin.err = as_global(a.fin.err);
+    p.zeros16 = as_global(p.zeros16); p.stamps = as_global(p.stamps);
+}
 
 // Shared epilogue: K-split reduction through LDS, + bias, GroupNorm partials, optional SiLU / residual, stores.
 template <int WM, int WN, int WK, int MT, int NT>
@@ -116,6 +155,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
     conv_stamp(p, 6);
     const bool owner = active && (wk == 0);
     const bool fin = a.fin.gamma != nullptr;
+    // this launch's epoch of the fused tail (drawn from the sample group's arrival counter at kernel start, parked in LDS)
+    const unsigned epoch = (fin && !p.fin_local) ? __float_as_uint(smem[p.o_epoch]) : 0u;
     float* partS = smem + p.o_part;               // [BM/16][BN]
     float* partQ = partS + (BM / 16) * BN;        // [BM/16][BN]
     if (a.stats_out) __syncthreads();             // patch/wl (aliased by part*) are dead for every wave
@@ -174,9 +215,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                     ltab[2 * (tb * ngt + gl)] = mean;
                     ltab[2 * (tb * ngt + gl) + 1] = 1.0f / sqrtf((q - s * mean) / n + a.fin.eps);
                 }
-                if (coherent) {   // read by other workgroups of this launch: device-scope stores that bypass the per-XCD L2
-                    __hip_atomic_store(d, mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(d + 1, q - s * mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (coherent) {   // read by the other workgroups of this sample group IN this launch: each value travels as ONE 8-byte
+                    // write-through store {epoch, bits} -- the data is its own flag (cdna_hip_programming.md G16, R2)
+                    gu64* gp = (gu64*)(a.fin.gran + (size_t)(d - dst));
+                    const unsigned long long tag = (unsigned long long)epoch << 32;
+                    __hip_atomic_store(gp, tag | __float_as_uint(mean), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(gp + 1, tag | __float_as_uint(q - s * mean), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
                     d[0] = mean;
                     d[1] = q - s * mean;
@@ -232,34 +276,43 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
         float* tab = smem + p.o_fin;
         const int ngt = p.cpg >= BN ? 1 : BN / p.cpg;
         if (!p.fin_local) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
-                unsigned* c = a.fin.sync + b0 / p.TB;
-                const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned target = (old / (unsigned)p.gsz + 1u) * (unsigned)p.gsz;
-                int spins = 0;
-                while ((int)(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1 << 21)) { if (a.fin.err) *a.fin.err = 1; break; }   // bounded: a residency mistake must not hang the device
-                }
-            }
-            __syncthreads();
-            // (mean, rstd) of the groups this tile's columns belong to, per sample of the tile
+            // One round trip when the others have already published: every thread polls ONE granule (sc1 loads that bypass this CU's
+            // L1) until its tag is this launch's epoch, parks the value in LDS; then the Chan combination runs from LDS.  Bounded:
+            // a residency mistake must not hang the device (err is checked by the host: fc_unet_fused_tail_errors).
             const int Tst = (p.TB > 1 ? 1 : p.tiles_x * p.tiles_y) * p.NPG;
+            const int cnt = p.TB * ngt * Tst * 2;
+            float* gv = smem + p.o_gran;
+            for (int i = tid; i < cnt; i += nthr) {
+                const int k = i & 1, t = (i >> 1) % Tst, j = (i >> 1) / Tst, tb = j / ngt, gl = j - tb * ngt;
+                const int b = b0 + tb, g = n0 / p.cpg + gl;
+                float val = 0.f;
+                if (b < a.B && g < a.Gout) {
+                    const gu64* gp = (const gu64*)(a.fin.gran + ((size_t)(b * a.Gout + g) * Tst + t) * 2 + k);
+                    unsigned long long v = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    int spins = 0;
+                    while ((unsigned)(v >> 32) != epoch) {
+                        if (++spins > (1 << 20)) { if (a.fin.err) *a.fin.err = 1; break; }
+                        __builtin_amdgcn_s_sleep(2);
+                        v = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    val = __uint_as_float((unsigned)v);
+                }
+                gv[i] = val;
+            }
+            lds_only_barrier();
             for (int i = tid; i < p.TB * ngt; i += nthr) {
                 const int tb = i / ngt, gl = i - tb * ngt, b = b0 + tb, g = n0 / p.cpg + gl;
                 float mean = 0.f, rstd = 0.f;
                 if (b < a.B && g < a.Gout) {
-                    float* sp = a.stats_out + (size_t)(b * a.Gout + g) * Tst * 2;
+                    const float* sp = gv + (size_t)i * Tst * 2;
                     const float nt_ = (float)(p.rps * p.cpgt);
                     float sm = 0.f;
-                    for (int t = 0; t < Tst; ++t) sm += __hip_atomic_load(sp + 2 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int t = 0; t < Tst; ++t) sm += sp[2 * t];
                     mean = sm / (float)Tst;
                     float m2 = 0.f, dv = 0.f;
                     for (int t = 0; t < Tst; ++t) {
-                        const float d = __hip_atomic_load(sp + 2 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - mean;
-                        m2 += __hip_atomic_load(sp + 2 * t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const float d = sp[2 * t] - mean;
+                        m2 += sp[2 * t + 1];
                         dv += d * d;
                     }
                     rstd = 1.0f / sqrtf((m2 + nt_ * dv) / (nt_ * (float)Tst) + a.fin.eps);

@@ -287,6 +287,9 @@ static int conv_geometry(const ConvArgs& a, int tile, bool pipe, ConvDev* d, Con
     p.tiles_x = a.W / TW; p.tiles_y = a.H / TH;
     p.ntiles = cdiv(a.Cout, t.BN);
     p.nblocks = cdiv(a.B, TB) * p.tiles_x * p.tiles_y * p.ntiles;
+    p.txl = ilog2(p.tiles_x); p.tyl = ilog2(p.tiles_y);
+    p.magic_nt = (p.ntiles > 1 && p.nblocks < 65536) ? (unsigned)((1ull << 32) / (unsigned)p.ntiles) + 1u : 0u;   // exact for x < 2^16
+    p.loader_prio = 0; p.o_epoch = p.o_gran = 0;
     p.act0 = a.s0.xf.mode == 2; p.act1 = a.s1.xf.mode == 2;
     p.any_xf = (a.s0.xf.mode != 0) || (a.s1.xf.mode != 0);
     p.rps = TB > 1 ? a.H * a.W : t.BM;
@@ -309,6 +312,7 @@ static int conv_geometry(const ConvArgs& a, int tile, bool pipe, ConvDev* d, Con
         const int G0 = a.s0.xf.mode ? a.s0.xf.G : 0, G1 = a.s1.xf.mode ? a.s1.xf.G : 0;
         int o = 0;
         p.o_pixoff = p.o_pixtb = 0;
+        p.o_epoch = o; o += 4;                     // fused tail: this launch's epoch, written in the prologue, read in the epilogue (never aliased)
         p.o_gstat = o; o += align4(2 * TB * (G0 + G1));
         p.o_aff = o; o += p.any_xf ? align4(2 * TB * a.Cin) : 0;
         p.o_patch = o;
@@ -329,9 +333,13 @@ static int conv_geometry(const ConvArgs& a, int tile, bool pipe, ConvDev* d, Con
         if (a.stats_out) epi += 2 * (t.BM / 16) * t.BN + 2 * TB * t.BN;
         p.o_fin = o + epi;
         if (a.fin.gamma) epi += 2 * TB * t.BN;
+        p.o_gran = o + epi;
+        if (a.fin.gamma) epi += align4(TB * (p.cpg >= t.BN ? 1 : t.BN / p.cpg) * g->T * 2);   // partials of every workgroup of the sample group, gathered
         o += main_sz > epi ? main_sz : epi;
         p.zeros16 = conv_zeros16();
         p.stamps = conv_stamp_buffer();
+        static const int lprio = [] { const char* e = std::getenv("FLOCODER_AMD_LOADER_PRIO"); return e ? std::atoi(e) : 1; }();   // measured: 1 = +1.5 %, 2 / 3 a little less (profiles/r02_*)
+        p.loader_prio = lprio;
         g->tile = tile; g->grid = p.nblocks; g->lds = (size_t)o * sizeof(float);
         if (g->lds > 160 * 1024) return fail(FC_E_SHAPE, "conv: tile does not fit in LDS");
         p.gsz = 1; p.fin_local = 0;

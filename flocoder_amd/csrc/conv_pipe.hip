@@ -76,7 +76,9 @@ __device__ __forceinline__ void loader_handover() {   // LDS stores of this wave
 // slab's LDS-DMA issue (~190 cycles per 1 KB piece per wave) took 1.65x the consumers' MFMA time per chunk and the consumers sat
 // at the chunk barrier half of the time (profiles/r01_c_stamps.txt); eight loader waves halve the issue time per wave.
 template <int WM, int WN, int WK, int MT, int NT, int CC, int NPL, int KS, int NL>
-__global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev p) {
+__global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev p_kernarg) {
+    ConvDev p;
+    conv_params_from_lanes(p);       // p_kernarg itself is never touched: see conv_dev.h
     constexpr int NTHR = 256 + 64 * NL, LT = 64 * NL;
     constexpr int BN = 32 * NT * WN, CS = CC + 1, KSTEPS = CC / 2, KPW = KSTEPS / WK, Q = CC / 4, PIXSTEP = LT / Q, KK = KS * KS;
     static_assert(WM * WN * WK == 4, "4 consumer waves per workgroup");
@@ -101,8 +103,10 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
 
     const int bid = xcd_remap(blockIdx.x, p.nblocks);
-    const int nt_i = bid % p.ntiles, mt_i = bid / p.ntiles;
-    const int tx = mt_i % p.tiles_x, ty = (mt_i / p.tiles_x) % p.tiles_y, bg = mt_i / (p.tiles_x * p.tiles_y);
+    // tile decode without integer division: tiles_x / tiles_y are powers of two, ntiles goes through a host-made reciprocal
+    const int mt_i = p.ntiles == 1 ? bid : (p.magic_nt ? (int)__umulhi((unsigned)bid, p.magic_nt) : bid / p.ntiles);
+    const int nt_i = bid - mt_i * p.ntiles;
+    const int tx = mt_i & (p.tiles_x - 1), ty = (mt_i >> p.txl) & (p.tiles_y - 1), bg = mt_i >> (p.txl + p.tyl);
     const int TW = 1 << p.TWl, TH = 1 << p.THl;
     const int b0 = bg * p.TB, y0 = ty * TH, x0 = tx * TW, n0 = nt_i * BN;
     const int PW = p.PW, PHW = p.PH * p.PW;
@@ -110,6 +114,16 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
     const bool has_res = a.res_out != nullptr;
     const int nchunks = p.nchunks;
     conv_stamp(p, 0);
+    // Fused tail across workgroups: draw this launch's epoch from the sample group's arrival counter NOW -- the round trip hides behind
+    // the whole main loop; every workgroup of the group gets the same quotient because launches of one op never overlap.
+    const bool meet = a.fin.gamma != nullptr && !p.fin_local;
+    // Inline asm on purpose: through the builtin, hipcc's atomic optimizer waits for the returned value on the spot (a cold round trip
+    // in front of everything else); here the wait sits where the value is used, after the GroupNorm tables.
+    unsigned arrival = 0;
+    if (meet && tid == 0) {
+        const gu32* cnt = (const gu32*)(a.fin.sync + b0 / p.TB);
+        asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(arrival) : "v"(cnt), "v"(1u) : "memory");
+    }
 
     // ---- GroupNorm tables: moments per (sample, group), then the folded affine per (sample, channel) -- all 512 threads.
     // Run by the consumers at once and by the loaders AFTER they have put the first weight slabs in flight (two dependent
@@ -210,6 +224,15 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
 
     if (!consumer) {
         // =========================================== LOADERS ===========================================
+        // Waves 4+ are the younger half of the workgroup: at equal priority the SIMD's issue arbitration (priority, then age) hands them
+        // the slots the MFMA waves leave over, and the consumers then sit at the chunk barrier waiting for a stage the loaders could
+        // not issue fast enough (stamps: 5 k cycles to issue three loads per thread).  s_setprio is scalar: the branch is wave-uniform.
+        {
+            const int lp = __builtin_amdgcn_readfirstlane(p.loader_prio);
+            if (lp == 1) __builtin_amdgcn_s_setprio(1);
+            else if (lp == 2) __builtin_amdgcn_s_setprio(2);
+            else if (lp == 3) __builtin_amdgcn_s_setprio(3);
+        }
         const float* wbase = a.w + (size_t)b0 * a.w_batch_stride;
         const int q4 = (ltid % Q) * 4;
         int e_po[NPL], e_lds[NPL], e_tb[NPL];   // this thread's patch elements: pixel (ltid/Q + k*256/Q), channel quad ltid%Q
@@ -332,6 +355,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
             unsigned long long* d = p.stamps + ((size_t)blockIdx.x * 8 + (wave8 < 8 ? wave8 : 7)) * 16;
             d[9] = dbg_mem; d[10] = dbg_store; d[11] = dbg_bar; d[12] = dbg_issue; d[13] = dbg_dma;
         }
+        __builtin_amdgcn_s_setprio(0);   // staging is over: in the epilogue the accumulator waves are the ones with work to do
     } else {
         // =========================================== CONSUMERS ===========================================
         int abase[MT];
@@ -365,6 +389,10 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
         if (DB) fetch_w(0, wcur, rcur);
         conv_stamp(p, 1);
         gn_tables();
+        if (meet && tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(arrival) :: "memory");
+            smem[p.o_epoch] = __uint_as_float(arrival / (unsigned)p.gsz + 1u);
+        }
         __syncthreads();        // stage 0 ready
         conv_stamp(p, 4);
         for (int i = 0; i < nchunks; ++i) {

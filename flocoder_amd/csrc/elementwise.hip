@@ -179,11 +179,20 @@ int gn_stats_launch(const float* x, float* stats, int B, int HW, int C, int G, h
 
 // ---------------------------------------------------------------------------------------------------
 // init_conv (unet.py:185-186,295): 1x1 conv reading the NCHW boundary tensor, writing NHWC.
+// Blocks beyond `conv_blocks` fetch this evaluation's precomputed scale / shift rows into the plan's table (CondFetch, common.h): the
+// first reader is two launches away, so the copy costs no launch of its own.
 __global__ void __launch_bounds__(256) init_conv_kernel(const float* x, int bmod, const float* w, const float* bias, float* out,
-                                                        int B, int Cin, int HW, int Cout) {
+                                                        int B, int Cin, int HW, int Cout, int conv_blocks, const CondFetch f) {
+    if ((int)blockIdx.x >= conv_blocks) {
+        const float4* src = reinterpret_cast<const float4*>(f.all) + (size_t)(*f.evalc) * f.n4;
+        float4* dst = reinterpret_cast<float4*>(f.dst);
+        const int nb = gridDim.x - conv_blocks;
+        for (int i = (blockIdx.x - conv_blocks) * 256 + threadIdx.x; i < f.n4; i += nb * 256) dst[i] = src[i];
+        return;
+    }
     const int q = Cout / 4;
     const size_t total = (size_t)B * HW * q;
-    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)conv_blocks * 256) {
         const int co = (int)(i % q) * 4;
         const size_t bp = i / q;
         const int pix = (int)(bp % HW), b = (int)(bp / HW);
@@ -198,12 +207,13 @@ __global__ void __launch_bounds__(256) init_conv_kernel(const float* x, int bmod
     }
 }
 
-int init_conv_launch(const float* x, int bmod, const float* w, const float* bias, float* out, int B, int Cin, int HW, int Cout,
-                     hipStream_t s) {
+int init_conv_launch(const CondFetch& fetch, const float* x, int bmod, const float* w, const float* bias, float* out, int B, int Cin, int HW,
+                     int Cout, hipStream_t s) {
     if (Cout & 3) return fail(FC_E_SHAPE, "init_conv: Cout must be a multiple of 4");
     const size_t total = (size_t)B * HW * (Cout / 4);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(init_conv_kernel, dim3(grid), dim3(256), 0, s, x, bmod, w, bias, out, B, Cin, HW, Cout);
+    const int extra = fetch.all ? (fetch.n4 + 255) / 256 < 512 ? (fetch.n4 + 255) / 256 : 512 : 0;
+    hipLaunchKernelGGL(init_conv_kernel, dim3(grid + extra), dim3(256), 0, s, x, bmod, w, bias, out, B, Cin, HW, Cout, grid, fetch);
     FC_HIP(hipGetLastError());
     return FC_OK;
 }
@@ -254,6 +264,7 @@ __global__ void __launch_bounds__(256) final_conv_kernel(const float* x, const f
         const float tv = __fmul_rn(t, e.t_scale);
         for (int r = threadIdx.x; r < e.rows; r += 256) e.tvec[r] = tv;
     }
+    if (e.evalc && blockIdx.x == 0 && threadIdx.x == 0) *e.evalc += 1;   // this forward is done: the next init_conv fetches the next slice
 }
 
 // The usual shapes (Cout <= 4 latent channels, Cin = dim a compile-time constant): one pixel per thread with its whole input row and
@@ -310,6 +321,7 @@ __global__ void __launch_bounds__(256) final_conv_small_kernel(const float* x, c
         const float tv = __fmul_rn(t, e.t_scale);
         for (int r = threadIdx.x; r < e.rows; r += 256) e.tvec[r] = tv;
     }
+    if (e.evalc && blockIdx.x == 0 && threadIdx.x == 0) *e.evalc += 1;   // this forward is done: the next init_conv fetches the next slice
 }
 
 int final_conv_launch(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int HW, int Cout, const EulerTail& tail,

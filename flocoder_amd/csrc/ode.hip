@@ -93,6 +93,27 @@ __global__ void __launch_bounds__(256) ode_rk4_final_kernel(const float* sc, flo
     }
 }
 
+// Scaled time of EVERY evaluation of an integration, with the very operations the per-step kernels above use (so a conditioning table
+// built from it is bit-identical to what the per-forward launches would compute): Euler: ts[i] * t_scale; RK4, interval i:
+// t, t + dt/2, t + dt/2, t + dt with dt = ts[i+1] - ts[i].
+__global__ void __launch_bounds__(256) ode_all_times_kernel(const float* ts, int n_steps, int rk4, float t_scale, float* tv) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_steps) return;
+    const float t = ts[i];
+    if (!rk4) { tv[i] = mul_(t, t_scale); return; }
+    const float dt = sub_(ts[i + 1], t);
+    const float th = mul_(add_(t, dt * 0.5f), t_scale);
+    tv[4 * i] = mul_(t, t_scale);
+    tv[4 * i + 1] = th;
+    tv[4 * i + 2] = th;
+    tv[4 * i + 3] = mul_(add_(t, dt), t_scale);
+}
+int ode_all_times_launch(const float* ts, int n_steps, int rk4, float t_scale, float* tv, hipStream_t s) {
+    hipLaunchKernelGGL(ode_all_times_kernel, dim3(cdiv(n_steps, 256)), dim3(256), 0, s, ts, n_steps, rk4, t_scale, tv);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
 static int egrid(int n) { int g = (n / 4 + 255) / 256; return g < 1 ? 1 : (g > 2048 ? 2048 : g); }
 
 int ode_time_launch(int* step, const float* ts, float t_scale, int rk4, float* sc, float* tvec, int rows, hipStream_t s) {

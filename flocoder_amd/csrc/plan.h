@@ -36,6 +36,7 @@ struct FwdCtx {             // per-call inputs of one forward
     float* dx_out = nullptr;           // backward only, optional: NCHW gradient of the input x
     float* dmask_out = nullptr;        // backward only, optional: NCHW gradient of the mask
     EulerTail euler;                   // integrator only: the Euler update rides in final_conv
+    CondFetch fetch;                   // integrator only: conditioning rows of every evaluation were computed up front
 };
 using Op = std::function<int(const FwdCtx&, hipStream_t)>;
 
@@ -271,6 +272,10 @@ struct PlanBuilder {
         unsigned* sync = reinterpret_cast<unsigned*>(dmalloc((size_t)g.groups + 1));
         if (err) return false;
         if (hipMemset(sync, 0, ((size_t)g.groups + 1) * sizeof(unsigned)) != hipSuccess) { err = fail(FC_E_HIP, "hipMemset failed"); return false; }
+        const size_t ngran = (size_t)B * G * g.T * 2;                       // one 8-byte {epoch, value} granule per partial statistic
+        a.fin.gran = reinterpret_cast<unsigned long long*>(dmalloc(2 * ngran));
+        if (err) return false;
+        if (hipMemset(a.fin.gran, 0, ngran * sizeof(unsigned long long)) != hipSuccess) { err = fail(FC_E_HIP, "hipMemset failed"); return false; }   // tag 0 = never a live epoch
         a.fin.sync = sync;
         a.fin.err = reinterpret_cast<int*>(sync + g.groups);
         pl->fin_err.push_back(a.fin.err);

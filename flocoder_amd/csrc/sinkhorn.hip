@@ -56,7 +56,8 @@ __global__ void __launch_bounds__(256) sk_extent_kernel(const float* x, const fl
         float lo = INFINITY, hi = -INFINITY;
         for (int i = 0; i < N; ++i) { const float v = x[(size_t)i * D + k]; lo = fminf(lo, v); hi = fmaxf(hi, v); }
         for (int j = 0; j < M; ++j) { const float v = y[(size_t)j * D + k]; lo = fminf(lo, v); hi = fmaxf(hi, v); }
-        sq = (double)(hi - lo) * (double)(hi - lo);
+        const double ext = (double)hi - (double)lo;
+        sq = ext * ext;
     }
     __shared__ double red[256];
     red[threadIdx.x] = sq;

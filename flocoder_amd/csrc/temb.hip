@@ -76,8 +76,9 @@ __device__ __forceinline__ float meet(float* red, const float (&acc)[SB], int wa
 
 __device__ __forceinline__ long class_of(const TembArgs& a, int b) {
     long cid = -1;
-    if (a.class_ids && a.n_classes > 0 && b < a.B && !(a.null_from > 0 && b >= a.null_from))
-        cid = a.class_ids[a.class_batch_mod > 0 ? b % a.class_batch_mod : b];
+    const int q = a.rows_per_eval > 0 ? b % a.rows_per_eval : b;      // row inside its evaluation
+    if (a.class_ids && a.n_classes > 0 && b < a.B && !(a.null_from > 0 && q >= a.null_from))
+        cid = a.class_ids[a.class_batch_mod > 0 ? q % a.class_batch_mod : q];
     return cid >= a.n_classes ? -1 : cid;
 }
 
@@ -116,7 +117,7 @@ __global__ void __launch_bounds__(kCondThreads) cond_hidden_kernel(const TembArg
         const float* erow = a.emb + (size_t)(cid >= 0 ? cid : 0) * a.td;
         stage8(xs, K * SB, tid, [&](int i) -> const float* { return cid >= 0 ? erow + i / SB : nullptr; }, [](float v) { return v; });
     } else {
-        const float tb = myb < a.B ? a.time[myb] : 0.f;
+        const float tb = myb < a.B ? a.time[a.rows_per_eval > 0 ? myb / a.rows_per_eval : myb] : 0.f;
         for (int i = tid; i < K * SB; i += kCondThreads) {
             const int k = i / SB, kk = k < half ? k : k - half;
             const float arg = tb * a.freqs[kk];   // table built on the host exactly as unet.py:26-27 does

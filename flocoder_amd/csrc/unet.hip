@@ -119,9 +119,11 @@ static int declare_all(fc_unet* u) {
     return FC_OK;
 }
 
+// Fused Block tails across workgroups (ConvFin): on by default since the meeting became one tagged-granule round trip (+2.5 % on the
+// sampler, profiles/r02_*); FLOCODER_AMD_FUSED_TAIL=local keeps only the meeting-free form, =0 turns both off.
 static int g_fused_tail = -1;
 static bool fused_tail_enabled() {
-    if (g_fused_tail < 0) { const char* e = std::getenv("FLOCODER_AMD_FUSED_TAIL"); g_fused_tail = (e && std::string(e) == "1") ? 1 : 0; }
+    if (g_fused_tail < 0) { const char* e = std::getenv("FLOCODER_AMD_FUSED_TAIL"); g_fused_tail = (e && (std::string(e) == "0" || std::string(e) == "local")) ? 0 : 1; }
     return g_fused_tail == 1;
 }
 
@@ -372,16 +374,18 @@ static int build_plan(fc_unet* u, Plan* pl, int maxB, int H, int W) {
             t.cw2t = u->P("class_cond_mlp.3.weight"); t.cb2 = u->R("class_cond_mlp.3.bias");
         }
         t.n_classes = ncls; t.t_out = pl->t_emb; t.dim = dim; t.td = td;
+        u->temb_proto = t;
         b.scope = "time_mlp";
         float *hid = b.dmalloc((size_t)maxB * td), *chid = b.dmalloc((size_t)maxB * td);
         b.push([t, hid, chid](const FwdCtx& cx, hipStream_t s) {
+            if (cx.fetch.all) return (int)FC_OK;   // this evaluation's rows were computed before the first step (fc_unet_integrate)
             TembArgs a = t; a.B = cx.B; a.time = cx.time; a.class_ids = cx.ids; a.class_batch_mod = cx.ids_mod; a.null_from = cx.null_from;
             return temb_launch(a, hid, chid, s);
         }, "temb", 2.0 * ((double)dim * td + (double)td * td * (ncls > 0 ? 3 : 1)));
         const float *te = pl->t_emb, *wt = u->P("__ss_wt"), *sb = u->P("__ss_bias");
         float* ss = pl->ss;
         b.scope = "resblock.mlp";
-        b.push([=](const FwdCtx& cx, hipStream_t s) { return ss_launch(te, wt, sb, ss, cx.B, td, S, s); }, "ss", 2.0 * (double)td * S);
+        b.push([=](const FwdCtx& cx, hipStream_t s) { return cx.fetch.all ? (int)FC_OK : ss_launch(te, wt, sb, ss, cx.B, td, S, s); }, "ss", 2.0 * (double)td * S);
         pl->side_ops = (int)pl->ops.size();   // the conditioning chain reads only time / class ids: it runs beside init_conv and the first conv1
     }
 
@@ -395,7 +399,7 @@ static int build_plan(fc_unet* u, Plan* pl, int maxB, int H, int W) {
         float* x0p = x0.p;
         b.scope = "init_conv";
         if (!c.mask_cond) {
-            b.push([=](const FwdCtx& cx, hipStream_t s) { return init_conv_launch(cx.x, cx.x_mod, w, bias, x0p, cx.B, ch, HW, dim, s); }, "init_conv", 2.0 * HW * ch * dim);
+            b.push([=](const FwdCtx& cx, hipStream_t s) { return init_conv_launch(cx.fetch, cx.x, cx.x_mod, w, bias, x0p, cx.B, ch, HW, dim, s); }, "init_conv", 2.0 * HW * ch * dim);
         } else {
             Act xi = b.act(dim, H, W), f1 = b.act(2 * dim, H, W), f2 = b.act(2 * dim, H, W);
             const bool keep = u->keep_all;         // training keeps the pre-activations z1, z2 of the two SiLU layers
@@ -404,7 +408,7 @@ static int build_plan(fc_unet* u, Plan* pl, int maxB, int H, int W) {
             float *xip = xi.p, *mp = mask_nhwc.p;
             b.push([=](const FwdCtx& cx, hipStream_t s) -> int {
                 if (cx.mask) FC_TRY(nchw_to_nhwc_launch(cx.mask, mp, cx.B, ch, HW, ch, cx.x_mod, s));
-                return init_conv_launch(cx.x, cx.x_mod, w, bias, cx.mask_fuse ? xip : x0p, cx.B, ch, HW, dim, s);
+                return init_conv_launch(cx.fetch, cx.x, cx.x_mod, w, bias, cx.mask_fuse ? xip : x0p, cx.B, ch, HW, dim, s);
             }, "init_conv", 2.0 * HW * ch * dim);
             ConvArgs a[3];
             const char* names[3] = {"mask_fusion_conv.0", "mask_fusion_conv.2", "mask_fusion_conv.4"};
@@ -665,6 +669,7 @@ void fc_unet_destroy(fc_unet* u) {
     (void)hipDeviceSynchronize();
     free_plan(u);
     if (u->ts_dev) (void)hipFree(u->ts_dev);
+    if (u->pre) (void)hipFree(u->pre);
     u->free_device();
     if (u->freqs) (void)hipFree(u->freqs);
     if (u->stream) (void)hipStreamDestroy(u->stream);
@@ -816,9 +821,13 @@ static bool euler_tail_ok(const fc_unet* u, int method, bool cfg_on) {
 }
 
 static int enqueue_step(fc_unet* u, int method, int B, bool cfg_on, float cfg, float dt_euler, float t_scale, bool has_ids, int mask_mode,
-                        hipStream_t s) {
+                        bool pre_on, hipStream_t s) {
     const int rows = cfg_on ? 2 * B : B, n = B * u->cfg.channels * u->H * u->W;
     FwdCtx c;
+    if (pre_on) {   // conditioning rows of every evaluation are in u->pre: init_conv fetches slice *evalc, final_conv advances the counter
+        c.fetch.all = u->pre_ss; c.fetch.evalc = u->step + 1; c.fetch.dst = u->plan[0].ss; c.fetch.n4 = rows * u->S / 4;
+        c.euler.evalc = u->step + 1;
+    }
     c.x_mod = B; c.time = u->tvec; c.ids = has_ids ? u->ids_own : nullptr; c.ids_mod = B; c.null_from = cfg_on ? B : 0;
     c.mask = mask_mode ? u->mask_own : nullptr; c.mask_fuse = mask_mode == 1;
     c.out = u->v2; c.B = rows;
@@ -873,23 +882,61 @@ int fc_unet_integrate(fc_unet* u, int method, float* x_dev, int B, int H, int W,
     FC_HIP(hipStreamWaitEvent(s, u->ev_in, 0));
     // pageable source: the runtime stages it before returning, so ts_host may be freed by the caller right away
     FC_HIP(hipMemcpyAsync(u->ts_dev, ts_host, n_points * sizeof(float), hipMemcpyHostToDevice, s));
-    FC_HIP(hipMemsetAsync(u->step, 0, sizeof(int), s));
+    FC_HIP(hipMemsetAsync(u->step, 0, 2 * sizeof(int), s));   // step counter | evaluation counter
     FC_HIP(hipMemcpyAsync(u->y, x_dev, nbytes, hipMemcpyDeviceToDevice, s));
     if (has_ids) FC_HIP(hipMemcpyAsync(u->ids_own, ids, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
     if (mask_mode) FC_HIP(hipMemcpyAsync(u->mask_own, mask, nbytes, hipMemcpyDeviceToDevice, s));
 
+    // Conditioning of every evaluation, once: the grid is known, so time MLP / class MLP / FiLM projections of all (evaluation, row)
+    // pairs are three launches here instead of three at the head of each forward (44 us of every 1.6 ms step inside the replayed graph:
+    // cold weights, latency-bound).  Rows are bit-identical to the per-forward ones (same kernels, same time arithmetic).
+    static const bool no_pre = std::getenv("FLOCODER_AMD_NO_PRECOND") != nullptr;
+    const int n_evals = method == FC_METHOD_RK4 ? 4 * n_steps : n_steps;
+    const size_t R = (size_t)n_evals * rows, tvn = ((size_t)n_evals + 3) & ~(size_t)3;
+    const size_t need = tvn + R * u->td * 3 + R * u->S;
+    const bool pre_on = !no_pre && u->nchains < 2 && n_steps >= 2 && need * sizeof(float) <= (2ull << 30) && R < (1u << 30) / (unsigned)u->S;
+    if (pre_on) {
+        if (need > u->pre_cap) {
+            FC_HIP(hipStreamSynchronize(s));
+            if (u->pre) FC_HIP(hipFree(u->pre));
+            u->pre = nullptr; u->pre_cap = 0;
+            FC_HIP(hipMalloc(reinterpret_cast<void**>(&u->pre), need * sizeof(float)));
+            u->pre_cap = need;
+            for (auto& kv : u->graphs) (void)hipGraphExecDestroy(kv.second);
+            u->graphs.clear();  // captured graphs hold the old table pointer
+        }
+        float *tv = u->pre, *te = tv + tvn, *hh = te + R * u->td, *c1 = hh + R * u->td;
+        if (u->pre_ss != c1 + R * u->td) {   // the table moved inside the buffer (another number of evaluations): graphs bake its address
+            for (auto& kv : u->graphs) (void)hipGraphExecDestroy(kv.second);
+            u->graphs.clear();
+        }
+        u->pre_ss = c1 + R * u->td;
+        FC_TRY(ode_all_times_launch(u->ts_dev, n_steps, method == FC_METHOD_RK4, t_scale, tv, s));
+        TembArgs ta = u->temb_proto;
+        ta.B = (int)R; ta.time = tv; ta.rows_per_eval = rows; ta.class_ids = has_ids ? u->ids_own : nullptr; ta.class_batch_mod = B;
+        ta.null_from = cfg_on ? B : 0; ta.t_out = te;
+        FC_TRY(temb_launch(ta, hh, c1, s));
+        // every ResnetBlock.mlp (SiLU -> Linear td -> 2*Cout, unet.py:79-82) of every row as ONE GEMM [R x td] . [td x S] on the
+        // implicit-GEMM kernel (a 1x1 convolution over R one-pixel "images"): the per-forward VALU kernel re-reads the 4 MB weight
+        // matrix for every eight rows (1.7 ms at R = 4096), this takes a tenth of that
+        FC_TRY(silu_fwd_launch(te, nullptr, hh, R * u->td, s));
+        ConvArgs ca;
+        ca.s0.p = hh; ca.s0.C = u->td; ca.Cin = u->td; ca.Cout = u->S; ca.B = (int)R; ca.H = ca.W = ca.Hs = ca.Ws = 1; ca.KS = 1;
+        ca.w = u->P("__ss_wt"); ca.bias = u->P("__ss_bias"); ca.out = u->pre_ss;
+        FC_TRY(conv_launch(ca, TILE_AUTO, s));
+    }
     if (euler_tail_ok(u, method, cfg_on))   // time of the first interval; every step publishes its successor's
         FC_TRY(ode_time_launch(u->step, u->ts_dev, t_scale, 0, u->sc, u->tvec, rows, s));
     static const bool no_graph = std::getenv("FLOCODER_AMD_NO_GRAPH") != nullptr;
     if (no_graph) {
-        for (int i = 0; i < n_steps; ++i) FC_TRY(enqueue_step(u, method, B, cfg_on, cfg_strength, dt_euler, t_scale, has_ids, mask_mode, s));
+        for (int i = 0; i < n_steps; ++i) FC_TRY(enqueue_step(u, method, B, cfg_on, cfg_strength, dt_euler, t_scale, has_ids, mask_mode, pre_on, s));
     } else {
-        const auto key = std::make_tuple(method, B, (int)cfg_on, mask_mode, fbits(cfg_strength), fbits(dt_euler), fbits(t_scale), (int)has_ids);
+        const auto key = std::make_tuple(method, B, (int)cfg_on, mask_mode, fbits(cfg_strength), fbits(dt_euler), fbits(t_scale), (int)has_ids | ((int)pre_on << 1));
         auto it = u->graphs.find(key);
         if (it == u->graphs.end()) {
             hipGraph_t graph = nullptr;
             FC_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            const int r = enqueue_step(u, method, B, cfg_on, cfg_strength, dt_euler, t_scale, has_ids, mask_mode, s);
+            const int r = enqueue_step(u, method, B, cfg_on, cfg_strength, dt_euler, t_scale, has_ids, mask_mode, pre_on, s);
             const hipError_t e = hipStreamEndCapture(s, &graph);
             if (r != FC_OK) { if (graph) (void)hipGraphDestroy(graph); return r; }
             if (e != hipSuccess) return fail(FC_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));

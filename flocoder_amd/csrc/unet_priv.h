@@ -31,6 +31,10 @@ struct fc_unet : fc::ParamStore {
     int ts_cap = 0;
     float *y = nullptr, *xs = nullptr, *k1 = nullptr, *k2 = nullptr, *k3 = nullptr, *v2 = nullptr, *mask_own = nullptr;
     int64_t* ids_own = nullptr;
+    float* pre = nullptr;                    // conditioning of every evaluation of the running integration (CondFetch): tv | t_emb | h | c1 | ss
+    size_t pre_cap = 0;                      // floats
+    float* pre_ss = nullptr;                 // the [evaluation][row][S] part of `pre`
+    fc::TembArgs temb_proto;                 // weights of the conditioning chain as the plan's own launches use them
     std::map<std::tuple<int, int, int, int, uint32_t, uint32_t, uint32_t, int>, hipGraphExec_t> graphs;
 
     bool keep_all = false;   // plans keep every intermediate (q/k/v, attention output) for the backward: set by fc_unet_train_reserve

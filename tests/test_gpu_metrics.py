@@ -19,7 +19,7 @@ def test_sinkhorn_matches_oracle(n, m, d, scale, shift):
     y = torch.randn(m, d, generator=g) * scale + shift
     want, winfo = mo.sinkhorn_divergence(x, y, return_info=True)
     got, info = sinkhorn_divergence(x.to(DEV), y.to(DEV), return_info=True)
-    assert info["iterations"] == winfo["iterations"] and abs(info["diameter"] - winfo["diameter"]) < 1e-9 * winfo["diameter"]
+    assert info["iterations"] == winfo["iterations"] and abs(info["diameter"] - winfo["diameter"]) < 1e-7 * winfo["diameter"]
     assert abs(got - want) <= 1e-6 * max(1.0, abs(want)), (got, want)
 
 

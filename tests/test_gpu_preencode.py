@@ -70,7 +70,7 @@ def test_vqvae_preencode_with_quantize(tmp_path):
     want = torch.cat([vq.encode(sd, x) for x, _ in batches])
     r = process_dataset(m, batches, tmp_path / "midi", DEV, n_classes=0, max_batches=2)
     assert r["samples"] == 4                                                  # the batch budget of preencode_data.py:100
-    ds = PreEncodedDataset(str(tmp_path / "midi"))
+    ds = PreEncodedDataset(str(tmp_path / "midi"), n_classes=0)   # the "00".."99" bucket directories are digits: class handling must be off
     assert ds.n_classes == 0 and sorted(p.parent.name for p in ds.files) == ["00", "00", "01", "01"]
     _check(ds, list(want[:4]), torch.zeros(4), 2e-5)
     z = encode_batch(m, batches[0][0], DEV)

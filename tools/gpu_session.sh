@@ -13,6 +13,8 @@ for s in $STEPS; do
     tests)     timeout -k 10 1000 python -m pytest tests -m gpu -x -q -s > $OUT/tests.log 2>&1; rc=$?; tail -5 $OUT/tests.log; [ $rc -ne 0 ] && exit $rc ;;
     bench)     timeout -k 10 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; rc=$?; tail -c 600 $OUT/bench.json; [ $rc -ne 0 ] && { tail -20 $OUT/bench.err; exit $rc; } ;;
     benchq)    timeout -k 10 300 python bench.py --no-cpu-baseline --no-secondary > $OUT/benchq.json 2> $OUT/benchq.err; rc=$?; tail -c 400 $OUT/benchq.json; [ $rc -ne 0 ] && { tail -20 $OUT/benchq.err; exit $rc; } ;;
+    benchft)   FLOCODER_AMD_FUSED_TAIL=1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-secondary > $OUT/bench_ft.json 2> $OUT/bench_ft.err; rc=$?; tail -c 300 $OUT/bench_ft.json; [ $rc -ne 0 ] && { tail -20 $OUT/bench_ft.err; exit $rc; } ;;
+    stamps)    timeout -k 10 300 python tools/conv_stamps.py > $OUT/stamps.txt 2>&1 || { tail $OUT/stamps.txt; exit 1; }; tail -40 $OUT/stamps.txt ;;
     rehearse2) FLOCODER_AMD_SINGLE_GPU=1 FLOCODER_AMD_DIST_BACKEND=gloo timeout -k 10 400 python bench.py --gpus 2 --steps 2 --warmup 1 --no-roofline > $OUT/bench_2rank.json 2> $OUT/bench_2rank.err; rc=$?; tail -c 400 $OUT/bench_2rank.json; [ $rc -ne 0 ] && { tail -20 $OUT/bench_2rank.err; exit $rc; } ;;
     counters)  rocprofv3 -L > $OUT/counters.txt 2>&1; grep -i -c mfma $OUT/counters.txt ;;
     optable)   timeout -k 10 300 python tools/op_table.py > $OUT/op_table.txt 2>&1 || exit 1; tail -3 $OUT/op_table.txt ;;
