@@ -75,6 +75,8 @@ SIGNATURES = {
     "fc_vae_flops_per_sample": (C.c_double, [_vp, _i]),
     "fc_vae_plan_launches": (_i, [_vp, _i]),
     "fc_vqvae_create": (_i, [_i, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "fc_vqvae_create_ex": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "fc_na2d": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "fc_vqvae_destroy": (None, [_vp]),
     "fc_vqvae_param_count": (_i, [_vp]),
     "fc_vqvae_param_numel": (_i64, [_vp]),

@@ -324,17 +324,23 @@ class VQVAE(nn.Module):
 
     def __init__(self, in_channels=3, hidden_channels=256, num_downsamples=3, vq_num_embeddings=512, internal_dim=256,
                  codebook_levels=3, vq_embedding_dim=4, commitment_weight=0.25, use_checkpoint=False, no_natten=False,
-                 encoder_nonlocal=False, decoder_nonlocal=True):
+                 encoder_nonlocal=False, decoder_nonlocal=True, natten_layout=0):
+        """``natten_layout``: 0 = no NATTENBlocks (what the reference builds when the natten package is missing or ``no_natten``),
+        1 / 2 = with them (needed to load a checkpoint TRAINED with NATTEN): 1 reads the 7x7 windows over image rows x
+        columns per head, 2 reproduces what natten >= 0.20 makes of the reference's [B, heads, H, W, d] call (include/flocoder_amd.h,
+        fc_vqvae_create_ex).  Third-party arithmetic, parity unpinned."""
         super().__init__()
         if encoder_nonlocal:
             raise NotImplementedError("VQVAE(encoder_nonlocal=True) is not built (no reference config uses it)")
+        natten_layout = 0 if no_natten else int(natten_layout)
         self.in_channels, self.num_downsamples = in_channels, num_downsamples
         self.codebook_levels, self.vq_num_embeddings = codebook_levels, vq_num_embeddings
         self.vq_embedding_dim, self.indices, self.info = vq_embedding_dim, None, None
-        self._cfg = (in_channels, hidden_channels, num_downsamples, internal_dim, vq_embedding_dim, int(bool(decoder_nonlocal)))
+        self._cfg = (in_channels, hidden_channels, num_downsamples, internal_dim, vq_embedding_dim, int(bool(decoder_nonlocal)), natten_layout)
+        self.natten_layout = natten_layout
         lib = B.lib()
         h = C.c_void_p()
-        B.check(lib.fc_vqvae_create(*self._cfg, -1, C.byref(h)))
+        B.check(lib.fc_vqvae_create_ex(*self._cfg, -1, C.byref(h)))
         try:
             self._table = []
             for i in range(lib.fc_vqvae_param_count(h)):
@@ -352,6 +358,14 @@ class VQVAE(nn.Module):
                     node.add_module(part, _Node())
                 node = getattr(node, part)
             p = torch.empty(shape, dtype=torch.float32)
+            if leaf == "gamma":
+                p.zero_()                                                 # NATTENBlock's residual gate starts closed (codecs.py:105)
+                node.register_parameter(leaf, nn.Parameter(p, requires_grad=False))
+                continue
+            if name.endswith((".attn.qkv.weight", ".attn.proj.weight")):
+                p.normal_(0.0, 0.02)                                      # codecs.py:108-109
+                node.register_parameter(leaf, nn.Parameter(p, requires_grad=False))
+                continue
             if leaf == "weight" and len(shape) > 1:                       # nn.Conv2d default init (kaiming_uniform, a=sqrt(5))
                 nn.init.kaiming_uniform_(p, a=math.sqrt(5))
             elif leaf == "weight":
@@ -388,7 +402,7 @@ class VQVAE(nn.Module):
         if self._handle is None or self._handle_device != device:
             self._release()
             h = C.c_void_p()
-            B.check(lib.fc_vqvae_create(*self._cfg, device.index or 0, C.byref(h)))
+            B.check(lib.fc_vqvae_create_ex(*self._cfg, device.index or 0, C.byref(h)))
             self._handle, self._handle_device, self._synced = h, device, None
         sd = dict(self.named_parameters())
         ver = tuple((sd[n].data_ptr(), sd[n]._version) for n, _, _ in self._table)
@@ -514,18 +528,7 @@ def setup_codec(config, device, no_natten=False, load_checkpoint=True, eval=True
         raise NotImplementedError("codec 'vqgan_plus' is codec-training territory and outside the flow hot path (SURVEY.md 2)")
     else:
         print("Loading VQVAE model")
-        codec = VQVAE(                                                    # codecs.py:707-718
-            in_channels=ldcfg(config, 'in_channels', 3, verbose=False),
-            hidden_channels=ldcfg(config, 'hidden_channels', 256, verbose=False),
-            num_downsamples=ldcfg(config, 'num_downsamples', 3, verbose=False),
-            internal_dim=ldcfg(config, 'internal_dim', 256, verbose=False),
-            vq_embedding_dim=ldcfg(config, 'vq_embedding_dim', 4, verbose=False),
-            codebook_levels=ldcfg(config, 'codebook_levels', 4, verbose=False),
-            vq_num_embeddings=ldcfg(config, 'vq_num_embeddings', 512, verbose=False),
-            commitment_weight=ldcfg(config, 'commitment_weight', 0.5, verbose=False),
-            use_checkpoint=not config.get('no_grad_ckpt', False),
-            no_natten=no_natten,
-        ).to(device)
+        checkpoint = None
         if load_checkpoint:
             if 'vqgan_checkpoint' in config:
                 path = config.vqgan_checkpoint
@@ -540,7 +543,31 @@ def setup_codec(config, device, no_natten=False, load_checkpoint=True, eval=True
                 checkpoint = torch.load(path, map_location=device, weights_only=True)
             except Exception:
                 checkpoint = torch.load(path, map_location=device, weights_only=False)
-            codec.load_state_dict(checkpoint['model_state_dict'], strict=False)   # strict=False: vq.* / NATTEN keys are ignored
+        # A checkpoint trained WITH the natten package carries NATTENBlock weights ('...attn.qkv.weight', codecs.py:93-145).  Upstream
+        # such a model silently loses its attention when the package is missing; here the blocks are native
+        # (fc_vqvae_create_ex), so they are built whenever the checkpoint has them -- unless no_natten asks for upstream's fallback.
+        natten_layout = 0
+        if checkpoint is not None and any(k.endswith('.attn.qkv.weight') for k in checkpoint['model_state_dict']):
+            if no_natten:
+                print("Warning: the checkpoint holds NATTEN attention blocks and no_natten=True drops them (as upstream without the package)")
+            else:
+                natten_layout = int(ldcfg(config, 'natten_layout', 2, verbose=False) or 2)
+                print(f"Codec checkpoint holds NATTEN blocks: building them natively (natten_layout={natten_layout}; 2 = what natten >= 0.20, "
+                      "the reference's pinned minimum, computes from its call; set codec.natten_layout=1 for windows over image rows x columns)")
+        codec = VQVAE(                                                    # codecs.py:707-718
+            in_channels=ldcfg(config, 'in_channels', 3, verbose=False),
+            hidden_channels=ldcfg(config, 'hidden_channels', 256, verbose=False),
+            num_downsamples=ldcfg(config, 'num_downsamples', 3, verbose=False),
+            internal_dim=ldcfg(config, 'internal_dim', 256, verbose=False),
+            vq_embedding_dim=ldcfg(config, 'vq_embedding_dim', 4, verbose=False),
+            codebook_levels=ldcfg(config, 'codebook_levels', 4, verbose=False),
+            vq_num_embeddings=ldcfg(config, 'vq_num_embeddings', 512, verbose=False),
+            commitment_weight=ldcfg(config, 'commitment_weight', 0.5, verbose=False),
+            use_checkpoint=not config.get('no_grad_ckpt', False),
+            no_natten=no_natten, natten_layout=natten_layout,
+        ).to(device)
+        if checkpoint is not None:
+            codec.load_state_dict(checkpoint['model_state_dict'], strict=False)   # strict=False: vq.* training buffers may be absent
     if eval:
         codec = codec.eval()
     print("Codec model ready")

@@ -8,6 +8,8 @@
 //   * loss, gradient norm, Adam + EMA on flat parameter vectors (reference: torch.optim.Adam, clip_grad_norm_, EMA.update).
 // Every reduction runs in a fixed order (no atomics): a step is bit-reproducible.
 #include <cmath>
+#include <cstdlib>
+#include <string>
 
 #include "common.h"
 #include "stats_dev.h"
@@ -139,11 +141,121 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const GnBwdArgs a, in
     }
 }
 
+// The same two passes as ONE launch when a sample's tensor is small (HW*C <= 8192 floats, C a power of two): one workgroup per
+// sample reduces, meets in LDS and applies, re-reading h / dy from cache.  At the training shapes (B = 32, 16x16 latents) the two
+// launches above were pure latency, 55 times per step.  256 threads; thread t owns float4 columns c0 = 4t mod C of rows t*4/C + k*1024/C.
+__global__ void __launch_bounds__(256) gn_bwd_small_kernel(const GnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* gt = sm;                       // [G][4]
+    float* A = gt + 4 * a.xf.G;
+    float* Bv = A + a.C;
+    float* ga = Bv + a.C;
+    float* f1 = ga + a.C;
+    float* f2 = f1 + a.C;
+    float* r1 = f2 + a.C;                 // [256][4]
+    float* r2 = r1 + 1024;
+    const int b = blockIdx.x, tid = threadIdx.x, C = a.C, cpg = C / a.xf.G, total = a.HW * C;
+    const size_t base = (size_t)b * total;
+    const bool act = a.xf.mode == 2;
+    // operands that depend on nothing computed here: requested together
+    const int c0 = (4 * tid) & (C - 1);
+    float4 hv[8], dv[8];                  // up to 8192 / 1024 float4 per thread of each tensor
+    const int nk = (total + 1023) >> 10;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = 4 * tid + 1024 * k;
+        const bool in = k < nk && i < total;
+        hv[k] = in ? *reinterpret_cast<const float4*>(a.h + base + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dv[k] = in ? *reinterpret_cast<const float4*>(a.dy + base + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int g = tid; g < a.xf.G; g += 256) combine_partials(a.xf, b, g, &gt[4 * g], &gt[4 * g + 1]);
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / cpg;
+        const float mean = gt[4 * g], rstd = gt[4 * g + 1];
+        float gam = a.xf.gamma[c];
+        float s = rstd * gam, t = a.xf.beta[c] - mean * s;
+        if (a.xf.ss) {
+            const float sc = a.xf.ss[(size_t)b * a.xf.ss_stride + c] + 1.0f;
+            const float sh = a.xf.ss[(size_t)b * a.xf.ss_stride + C + c];
+            s *= sc; t = t * sc + sh; gam *= sc;
+        }
+        A[c] = s; Bv[c] = t; ga[c] = gam * rstd;
+    }
+    __syncthreads();
+    // pass 1: du = dy * act'(u) kept in dv; per-thread sums of du and du * xhat for its four channels
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float mean4[4], rstd4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int g = (c0 + j) / cpg; mean4[j] = gt[4 * g]; rstd4[j] = gt[4 * g + 1]; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (k >= nk || 4 * tid + 1024 * k >= total) break;
+        float hs[4] = {hv[k].x, hv[k].y, hv[k].z, hv[k].w}, ds[4] = {dv[k].x, dv[k].y, dv[k].z, dv[k].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float du = ds[j];
+            if (act) du *= silu_grad_e(A[c0 + j] * hs[j] + Bv[c0 + j]);
+            ds[j] = du;
+            s1[j] += du;
+            s2[j] += du * ((hs[j] - mean4[j]) * rstd4[j]);
+        }
+        dv[k] = make_float4(ds[0], ds[1], ds[2], ds[3]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { r1[4 * tid + j] = s1[j]; r2[4 * tid + j] = s2[j]; }
+    __syncthreads();
+    const int q = C >> 2, rows = 256 / q;          // threads t, t + q, t + 2q ... share the same four channels (C <= 1024: q <= 256)
+    for (int c = tid; c < C; c += 256) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int r = 0; r < rows; ++r) { t1 += r1[(r * q + (c >> 2)) * 4 + (c & 3)]; t2 += r2[(r * q + (c >> 2)) * 4 + (c & 3)]; }
+        f1[c] = t1; f2[c] = t2;
+        a.s12[((size_t)b * C + c) * 2] = t1;
+        a.s12[((size_t)b * C + c) * 2 + 1] = t2;
+    }
+    __syncthreads();
+    for (int g = tid; g < a.xf.G; g += 256) {
+        float p1 = 0.f, p2 = 0.f;
+        const float rstd = gt[4 * g + 1];
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            const float gp = ga[c] / rstd;
+            p1 += gp * f1[c];
+            p2 += gp * f2[c];
+        }
+        const float inv_n = 1.0f / ((float)a.HW * (float)cpg);
+        gt[4 * g + 2] = rstd * p1 * inv_n;
+        gt[4 * g + 3] = rstd * p2 * inv_n;
+    }
+    __syncthreads();
+    float k1[4], k2[4], gaj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int g = (c0 + j) / cpg; k1[j] = gt[4 * g + 2]; k2[j] = gt[4 * g + 3]; gaj[j] = ga[c0 + j]; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = 4 * tid + 1024 * k;
+        if (k >= nk || i >= total) break;
+        const float hs[4] = {hv[k].x, hv[k].y, hv[k].z, hv[k].w}, ds[4] = {dv[k].x, dv[k].y, dv[k].z, dv[k].w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = gaj[j] * ds[j] - k1[j] - ((hs[j] - mean4[j]) * rstd4[j]) * k2[j];
+        float4* dst = reinterpret_cast<float4*>(a.dh + base + i);
+        if (a.accumulate) { const float4 p = *dst; o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w; }
+        *dst = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 int gn_bwd_chunks(int HW) { return (HW + kGnChunk - 1) / kGnChunk; }
 
 int gn_bwd_launch(const GnBwdArgs& a, hipStream_t s) {
     if (a.C & 3) return fail(FC_E_SHAPE, "gn_bwd: C must be a multiple of 4");
     if (!a.xf.mode || !a.xf.stats || !a.s12 || !a.s12p || !a.dh) return fail(FC_E_ARG, "gn_bwd: needs statistics and workspaces");
+    static const bool no_small = std::getenv("FLOCODER_AMD_GN_BWD_SPLIT") != nullptr;
+    if (!no_small && a.HW * a.C <= 8192 && (a.C & (a.C - 1)) == 0 && a.C <= 1024 && a.C % a.xf.G == 0) {
+        const size_t lds = (size_t)(4 * a.xf.G + 5 * a.C + 2048) * sizeof(float);
+        hipLaunchKernelGGL(gn_bwd_small_kernel, dim3(a.B), dim3(256), lds, s, a);
+        FC_HIP(hipGetLastError());
+        return FC_OK;
+    }
     int CW = 4;
     while (CW < a.C && CW < 64) CW *= 2;
     const int nchunks = gn_bwd_chunks(a.HW);

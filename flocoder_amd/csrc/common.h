@@ -234,6 +234,9 @@ int attn_small_launch(const float* qkv, float* out, int B, int n, int heads, hip
 // interval in flight.  All arithmetic is fp32 in the reference's operation order (sampling.py:43-48,74),
 // with FMA contraction disabled, so a step is reproducible against the CPU oracle to rounding.
 // First kernel of a step: reads ts[*step], publishes sc/tvec, then advances the counter.
+int delay_launch(long long cycles, hipStream_t s);
+// 2-D neighbourhood attention on a fused NHWC qkv tensor (natten.hip)
+int na2d_launch(const float* qkv, float* out, const float* gamma, int B, int H, int W, int C, int heads, int ksize, int mode, hipStream_t s);
 int ode_all_times_launch(const float* ts, int n_steps, int rk4, float t_scale, float* tv_out, hipStream_t s);
 int ode_time_launch(int* step, const float* ts, float t_scale, int rk4, float* sc, float* tvec, int rows, hipStream_t s);
 // v = cfg_on ? v_nc + cfg*(v_c - v_nc) : v   with v2 = [v_c ; v_nc] (n elements each)

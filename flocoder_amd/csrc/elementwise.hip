@@ -177,6 +177,18 @@ int gn_stats_launch(const float* x, float* stats, int B, int HW, int C, int G, h
     return FC_OK;
 }
 
+// One wave that does nothing for `cycles` shader clocks: offsets the second row-range chain against the first so that their
+// load / MFMA / store phases interleave on a CU instead of marching in step (FLOCODER_AMD_CHAINS=2, unet.hip run_forward).
+__global__ void __launch_bounds__(64) delay_kernel(long long cycles) {
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    while ((long long)__builtin_amdgcn_s_memtime() - t0 < cycles) __builtin_amdgcn_s_sleep(8);
+}
+int delay_launch(long long cycles, hipStream_t s) {
+    hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, s, cycles);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // init_conv (unet.py:185-186,295): 1x1 conv reading the NCHW boundary tensor, writing NHWC.
 // Blocks beyond `conv_blocks` fetch this evaluation's precomputed scale / shift rows into the plan's table (CondFetch, common.h): the

@@ -601,6 +601,8 @@ static int run_forward(fc_unet* u, const FwdCtx& c, hipStream_t s) {
     const size_t sf = (size_t)u->cfg.channels * u->H * u->W;
     FC_HIP(hipEventRecord(u->ev_fork, s));
     FC_HIP(hipStreamWaitEvent(u->stream2, u->ev_fork, 0));
+    static const long long delay = [] { const char* e = std::getenv("FLOCODER_AMD_CHAIN_DELAY_US"); return e ? (long long)(std::atof(e) * 2100.0) : 0ll; }();
+    if (delay > 0) FC_TRY(delay_launch(delay, u->stream2));   // the second chain runs half a kernel behind the first
     FC_TRY(run_plan(u->plan[1], slice_ctx(c, r0, c.B - r0, sf), u->stream2));
     FC_HIP(hipEventRecord(u->ev_join, u->stream2));
     FC_TRY(run_plan(u->plan[0], slice_ctx(c, 0, r0, sf), s));

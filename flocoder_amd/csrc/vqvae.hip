@@ -12,11 +12,11 @@
 
 using namespace fc;
 
-struct fc_vqvae_config_s { int in_channels, hidden_channels, num_downsamples, internal_dim, vq_embedding_dim, decoder_nonlocal; };
+struct fc_vqvae_config_s { int in_channels, hidden_channels, num_downsamples, internal_dim, vq_embedding_dim, decoder_nonlocal, natten = 0; };
 
 struct fc_vqvae : fc::ParamStore {
     int device = 0;
-    fc_vqvae_config_s c{3, 256, 3, 256, 4, 1};
+    fc_vqvae_config_s c{3, 256, 3, 256, 4, 1, 0};
     fc::Plan enc, dec;
 };
 
@@ -42,7 +42,9 @@ static void decl_conv_any(fc_vqvae* v, const std::string& n, int O, int I, int K
 }
 static const float* bias_of(const fc_vqvae* v, const std::string& n) { return v->pk.count(n + ".bias") ? v->P(n + ".bias") : v->R(n + ".bias"); }
 
-static void decl_block(fc_vqvae* v, const std::string& n, int ci, int co, int stride, bool full_attn) {
+// attn: 0 none | 1 AttnBlock ('full', codecs.py:52-90) | 2 NATTENBlock ('natten', codecs.py:93-145: GroupNorm, bias-free qkv / proj Linears, scalar gate)
+static void decl_block(fc_vqvae* v, const std::string& n, int ci, int co, int stride, int attn) {
+    const bool full_attn = attn == 1;
     decl_conv_any(v, n + ".conv1", co, ci, 3);
     v->decl_norm(n + ".norm1", co);
     v->decl_conv(n + ".conv2", co, co, 3);
@@ -52,19 +54,29 @@ static void decl_block(fc_vqvae* v, const std::string& n, int ci, int co, int st
         v->decl_norm(n + ".attn.norm.norm", co);
         for (const char* p : {".attn.q", ".attn.k", ".attn.v", ".attn.proj_out"}) v->decl_conv(n + p, co, co, 1);
     }
+    if (attn == 2) {   // state_dict order of NATTENBlock: its own parameter (gamma) first, then the sub-modules norm, qkv, proj
+        v->declare(n + ".attn.gamma", {1});
+        v->decl_norm(n + ".attn.norm", co);
+        for (auto pr : {std::make_pair(".attn.qkv", 3 * co), std::make_pair(".attn.proj", co)}) {   // nn.Linear [out][in] -> operand [in][out]
+            v->declare(n + pr.first + ".weight", {pr.second, co});
+            const int64_t dst = v->pk_alloc(n + pr.first + ".weight", (int64_t)pr.second * co);
+            v->packops.push_back({2, v->params[v->pidx[n + pr.first + ".weight"]].offset, dst, pr.second, co, pr.second, 0});
+        }
+    }
 }
 
 static int declare_all(fc_vqvae* v) {
     const auto& c = v->c;
     const int nd = c.num_downsamples, hid = c.hidden_channels, emb = c.vq_embedding_dim;
     int cur = c.in_channels;
+    const int na = c.natten ? 2 : 0;       // with NATTEN: the last two encoder levels and the bottleneck block (codecs.py:414-429)
     for (int i = 0; i < nd; ++i) {
-        const int co = hid << i;
-        decl_block(v, "encoder." + std::to_string(2 * i), cur, co, 2, false);
-        decl_block(v, "encoder." + std::to_string(2 * i + 1), co, co, 1, false);
+        const int co = hid << i, at = i >= nd - 2 ? na : 0;
+        decl_block(v, "encoder." + std::to_string(2 * i), cur, co, 2, at);
+        decl_block(v, "encoder." + std::to_string(2 * i + 1), co, co, 1, at);
         cur = co;
     }
-    decl_block(v, "encoder." + std::to_string(2 * nd), cur, c.internal_dim, 1, false);
+    decl_block(v, "encoder." + std::to_string(2 * nd), cur, c.internal_dim, 1, na);
     v->decl_conv("encoder." + std::to_string(2 * nd + 1), c.internal_dim, c.internal_dim, 1);
     v->decl_conv("encoder." + std::to_string(2 * nd + 2), emb, c.internal_dim, 1);
     v->decl_norm("encoder." + std::to_string(2 * nd + 3), emb);
@@ -84,14 +96,14 @@ static int declare_all(fc_vqvae* v) {
     v->decl_conv(L + std::to_string(i), c.internal_dim, emb, 1);
     v->decl_norm(L + std::to_string(i + 1), c.internal_dim);
     v->decl_conv(L + std::to_string(i + 3), cur, c.internal_dim, 1);
-    decl_block(v, L + std::to_string(i + 5), cur, cur, 1, c.decoder_nonlocal != 0);
+    decl_block(v, L + std::to_string(i + 5), cur, cur, 1, c.decoder_nonlocal ? 1 : na);   // attn = 'full' if decoder_nonlocal else 'natten' (codecs.py:266)
     i += 6;
     for (int lvl = nd - 1; lvl >= 0; --lvl) {
         int co = hid << (lvl - 1 > 0 ? lvl - 1 : 0);
         if (lvl == 0) co = hid;
         v->decl_conv(L + std::to_string(i), 4 * cur, cur, 3);
-        decl_block(v, L + std::to_string(i + 4), cur, co, 1, false);
-        decl_block(v, L + std::to_string(i + 6), co, co, 1, false);
+        decl_block(v, L + std::to_string(i + 4), cur, co, 1, lvl > nd - 2 ? na : 0);                // first upsampling level only (codecs.py:275-278)
+        decl_block(v, L + std::to_string(i + 6), co, co, 1, 0);
         cur = co;
         i += 7;
     }
@@ -134,6 +146,33 @@ struct QBuilder : PlanBuilder {
                           v->P(n + ".attn.v.weight"), v->R(n + ".attn.v.bias"), v->P(n + ".attn.proj_out.weight"), v->R(n + ".attn.proj_out.bias")};
             Act a2 = attention_block(a1, gn(sa, n + ".attn.norm.norm", 1, 1e-6f), w, 0, nullptr);
             release(a1);
+            mid_in = a2; mid_raw = true;
+        }
+        if (v->has(n + ".attn.qkv.weight")) {                     // attention='natten': NATTENBlock on the activated tensor (codecs.py:93-145)
+            Act a1 = act(co, Ho, Wo);
+            FinalizeArgs f;
+            f.h = h1.p; f.xf = mid_xf; f.y = a1.p; f.HW = Ho * Wo; f.C = co;
+            push([f](const FwdCtx& c, hipStream_t s) { FinalizeArgs g = f; g.B = c.B; return finalize_launch(g, s); }, "finalize");
+            const int G8 = gn_groups(8, co);
+            Stat sa = stat(G8, 1, (float)(Ho * Wo * (co / G8)));
+            float* sp = sa.p; const float* ap = a1.p; const int HW = Ho * Wo;
+            push([=](const FwdCtx& c, hipStream_t s) { return gn_stats_launch(ap, sp, c.B, HW, co, G8, s); }, "gn_stats");
+            Act qkv = act(3 * co, Ho, Wo), att = act(co, Ho, Wo), a2 = act(co, Ho, Wo);
+            ConvArgs q;
+            q.s0.p = a1.p; q.s0.C = co; q.s0.xf = gn(sa, n + ".attn.norm", 1);
+            q.Hs = Ho; q.Ws = Wo; q.KS = 1;
+            q.w = v->P(n + ".attn.qkv.weight");
+            conv(q, qkv, 0, nullptr);
+            const float *qp = qkv.p, *gam = v->R(n + ".attn.gamma");
+            float* tp = att.p;
+            const int mode = v->c.natten;
+            push([=](const FwdCtx& c, hipStream_t s) { return na2d_launch(qp, tp, gam, c.B, Ho, Wo, co, 8, 7, mode, s); }, "na2d",
+                 2.0 * 2 * 49 * (double)co * Ho * Wo);
+            ConvArgs pj;                                            // identity + gamma * proj(att): gamma rides in na2d's output (proj is linear, no bias)
+            pj.s0.p = att.p; pj.s0.C = co; pj.Hs = Ho; pj.Ws = Wo; pj.KS = 1;
+            pj.w = v->P(n + ".attn.proj.weight"); pj.add = a1.p;
+            conv(pj, a2, 0, nullptr);
+            release(qkv); release(att); release(a1);
             mid_in = a2; mid_raw = true;
         }
         Act h2 = act(co, Ho, Wo);
@@ -307,14 +346,17 @@ static int build_decoder(fc_vqvae* v, int maxB, int h, int w) {
 
 extern "C" {
 
-int fc_vqvae_create(int in_channels, int hidden_channels, int num_downsamples, int internal_dim, int vq_embedding_dim, int decoder_nonlocal,
-                    int device, fc_vqvae** out) {
+int fc_vqvae_create_ex(int in_channels, int hidden_channels, int num_downsamples, int internal_dim, int vq_embedding_dim, int decoder_nonlocal,
+                       int natten_layout, int device, fc_vqvae** out) {
     if (!out || in_channels < 1 || hidden_channels < 8 || num_downsamples < 1 || num_downsamples > 6 || internal_dim < 4 || vq_embedding_dim < 1)
         return fail(FC_E_ARG, "fc_vqvae_create: bad config");
+    if (natten_layout < 0 || natten_layout > 2) return fail(FC_E_ARG, "fc_vqvae_create: natten_layout must be 0 (no NATTEN blocks), 1 or 2");
     if ((hidden_channels & 3) || (internal_dim & 3) || (vq_embedding_dim & 3)) return fail(FC_E_SHAPE, "vqvae: hidden, internal and embedding widths must be multiples of 4");
+    if (natten_layout && ((hidden_channels % 32) || (internal_dim % 32)))
+        return fail(FC_E_SHAPE, "vqvae: NATTEN blocks need widths that are multiples of 32 (8 heads, head_dim a multiple of 4)");
     std::unique_ptr<fc_vqvae> v(new fc_vqvae);
     v->device = device;
-    v->c = {in_channels, hidden_channels, num_downsamples, internal_dim, vq_embedding_dim, decoder_nonlocal};
+    v->c = {in_channels, hidden_channels, num_downsamples, internal_dim, vq_embedding_dim, decoder_nonlocal, natten_layout};
     FC_TRY(declare_all(v.get()));
     if (device < 0) { *out = v.release(); return FC_OK; }
     FC_TRY(fc_check_device(device));
@@ -324,6 +366,10 @@ int fc_vqvae_create(int in_channels, int hidden_channels, int num_downsamples, i
     FC_HIP(hipMemset(v->packed, 0, (size_t)(v->packed_numel ? v->packed_numel : 4) * sizeof(float)));
     *out = v.release();
     return FC_OK;
+}
+int fc_vqvae_create(int in_channels, int hidden_channels, int num_downsamples, int internal_dim, int vq_embedding_dim, int decoder_nonlocal,
+                    int device, fc_vqvae** out) {
+    return fc_vqvae_create_ex(in_channels, hidden_channels, num_downsamples, internal_dim, vq_embedding_dim, decoder_nonlocal, 0, device, out);
 }
 void fc_vqvae_destroy(fc_vqvae* v) {
     if (!v) return;

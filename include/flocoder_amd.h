@@ -220,6 +220,18 @@ typedef struct fc_vqvae fc_vqvae;
 /* Constructor arguments of VQVAE (codecs.py:399-405); widths must be multiples of 4.  device < 0: description only. */
 int fc_vqvae_create(int in_channels, int hidden_channels, int num_downsamples, int internal_dim, int vq_embedding_dim, int decoder_nonlocal,
                     int device, fc_vqvae** out);
+/* The same with NATTENBlocks (codecs.py:93-145; 7x7 neighbourhood attention, 8 heads) in the EncDecResidualBlocks the reference
+ * gives them to when the natten package is importable: the last two encoder levels, the bottleneck block, the first decoder block
+ * (decoder_nonlocal == 0) and the first upsampling level (codecs.py:266,275-278,414-429).  natten_layout: 0 = none (fc_vqvae_create),
+ * 1 = windows over image rows x columns per head (the intended reading), 2 = what natten >= 0.20 computes from the reference's
+ * [B, heads, H, W, d] tensors (windows over head index x image rows, per image column).  PARITY UNPINNED: the package is absent. */
+int fc_vqvae_create_ex(int in_channels, int hidden_channels, int num_downsamples, int internal_dim, int vq_embedding_dim,
+                       int decoder_nonlocal, int natten_layout, int device, fc_vqvae** out);
+/* 2-D neighbourhood attention by itself: qkv_nhwc_dev [B][H][W][3C] (channel = which*C + head*(C/heads) + d), out [B][H][W][C],
+ * kernel_size odd <= 7, windows clamped (shifted) at the borders, scale (C/heads)^-0.5, optional scalar gate gamma_dev[0].
+ * Replaces natten.functional.na2d / na2d_qk + softmax + na2d_av (codecs.py:130-135). */
+int fc_na2d(const float* qkv_nhwc_dev, float* out_nhwc_dev, const float* gamma_dev, int batch, int height, int width, int channels,
+            int heads, int kernel_size, int layout_mode, void* stream);
 void fc_vqvae_destroy(fc_vqvae* v);
 /* Parameter table: the reference's state_dict keys ("encoder.0.conv1.weight", "decoder.layers.0.q_proj.weight", ...). */
 int fc_vqvae_param_count(const fc_vqvae* v);

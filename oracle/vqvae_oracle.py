@@ -5,7 +5,9 @@ TEST INFRASTRUCTURE ONLY -- see ``oracle/__init__.py``.  Parity status: PINNED f
 package, which neither method calls) on seeded weights and ``tests/test_oracle_golden.py`` holds this file to the result
 (fixture g9).  ``quantize`` = ``vector_quantize_pytorch.ResidualVQ`` (``>=1.22.4``, pyproject.toml:41; call sites codecs.py:456-467,
 504-521) is third-party and absent: ``residual_vq`` / ``quantize`` below restate its published INFERENCE behaviour -- PARITY
-UNPINNED.  NATTEN is absent here, so ``attention='natten'`` blocks have no attention (codecs.py:170-175, SURVEY Q23);
+UNPINNED.  NATTEN is absent here, so in the pinned fixtures ``attention='natten'`` blocks have no attention (codecs.py:170-175,
+SURVEY Q23); state dicts that DO carry ``attn.qkv`` weights run ``natten_block`` / ``na2d`` below -- a restatement of the package's
+published neighbourhood-attention definition, PARITY UNPINNED;
 eval mode: dropout is the identity and NoiseInjection is a no-op at noise_strength 0 (codecs.py:229-232).
 """
 from __future__ import annotations
@@ -51,11 +53,55 @@ def attn_block(sd: SD, n: str, x: Tensor) -> Tensor:
     return x + _conv(sd, n + ".proj_out", o)
 
 
-def res_block(sd: SD, n: str, x: Tensor, stride: int = 1) -> Tensor:
+def na2d(q: Tensor, k: Tensor, v: Tensor, kernel_size: int = 7, scale: float | None = None) -> Tensor:
+    """2-D neighbourhood attention on [B, X, Y, heads, d] tensors: query (x, y) attends to the kernel_size^2 keys of the window whose
+    start along each axis is clamp(pos - kernel_size // 2, 0, L - kernel_size) (it shifts inwards at the borders: never padded), with
+    softmax(q . k * scale) and scale = d^-0.5 by default.  Restates the PUBLISHED definition of ``natten.functional.na2d`` (dilation 1,
+    non-causal, no relative position bias; natten >= 0.20.1, pyproject.toml:40).  PARITY UNPINNED: the package is absent."""
+    B, X, Y, H, D = q.shape
+    if X < kernel_size or Y < kernel_size:
+        raise ValueError("neighbourhood larger than the attended axes")
+    scale = D ** -0.5 if scale is None else scale
+    r = kernel_size // 2
+    sx = (torch.arange(X) - r).clamp(0, X - kernel_size)
+    sy = (torch.arange(Y) - r).clamp(0, Y - kernel_size)
+    ix = sx[:, None] + torch.arange(kernel_size)[None, :]                   # [X, K]
+    iy = sy[:, None] + torch.arange(kernel_size)[None, :]                   # [Y, K]
+    kw = k[:, ix][:, :, :, iy]                                              # [B, X, K, Y, K, H, D]
+    vw = v[:, ix][:, :, :, iy]
+    kw = kw.permute(0, 1, 3, 5, 2, 4, 6).reshape(B, X, Y, H, kernel_size * kernel_size, D)
+    vw = vw.permute(0, 1, 3, 5, 2, 4, 6).reshape(B, X, Y, H, kernel_size * kernel_size, D)
+    a = torch.softmax(torch.einsum("bxyhd,bxyhwd->bxyhw", q, kw) * scale, dim=-1)
+    return torch.einsum("bxyhw,bxyhwd->bxyhd", a, vw)
+
+
+def natten_block(sd: SD, n: str, x: Tensor, layout: int = 1, heads: int = 8, kernel_size: int = 7) -> Tensor:
+    """NATTENBlock._forward, codecs.py:116-140: GroupNorm(gn_groups(8, C)) -> qkv Linear (no bias) -> neighbourhood attention ->
+    proj Linear (no bias) -> identity + gamma * (.).  The reference builds q / k / v as [B, heads, H, W, d] (codecs.py:122-124).
+    ``layout`` 1 reads that as intended (7x7 windows over image rows x columns, per head); ``layout`` 2 is what a natten >= 0.20
+    ``na2d`` -- which documents [B, X, Y, heads, d] -- computes from the very same tensors: windows over (head index, image row), the
+    image column playing the part of the head.  Which one a trained checkpoint needs can only be settled against the package."""
+    B, C, H, W = x.shape
+    d = C // heads
+    t = F.group_norm(x, gn_groups(8, C), sd[n + ".norm.weight"], sd[n + ".norm.bias"]).permute(0, 2, 3, 1)      # B H W C
+    qkv = F.linear(t, sd[n + ".qkv.weight"]).reshape(B, H, W, 3, heads, d).permute(3, 0, 4, 1, 2, 5)            # 3 B heads H W d
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    if layout == 1:
+        o = na2d(q.permute(0, 2, 3, 1, 4), k.permute(0, 2, 3, 1, 4), v.permute(0, 2, 3, 1, 4), kernel_size).permute(0, 3, 1, 2, 4)
+    else:
+        o = na2d(q, k, v, kernel_size)                                                                          # dims taken as [B, X, Y, heads, d]
+    o = o.permute(0, 2, 3, 1, 4).reshape(B, H, W, C)                                                            # codecs.py:137
+    o = F.linear(o, sd[n + ".proj.weight"]).permute(0, 3, 1, 2)
+    return x + o * sd[n + ".gamma"]
+
+
+def res_block(sd: SD, n: str, x: Tensor, stride: int = 1, natten_layout: int = 1) -> Tensor:
     """EncDecResidualBlock._forward, codecs.py:178-209 (eval): silu(norm1(conv1 x)) [-> attn] -> norm2(conv2 .) + identity -> silu."""
     out = F.silu(_gn(sd, n + ".norm1", _conv(sd, n + ".conv1", x, padding=1, stride=stride), 8))
-    if (n + ".attn.q.weight") in sd:                       # attention='full'; 'natten' without NATTEN has no attn
+    if (n + ".attn.q.weight") in sd:                       # attention='full'
         out = attn_block(sd, n + ".attn", out)
+    elif (n + ".attn.qkv.weight") in sd:                   # attention='natten' with the package present (else: no attention at all)
+        out = natten_block(sd, n + ".attn", out, natten_layout)
     out = _gn(sd, n + ".norm2", _conv(sd, n + ".conv2", out, padding=1), 8)
     if (n + ".downsample.0.weight") in sd:
         x = _gn(sd, n + ".downsample.1", _conv(sd, n + ".downsample.0", x, stride=stride), 8)
@@ -94,22 +140,22 @@ def n_downsamples(sd: SD) -> int:
     return (len(blocks) - 1) // 2
 
 
-def encode(sd: SD, x: Tensor) -> Tensor:
+def encode(sd: SD, x: Tensor, natten_layout: int = 1) -> Tensor:
     """VQVAE.encode = self.encoder(x), codecs.py:414-443,492-502: 2 residual blocks per downsample (the first with stride 2), one
     more to internal_dim, a 1x1 conv, then the compress stack conv1x1 -> GroupNorm -> SiLU -> conv3x3."""
     nd = n_downsamples(sd)
     h = x
     for i in range(nd):
-        h = res_block(sd, f"encoder.{2 * i}", h, stride=2)
-        h = res_block(sd, f"encoder.{2 * i + 1}", h)
-    h = res_block(sd, f"encoder.{2 * nd}", h)
+        h = res_block(sd, f"encoder.{2 * i}", h, stride=2, natten_layout=natten_layout)
+        h = res_block(sd, f"encoder.{2 * i + 1}", h, natten_layout=natten_layout)
+    h = res_block(sd, f"encoder.{2 * nd}", h, natten_layout=natten_layout)
     h = _conv(sd, f"encoder.{2 * nd + 1}", h)
     h = _conv(sd, f"encoder.{2 * nd + 2}", h)
     h = F.silu(_gn(sd, f"encoder.{2 * nd + 3}", h, 2))
     return _conv(sd, f"encoder.{2 * nd + 5}", h, padding=1)
 
 
-def decode(sd: SD, z: Tensor) -> Tensor:
+def decode(sd: SD, z: Tensor, natten_layout: int = 1) -> Tensor:
     """VQVAE.decode -> Decoder.forward at noise_strength 0, codecs.py:245-316,523-525."""
     nd = n_downsamples(sd)
     L = "decoder.layers."
@@ -121,11 +167,11 @@ def decode(sd: SD, z: Tensor) -> Tensor:
     emb = z.shape[1]
     h = F.silu(_gn(sd, L + str(i + 1), h, emb))
     h = _conv(sd, L + str(i + 3), h)
-    h = res_block(sd, L + str(i + 5), h)                   # i+4 is a NoiseInjection
+    h = res_block(sd, L + str(i + 5), h, natten_layout=natten_layout)   # i+4 is a NoiseInjection
     i += 6
     for _ in range(nd):
         h = F.pixel_shuffle(F.silu(_conv(sd, L + str(i), h, padding=1)), 2)      # conv, SiLU, PixelShuffle(2), NoiseInjection
-        h = res_block(sd, L + str(i + 4), h)
+        h = res_block(sd, L + str(i + 4), h, natten_layout=natten_layout)
         h = res_block(sd, L + str(i + 6), h)                                       # i+5 is a NoiseInjection
         i += 7
     h = F.silu(_conv(sd, L + str(i + 1), h, padding=1))   # i is a NoiseInjection

@@ -153,3 +153,26 @@ def test_checkpoint_dict_layout(tmp_path):
     assert set(ck) == {"model_state_dict", "epoch", "optimizer_state_dict", "config"} and ck["epoch"] == 25
     m2 = load_flow_model(path, cfg, "cpu")
     assert m2.dim == 8 and m2.class_condition and all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+
+
+def test_setup_codec_builds_natten_blocks_when_the_checkpoint_has_them(tmp_path):
+    """upstream a NATTEN-trained VQGAN silently loses its attention without the package; here the blocks are native and are
+    built whenever the checkpoint carries their weights (natten_layout from the config, default 2), unless no_natten asks otherwise."""
+    from flocoder_amd.codecs import VQVAE, setup_codec
+    from flocoder_amd.general import Config, _wrap
+    kw = dict(in_channels=1, hidden_channels=32, num_downsamples=3, internal_dim=32, vq_embedding_dim=4)
+    src = VQVAE(natten_layout=1, decoder_nonlocal=True, **kw)
+    sd = src.state_dict()
+    assert any(k.endswith(".attn.qkv.weight") for k in sd) and sd["encoder.2.attn.qkv.weight"].shape == (96 * 2, 64)
+    path = str(tmp_path / "vq.pt")
+    torch.save({"model_state_dict": sd}, path)
+    cfg = _wrap({"codec": {"choice": "vqgan", "checkpoint": path, "codebook_levels": 3, "vq_num_embeddings": 512, "commitment_weight": 0.5, **kw}})
+    c = setup_codec(cfg, "cpu")
+    assert c.natten_layout == 2 and torch.equal(c.state_dict()["encoder.2.attn.qkv.weight"], sd["encoder.2.attn.qkv.weight"])
+    cfg.codec["natten_layout"] = 1
+    assert setup_codec(cfg, "cpu").natten_layout == 1
+    c0 = setup_codec(cfg, "cpu", no_natten=True)
+    assert c0.natten_layout == 0 and not any(k.endswith(".attn.qkv.weight") for k in c0.state_dict())
+    plain = VQVAE(**kw)
+    torch.save({"model_state_dict": plain.state_dict()}, path)
+    assert setup_codec(cfg, "cpu").natten_layout == 0
