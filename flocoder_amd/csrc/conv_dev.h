@@ -21,6 +21,7 @@ struct ConvDev {
     int txl, tyl;                // log2 of tiles_x / tiles_y (both powers of two)
     unsigned magic_nt;           // ceil(2^32 / ntiles) (0: ntiles == 1, or the grid is too large for the 16-bit fast path: divide)
     int loader_prio;             // s_setprio level of the loader waves (the younger half of the workgroup loses issue arbitration to the MFMA waves otherwise)
+    int o_out;                   // LDS image of the output tile for the wide (16-byte) stores, or -1: per-lane dword stores
     int o_epoch, o_gran;         // fused tail: LDS word holding this launch's epoch (outside the aliased region); gathered partials
     // pipelined kernel only
     const float* zeros16;        // 16 zero bytes in global memory: source of out-of-range LDS-DMA lanes
@@ -188,6 +189,34 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
     // thread i <-> (sample tb, column col) sums its column over the sample's 16-row half-blocks, then the cpgt columns of a
     // group -- consecutive lanes of one wave, cpgt a power of two <= 64 -- meet by xor-shuffles; the group's first lane writes
     // (mean_t, M2_t) of this tile's share of group g of sample b.
+    // (sum, sum of squares) of this tile's share of group (tb, gl) -> its (mean_t, M2_t) partial slot (or granules / the local table)
+    auto publish = [&](float* dst, int G, int cpg, int cpgt, int NPG, bool coherent, float* ltab, int tb, int gl, float s, float q) {
+        const int b = b0 + tb;
+        const float n = (float)(p.rps * cpgt), mean = s / n;
+        const int g = n0 / cpg + (cpg >= BN ? 0 : gl);
+        const int nsub = (cpg >= BN) ? (n0 % cpg) / BN : 0;
+        const int msub = (p.TB > 1) ? 0 : ty * p.tiles_x + tx;
+        const int T = (p.TB > 1 ? 1 : p.tiles_x * p.tiles_y) * NPG;
+        float* d = dst + ((size_t)(b * G + g) * T + msub * NPG + nsub) * 2;
+        if (ltab) {       // the tile holds the whole group: (mean, rstd) for the tail below, no trip through memory
+            const int ngt = cpg >= BN ? 1 : BN / cpg;
+            ltab[2 * (tb * ngt + gl)] = mean;
+            ltab[2 * (tb * ngt + gl) + 1] = 1.0f / sqrtf((q - s * mean) / n + a.fin.eps);
+        }
+        if (coherent) {   // read by the other workgroups of this sample group IN this launch: each value travels as ONE 8-byte
+            // write-through store {epoch, bits} -- the data is its own flag (cdna_hip_programming.md G16, R2)
+            gu64* gp = (gu64*)(a.fin.gran + (size_t)(d - dst));
+            const unsigned long long tag = (unsigned long long)epoch << 32;
+            __hip_atomic_store(gp, tag | __float_as_uint(mean), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(gp + 1, tag | __float_as_uint(q - s * mean), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            d[0] = mean;
+            d[1] = q - s * mean;
+        }
+    };
+    // thread i <-> (sample tb, column col) sums its column over the sample's 16-row half-blocks, then the cpgt columns of a
+    // group -- consecutive lanes of one wave, cpgt a power of two <= 64 -- meet by xor-shuffles; the group's first lane writes
+    // (mean_t, M2_t) of this tile's share of group g of sample b.
     auto emit = [&](float* dst, int G, int cpg, int cpgt, int NPG, bool coherent, float* ltab) {
         const int hb_per = p.rps >> 4;
         const int ncols = min(BN, Cout - n0);
@@ -201,33 +230,57 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                 for (int h = 0; h < hb_per; ++h) { s += partS[(tb * hb_per + h) * BN + col]; q += partQ[(tb * hb_per + h) * BN + col]; }
             }
             for (int o = cpgt >> 1; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-            const int b = b0 + tb;
-            if (live && (col & (cpgt - 1)) == 0 && col < ncols && b < a.B) {
-                const int gl = col / cpgt;
-                const float n = (float)(p.rps * cpgt), mean = s / n;
-                const int g = n0 / cpg + (cpg >= BN ? 0 : gl);
-                const int nsub = (cpg >= BN) ? (n0 % cpg) / BN : 0;
-                const int msub = (p.TB > 1) ? 0 : ty * p.tiles_x + tx;
-                const int T = (p.TB > 1 ? 1 : p.tiles_x * p.tiles_y) * NPG;
-                float* d = dst + ((size_t)(b * G + g) * T + msub * NPG + nsub) * 2;
-                if (ltab) {       // the tile holds the whole group: (mean, rstd) for the tail below, no trip through memory
-                    const int ngt = cpg >= BN ? 1 : BN / cpg;
-                    ltab[2 * (tb * ngt + gl)] = mean;
-                    ltab[2 * (tb * ngt + gl) + 1] = 1.0f / sqrtf((q - s * mean) / n + a.fin.eps);
-                }
-                if (coherent) {   // read by the other workgroups of this sample group IN this launch: each value travels as ONE 8-byte
-                    // write-through store {epoch, bits} -- the data is its own flag (cdna_hip_programming.md G16, R2)
-                    gu64* gp = (gu64*)(a.fin.gran + (size_t)(d - dst));
-                    const unsigned long long tag = (unsigned long long)epoch << 32;
-                    __hip_atomic_store(gp, tag | __float_as_uint(mean), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(gp + 1, tag | __float_as_uint(q - s * mean), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-                    d[0] = mean;
-                    d[1] = q - s * mean;
+            if (live && (col & (cpgt - 1)) == 0 && col < ncols && b0 + tb < a.B) publish(dst, G, cpg, cpgt, NPG, coherent, ltab, tb, col / cpgt, s, q);
+        }
+    };
+    // The same partials when the tile lies inside ONE sample (TB == 1, every layer with >= BM pixels per image): each accumulator wave
+    // folds its own rows and its group's columns in registers (shuffles only), one LDS word pair per (wave row, group) crosses to the
+    // publishing thread.  The general form above goes through [BM/16][BN] LDS tables and sums them again per thread: 5 k cycles of the
+    // 10 k-cycle epilogue of a 32x32 layer, this is 2 k.
+    auto stats_fast = [&](float* dst, int G, int cpg, int cpgt, int NPG, bool coherent, float* ltab) {
+        const int lanes = cpgt < 32 ? cpgt : 32;          // columns of a group inside one 32-column accumulator block
+        const int per = cpgt <= 32 ? 1 : cpgt / 32;       // accumulator blocks a group spans (cpgt == 64 with NT == 2)
+        if (owner) {
+            float sv[NT], qv[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { const float v = acc[mt][nt][r]; s_ += v; q_ += v * v; }
+                s_ += __shfl_xor(s_, 32);
+                q_ += __shfl_xor(q_, 32);
+                for (int o = lanes >> 1; o > 0; o >>= 1) { s_ += __shfl_xor(s_, o); q_ += __shfl_xor(q_, o); }
+                sv[nt] = s_; qv[nt] = q_;
+            }
+            if (half == 0 && (l31 & (lanes - 1)) == 0) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (per > 1 && (nt % per)) continue;
+                    float s_ = sv[nt], q_ = qv[nt];
+                    if (per > 1) {
+#pragma unroll
+                        for (int k = 1; k < NT; ++k) if (k < per && nt + k < NT) { s_ += sv[nt + k]; q_ += qv[nt + k]; }
+                    }
+                    const int col = (wn * NT + nt) * 32 + l31;
+                    partS[wm * BN + col] = s_;
+                    partQ[wm * BN + col] = q_;
                 }
             }
         }
+        __syncthreads();
+        const int ncols = min(BN, Cout - n0);
+        for (int i = tid; i < BN / cpgt; i += nthr) {
+            const int col = i * cpgt;
+            if (col >= ncols || b0 >= a.B) continue;
+            float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < WM; ++w2) { s_ += partS[w2 * BN + col]; q_ += partQ[w2 * BN + col]; }
+            publish(dst, G, cpg, cpgt, NPG, coherent, ltab, 0, i, s_, q_);
+        }
     };
+    const bool fast_stats = p.TB == 1;
 
     // Statistics first, stores last: a workgroup barrier waits for every outstanding global store (s_waitcnt vmcnt(0)), so a
     // barrier AFTER the output stores would park the whole workgroup for the store round trip.
@@ -259,12 +312,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                 }
             }
     }
-    if (a.stats_out) block_sums();
+    if (a.stats_out && !fast_stats) block_sums();
 
     conv_stamp(p, 7);
     if (a.stats_out) {
-        __syncthreads();
-        emit(a.stats_out, a.Gout, p.cpg, p.cpgt, p.NPG, fin && !p.fin_local, (fin && p.fin_local) ? smem + p.o_fin : nullptr);
+        if (fast_stats) stats_fast(a.stats_out, a.Gout, p.cpg, p.cpgt, p.NPG, fin && !p.fin_local, (fin && p.fin_local) ? smem + p.o_fin : nullptr);
+        else {
+            __syncthreads();
+            emit(a.stats_out, a.Gout, p.cpg, p.cpgt, p.NPG, fin && !p.fin_local, (fin && p.fin_local) ? smem + p.o_fin : nullptr);
+        }
     }
     conv_stamp(p, 14);
 
@@ -350,20 +406,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
         }
         if (a.fin.gn1_out) {   // GroupNorm(1) partials of the final value for the PreNorm that follows (unet.py:156-160)
             lds_only_barrier();                    // every reader of part* / tab is done
-            block_sums();
-            lds_only_barrier();
             const int cpg1 = Cout, cpgt1 = Cout < BN ? Cout : BN, NPG1 = Cout >= BN ? Cout / BN : 1;
-            emit(a.fin.gn1_out, 1, cpg1, cpgt1, NPG1, false, nullptr);
+            if (fast_stats) stats_fast(a.fin.gn1_out, 1, cpg1, cpgt1, NPG1, false, nullptr);
+            else {
+                block_sums();
+                lds_only_barrier();
+                emit(a.fin.gn1_out, 1, cpg1, cpgt1, NPG1, false, nullptr);
+            }
         }
     }
 
     // Output stores.  Written flat: the pixel index of every accumulator row first (one 32-bit value per row; -1 = sample beyond B),
     // then the optional activation / residual with all its loads in flight together, then the stores back to back.  The earlier
     // per-row form (decode, three uniform branches, load, wait, store -- sixteen times) took 4.8 k cycles of a 32x32 layer's 42 k.
+    //
+    // Wide form (p.o_out >= 0): an accumulator lane holds ONE channel of sixteen pixels, so its natural stores are sixteen dword
+    // instructions of two 128-byte segments each -- store-ISSUE bound (3.9 k cycles of a 32x32 layer).  Through an LDS image
+    // [row][BN + 4] every thread of the workgroup (the staging waves too) then writes whole 16-byte channel quads: a quarter of the
+    // store instructions, each 1 KiB contiguous when Cout == BN.
+    const bool post = !a.stats_post && !fin;                // activation / residual still to apply (else already in the accumulators)
+    const bool act = post && a.out_act;
+    const float* addp = post ? a.add : nullptr;
     if (owner) {
-        const bool post = !a.stats_post && !fin;            // activation / residual still to apply (else already in the accumulators)
-        const bool act = post && a.out_act;
-        const float* addp = post ? a.add : nullptr;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             int pix[16];
@@ -384,15 +448,49 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mt][nt][r] = silu_f(acc[mt][nt][r]);
                 }
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (pix[r] >= 0) op[(size_t)pix[r] * Cout] = acc[mt][nt][r];
-                if (has_res) {
-                    const float rbias = pre ? pre[NT + nt] : (a.res_b ? a.res_b[n] : 0.f);
-                    float* rp = a.res_out + n;
+                if (p.o_out < 0) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        if (pix[r] >= 0) rp[(size_t)pix[r] * Cout] = accr[mt][nt][r] + rbias;
+                        if (pix[r] >= 0) op[(size_t)pix[r] * Cout] = acc[mt][nt][r];
+                    if (has_res) {
+                        const float rbias = pre ? pre[NT + nt] : (a.res_b ? a.res_b[n] : 0.f);
+                        float* rp = a.res_out + n;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (pix[r] >= 0) rp[(size_t)pix[r] * Cout] = accr[mt][nt][r] + rbias;
+                    }
+                }
+            }
+        }
+    }
+    if (p.o_out >= 0) {
+        constexpr int OS = BN + 4, Q4 = BN / 4;
+        float* ot = smem + p.o_out;
+        for (int pass = 0; pass < (has_res ? 2 : 1); ++pass) {
+            if (pass) lds_only_barrier();                   // the image of the first output has been read by everyone
+            if (owner) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int ncol = (wn * NT + nt) * 32 + l31;
+                        const float rbias = pass ? (pre ? pre[NT + nt] : ((a.res_b && n0 + ncol < Cout) ? a.res_b[n0 + ncol] : 0.f)) : 0.f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            ot[m * OS + ncol] = pass ? accr[mt][nt][r] + rbias : acc[mt][nt][r];
+                        }
+                    }
+            }
+            lds_only_barrier();
+            float* gout = pass ? a.res_out : a.out;
+            for (int i = tid; i < BM * Q4; i += nthr) {
+                const int m = i / Q4, c4 = (i - m * Q4) * 4, n = n0 + c4;
+                const int tw = m & (TW - 1), th = (m >> p.TWl) & (TH - 1), tb = m >> (p.TWl + p.THl);
+                const int b = b0 + tb;
+                if (b < a.B && n < Cout) {
+                    const float4 v = *reinterpret_cast<const float4*>(ot + m * OS + c4);
+                    *reinterpret_cast<float4*>(gout + (size_t)((b * a.H + y0 + th) * a.W + x0 + tw) * Cout + n) = v;
                 }
             }
         }

@@ -289,7 +289,7 @@ static int conv_geometry(const ConvArgs& a, int tile, bool pipe, ConvDev* d, Con
     p.nblocks = cdiv(a.B, TB) * p.tiles_x * p.tiles_y * p.ntiles;
     p.txl = ilog2(p.tiles_x); p.tyl = ilog2(p.tiles_y);
     p.magic_nt = (p.ntiles > 1 && p.nblocks < 65536) ? (unsigned)((1ull << 32) / (unsigned)p.ntiles) + 1u : 0u;   // exact for x < 2^16
-    p.loader_prio = 0; p.o_epoch = p.o_gran = 0;
+    p.loader_prio = 0; p.o_epoch = p.o_gran = 0; p.o_out = -1;
     p.act0 = a.s0.xf.mode == 2; p.act1 = a.s1.xf.mode == 2;
     p.any_xf = (a.s0.xf.mode != 0) || (a.s1.xf.mode != 0);
     p.rps = TB > 1 ? a.H * a.W : t.BM;
@@ -335,6 +335,9 @@ static int conv_geometry(const ConvArgs& a, int tile, bool pipe, ConvDev* d, Con
         if (a.fin.gamma) epi += 2 * TB * t.BN;
         p.o_gran = o + epi;
         if (a.fin.gamma) epi += align4(TB * (p.cpg >= t.BN ? 1 : t.BN / p.cpg) * g->T * 2);   // partials of every workgroup of the sample group, gathered
+        static const bool wide = [] { const char* e = std::getenv("FLOCODER_AMD_WIDE_STORE"); return !(e && std::string(e) == "0"); }();
+        p.o_out = -1;
+        if (wide && (size_t)(o + epi + t.BM * (t.BN + 4)) * sizeof(float) <= 160 * 1024) { p.o_out = o + epi; epi += t.BM * (t.BN + 4); }
         o += main_sz > epi ? main_sz : epi;
         p.zeros16 = conv_zeros16();
         p.stamps = conv_stamp_buffer();
