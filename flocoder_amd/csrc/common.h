@@ -285,6 +285,12 @@ struct WgradArgs {          // dW[co][ci][ky][kx] (+ db[co]) of a convolution fr
 int conv_wgrad_init();
 size_t conv_wgrad_workspace(const WgradArgs& a);
 int conv_wgrad_launch(const WgradArgs& a, hipStream_t s);
+// The split partials of MANY weight-gradient launches summed by ONE table-driven launch at the end of the backward (each launch then
+// needs a workspace of its own): 53 five-microsecond reduce launches per training step become one.
+struct WredJob { const float* ws; int nsplit; int nb; size_t stride, nw; int64_t dw, db; };   // dw / db: offsets into the flat gradient vector (db < 0: none)
+int conv_wgrad_split(const WgradArgs& a, int* nsplit, size_t* part_stride);                   // geometry of the launch conv_wgrad_launch would make
+int conv_wgrad_launch_noreduce(const WgradArgs& a, hipStream_t s);                           // partials into a.ws (nsplit > 1), nothing else
+int wgrad_reduce_table_launch(const WredJob* jobs_dev, const int2* blocks_dev, int nblocks, float* grads, hipStream_t s);
 
 struct GnBwdArgs {          // backward of y = act((gamma xhat + beta)(sc+1) + sh); xf describes the forward (mode 1: no act, 2: SiLU)
     const float* dy = nullptr;  // NHWC [B][HW][C]

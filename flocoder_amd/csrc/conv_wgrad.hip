@@ -74,8 +74,12 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradDev p) {
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
         __syncthreads();
-        if (a.db && cic == 0 && tid < 32)
-            for (int m = 0; m < BM; ++m) bsum += ys[m * CS + tid];
+        // bias gradient: every thread folds its share of the tile's rows (row group = tid / 32), the eight groups meet once after the
+        // tile loop -- as one 32-lane serial sweep over the BM rows this was 128 dependent LDS reads per tile on the critical path
+        if (a.db && cic == 0) {
+            const int rg = tid >> 5;
+            for (int m = rg; m < BM; m += 8) bsum += ys[m * CS + l31];
+        }
         if (KS == 1) {
             const int per = BM / 8;                      // k-steps (pixel pairs) per wave
             for (int j = wave * per; j < (wave + 1) * per; ++j) {
@@ -83,19 +87,41 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradDev p) {
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[pixbase[pk] + l31], ys[pk * CS + l31], acc[0], 0, 0, 0);
             }
         } else {
-            for (int j = 0; j < BM / 2; ++j) {
-                const int pk = 2 * j + half, pb = pixbase[pk];
-                const float bv = ys[pk * CS + l31];
+            // four k-steps per trip with every LDS operand requested before the first MFMA: rolled one step at a time the loop was a
+            // chain of dependent LDS reads (pixbase -> patch address -> operand) in front of each group of MFMAs
+            int tapoff[TPW];
 #pragma unroll
-                for (int t = 0; t < TPW; ++t) {
-                    const int tap = wave + 4 * t;
-                    if (tap < KK) {
-                        const int ky = tap / KS, kx = tap % KS;
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[pb + (ky * p.PW + kx) * CS + l31], bv, acc[t], 0, 0, 0);
-                    }
+            for (int t = 0; t < TPW; ++t) {
+                const int tap = wave + 4 * t;
+                tapoff[t] = tap < KK ? ((tap / KS) * p.PW + (tap % KS)) * CS + l31 : -1;
+            }
+            for (int j0 = 0; j0 < BM / 2; j0 += 4) {
+                int pb[4];
+                float bv[4], av[4][TPW];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int pk = 2 * (j0 + u) + half;
+                    pb[u] = pixbase[pk];
+                    bv[u] = ys[pk * CS + l31];
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) av[u][t] = tapoff[t] >= 0 ? xs[pb[u] + tapoff[t]] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t)
+                        if (tapoff[t] >= 0) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][t], bv[u], acc[t], 0, 0, 0);
             }
         }
+    }
+    if (a.db && cic == 0) {   // the eight row groups of the bias gradient: wave halves by shuffle, waves through LDS
+        bsum += __shfl_xor(bsum, 32);
+        __syncthreads();
+        if (half == 0) xs[wave * 32 + l31] = bsum;
+        __syncthreads();
+        if (tid < 32) bsum = (xs[tid] + xs[32 + tid]) + (xs[64 + tid] + xs[96 + tid]);
     }
     if (KS == 1) {    // the four waves hold partial sums over different pixels of the same block
         __syncthreads();
@@ -152,6 +178,31 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* ws, int 
     }
 }
 
+// block (job, chunk): 64 consecutive elements of one job's [dw | db] vector, 4 split lanes each (same fixed order as wgrad_reduce_kernel)
+__global__ void __launch_bounds__(256) wgrad_reduce_table_kernel(const WredJob* jobs, const int2* blocks, float* grads) {
+    __shared__ float part[4][64];
+    const int2 bj = blocks[blockIdx.x];
+    const WredJob j = jobs[bj.x];
+    const size_t total = j.nw + (j.db >= 0 ? (size_t)j.nb : 0), e = (size_t)bj.y * 64 + (threadIdx.x & 63);
+    const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (e < total)
+        for (int s = sl; s < j.nsplit; s += 4) acc += j.ws[(size_t)s * j.stride + e];
+    part[sl][el] = acc;
+    __syncthreads();
+    if (sl == 0 && e < total) {
+        const float v = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
+        if (e < j.nw) grads[j.dw + e] = v;
+        else grads[j.db + (e - j.nw)] = v;
+    }
+}
+int wgrad_reduce_table_launch(const WredJob* jobs_dev, const int2* blocks_dev, int nblocks, float* grads, hipStream_t s) {
+    if (!nblocks) return FC_OK;
+    hipLaunchKernelGGL(wgrad_reduce_table_kernel, dim3(nblocks), dim3(256), 0, s, jobs_dev, blocks_dev, grads);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
 static int wgrad_geometry(const WgradArgs& a, WgradDev* d) {
     if (!is_pow2(a.H) || !is_pow2(a.W)) return fail(FC_E_SHAPE, "wgrad: H and W must be powers of two");
     if ((a.C0 & 3) || (a.C1 & 3) || (a.Cout & 3) || a.C0 + a.C1 != a.Cin) return fail(FC_E_SHAPE, "wgrad: channel counts must be multiples of 4");
@@ -196,7 +247,20 @@ size_t conv_wgrad_workspace(const WgradArgs& a) {   // floats wanted for the pre
     return d.nsplit > 1 ? (size_t)d.nsplit * d.part_stride : 0;
 }
 
-int conv_wgrad_launch(const WgradArgs& a, hipStream_t s) {
+int conv_wgrad_split(const WgradArgs& a, int* nsplit, size_t* part_stride) {
+    WgradArgs b = a;
+    b.ws_floats = 0;                         // the preferred split, not one squeezed into a shared workspace
+    WgradDev d;
+    FC_TRY(wgrad_geometry(b, &d));
+    *nsplit = d.nsplit; *part_stride = d.part_stride;
+    return FC_OK;
+}
+
+static int wgrad_launch_impl(const WgradArgs& a, bool reduce, hipStream_t s);
+int conv_wgrad_launch(const WgradArgs& a, hipStream_t s) { return wgrad_launch_impl(a, true, s); }
+int conv_wgrad_launch_noreduce(const WgradArgs& a, hipStream_t s) { return wgrad_launch_impl(a, false, s); }
+
+static int wgrad_launch_impl(const WgradArgs& a, bool reduce, hipStream_t s) {
     WgradDev d;
     FC_TRY(wgrad_geometry(a, &d));
     if (d.nsplit > 1 && !a.ws) return fail(FC_E_ARG, "wgrad: workspace missing");
@@ -209,7 +273,7 @@ int conv_wgrad_launch(const WgradArgs& a, hipStream_t s) {
         default: hipLaunchKernelGGL(conv_wgrad_kernel<5>, grid, dim3(256), lds, s, d); break;
     }
     FC_HIP(hipGetLastError());
-    if (d.nsplit > 1) {
+    if (d.nsplit > 1 && reduce) {
         const size_t nw = (size_t)a.Cout * a.Cin * a.KS * a.KS;
         const size_t total = nw + (a.db ? a.Cout : 0);
         const int g = (int)((total + 63) / 64 < 4096 ? (total + 63) / 64 : 4096);

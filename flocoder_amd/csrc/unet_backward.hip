@@ -13,6 +13,7 @@
 // kernel on flipped, transposed weights (re-packed whenever the parameters change); a tensor with several consumers gets its
 // gradient contributions through the kernels' accumulate paths in a fixed order.  Parameter gradients land in the caller's flat
 // vector in the parameter table's layout, each written exactly once.
+#include <cstdlib>
 #include <memory>
 
 #include "plan.h"
@@ -48,6 +49,7 @@ struct BwdBuilder : PlanBuilder {
         return s.g;
     }
 
+    std::vector<WredJob> wred_jobs;         // deferred split reductions of the weight gradients: one table-driven launch at the end
     void wgrad(const std::string& wname, const std::string& bname, const Act& x, const Act* skip, const Act& dy, int KS, int pad, int stride, int ups) {
         if (err) return;
         WgradArgs a;
@@ -57,9 +59,21 @@ struct BwdBuilder : PlanBuilder {
         a.KS = KS; a.pad = pad; a.stride = stride; a.ups = ups; a.B = B;
         a.ws = ws; a.ws_floats = ws_floats;
         const int64_t wo = off(wname), bo = bname.empty() ? -1 : off(bname);
-        push([a, wo, bo](const FwdCtx& c, hipStream_t s) {
+        // at the plan's full batch the launch keeps its partials in a workspace of its own and leaves the summation to the table launch
+        int ns = 1; size_t stride_f = 0;
+        static const bool no_defer = std::getenv("FLOCODER_AMD_WGRAD_REDUCE_EACH") != nullptr;
+        float* own = nullptr;
+        if (!no_defer && guard == 0 && conv_wgrad_split(a, &ns, &stride_f) == FC_OK && ns > 1) {   // guarded (mask-branch) launches may not run: they reduce on the spot
+            own = dmalloc((size_t)ns * stride_f);
+            if (err) return;
+            wred_jobs.push_back({own, ns, a.Cout, stride_f, (size_t)a.Cout * a.Cin * KS * KS, wo, bo});
+        }
+        const int maxB = B;
+        const size_t own_floats = (size_t)ns * stride_f;
+        push([a, wo, bo, own, own_floats, maxB](const FwdCtx& c, hipStream_t s) {
             WgradArgs b = a;
             b.B = c.B; b.dw = c.grads + wo; b.db = bo >= 0 ? c.grads + bo : nullptr;
+            if (own && c.B == maxB) { b.ws = own; b.ws_floats = own_floats; return conv_wgrad_launch_noreduce(b, s); }
             return conv_wgrad_launch(b, s);
         }, "conv_wgrad", 2.0 * dy.H * dy.W * KS * KS * (double)a.Cin * a.Cout);
     }
@@ -420,6 +434,23 @@ int build_backward(fc_unet* u) {
         }
     }
     if (b.err) return b.err;
+    // -- the split partials of every weight gradient above, summed in one launch (full-batch steps; smaller batches reduced per launch) --
+    if (!b.wred_jobs.empty()) {
+        b.scope = "wgrad";
+        std::vector<int2> blocks;
+        for (size_t j = 0; j < b.wred_jobs.size(); ++j) {
+            const WredJob& w = b.wred_jobs[j];
+            const size_t total = w.nw + (w.db >= 0 ? (size_t)w.nb : 0);
+            for (size_t k = 0; k < (total + 63) / 64; ++k) blocks.push_back(make_int2((int)j, (int)k));
+        }
+        WredJob* jd = reinterpret_cast<WredJob*>(b.dmalloc((b.wred_jobs.size() * sizeof(WredJob) + 3) / 4 + 4));
+        int2* bd = reinterpret_cast<int2*>(b.dmalloc(blocks.size() * 2 + 4));
+        if (b.err) return b.err;
+        FC_HIP(hipMemcpy(jd, b.wred_jobs.data(), b.wred_jobs.size() * sizeof(WredJob), hipMemcpyHostToDevice));
+        FC_HIP(hipMemcpy(bd, blocks.data(), blocks.size() * sizeof(int2), hipMemcpyHostToDevice));
+        const int nblk = (int)blocks.size();
+        b.push([=](const FwdCtx& cx, hipStream_t s) { return cx.B == B ? wgrad_reduce_table_launch(jd, bd, nblk, cx.grads, s) : (int)FC_OK; }, "wgrad_reduce");
+    }
     // -- parameter gradients of every norm layer and the FiLM gradients, one launch --
     {
         b.scope = "norms";

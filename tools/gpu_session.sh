@@ -25,6 +25,8 @@ for s in $STEPS; do
                python tools/pmc_summary.py $(find $OUT/pmc_fetch -name '*counter_collection.csv') $(find $OUT/pmc_write -name '*counter_collection.csv') 3 > $OUT/pmc_traffic.json; head -5 $OUT/pmc_traffic.json ;;
     mfma)      (cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_mfma -- python3 $GRAFT_REPO_ROOT/tools/pmc_forward.py 3 > $GRAFT_REPO_ROOT/$OUT/pmc_mfma.log 2>&1) || { tail -20 $OUT/pmc_mfma.log; exit 1; }
                python tools/pmc_mfma_summary.py $(find $OUT/pmc_mfma -name '*counter_collection.csv') > $OUT/pmc_mfma.json; head -30 $OUT/pmc_mfma.json ;;
+    trainprof) (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/trainprof -- python3 $GRAFT_REPO_ROOT/tools/bench_train.py --steps 25 --warmup 5 > $GRAFT_REPO_ROOT/$OUT/trainprof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/trainprof.err) || { tail -20 $OUT/trainprof.err; exit 1; }
+               find $OUT/trainprof -name '*kernel_stats.csv' -exec cp {} $OUT/train_kernel_stats.csv \; ; head -30 $OUT/train_kernel_stats.csv | cut -c1-150 ;;
     train)     timeout -k 10 300 python tools/bench_train.py > $OUT/train_bench.json 2> $OUT/train.err || { tail -20 $OUT/train.err; exit 1; }; cat $OUT/train_bench.json ;;
     *)         echo "unknown step $s"; exit 2 ;;
   esac
