@@ -10,7 +10,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libflocoder_amd.so")
+# FLOCODER_AMD_LIB: another build of the same ABI (A/B timing of two builds inside one box session: tools/ab.sh)
+LIB_PATH = os.environ.get("FLOCODER_AMD_LIB") or os.path.join(_HERE, "_lib", "libflocoder_amd.so")
 
 FC_OK, FC_E_ARG, FC_E_SHAPE, FC_E_ARCH, FC_E_HIP, FC_E_STATE = 0, -1, -2, -3, -4, -5
 FC_METHOD_EULER, FC_METHOD_RK4 = 0, 1

@@ -38,6 +38,11 @@ def main():
         busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
         out[fam] = {"launches": len(launches[fam]), "gpu_active_cycles": round(gui), "mfma_busy_cycles_all_simds": round(busy),
                     "mfma_util": round(busy / (gui * N_SIMD), 4) if gui else None,
+                    # counter collection serialises and slows the dispatches (GRBM_GUI_ACTIVE per launch reads about twice the un-profiled
+                    # duration), so the busy cycles are also given per SIMD per launch: divide by (un-profiled duration x clock) for the
+                    # utilisation inside a normal launch; at the 2.4 GHz peak clock they are the microseconds of pure matrix work per launch
+                    "mfma_busy_cycles_per_simd_per_launch": round(busy / N_SIMD / max(len(launches[fam]), 1)),
+                    "mfma_us_per_launch_at_2p4_ghz": round(busy / N_SIMD / max(len(launches[fam]), 1) / 2400.0, 2),
                     "mfma_gflop": round(c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) * 512 / 1e9, 3),
                     "sq_busy_cycles": round(c.get("SQ_BUSY_CYCLES", 0.0)), "sq_wave_cycles": round(c.get("SQ_WAVE_CYCLES", 0.0))}
         for k in ("GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32"):
