@@ -282,6 +282,14 @@ struct WgradArgs {          // dW[co][ci][ky][kx] (+ db[co]) of a convolution fr
     float* ws = nullptr; size_t ws_floats = 0; // split-reduction workspace
     int B = 0, H = 0, W = 0, Hs = 0, Ws = 0, Cin = 0, Cout = 0, KS = 1, pad = 0, stride = 1, ups = 0;
 };
+struct WgradDev {            // a launch's geometry as the device sees it (conv_wgrad.hip)
+    WgradArgs a;
+    int BM, TWl, THl, TB, PH, PW, P;
+    int tiles_x, tiles_y, mtiles, nsplit, nci, nco;
+    int o_ys, o_pix;          // LDS offsets (floats)
+    size_t part_stride;       // floats per split in the workspace
+    int64_t dw_off = 0, db_off = -1;   // table-driven launches: where dw / db live in the caller's flat gradient vector
+};
 int conv_wgrad_init();
 size_t conv_wgrad_workspace(const WgradArgs& a);
 int conv_wgrad_launch(const WgradArgs& a, hipStream_t s);
@@ -290,6 +298,9 @@ int conv_wgrad_launch(const WgradArgs& a, hipStream_t s);
 struct WredJob { const float* ws; int nsplit; int nb; size_t stride, nw; int64_t dw, db; };   // dw / db: offsets into the flat gradient vector (db < 0: none)
 int conv_wgrad_split(const WgradArgs& a, int* nsplit, size_t* part_stride);                   // geometry of the launch conv_wgrad_launch would make
 int conv_wgrad_launch_noreduce(const WgradArgs& a, hipStream_t s);                           // partials into a.ws (nsplit > 1), nothing else
+// Every weight gradient of one kernel size in one launch (full-batch training steps): the entries' inputs must all still be alive
+int conv_wgrad_table_entry(const WgradArgs& a, int64_t dw_off, int64_t db_off, WgradDev* out, int* nblocks, size_t* lds_bytes);
+int conv_wgrad_table_launch(int KS, const WgradDev* jobs_dev, const int2* blocks_dev, int nblocks, size_t lds_bytes, float* grads, hipStream_t s);
 int wgrad_reduce_table_launch(const WredJob* jobs_dev, const int2* blocks_dev, int nblocks, float* grads, hipStream_t s);
 
 struct GnBwdArgs {          // backward of y = act((gamma xhat + beta)(sc+1) + sh); xf describes the forward (mode 1: no act, 2: SiLU)

@@ -12,18 +12,12 @@ namespace fc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-struct WgradDev {
-    WgradArgs a;
-    int BM, TWl, THl, TB, PH, PW, P;
-    int tiles_x, tiles_y, mtiles, nsplit, nci, nco;
-    int o_ys, o_pix;          // LDS offsets (floats)
-    size_t part_stride;       // floats per split in the workspace
-};
-
 constexpr int CS = 33;
 
+// (split, cicoc): which share of the pixel tiles and which 32 x 32 block of every tap this workgroup owns; dw / db: where the
+// un-split result goes (the launch's own pointers, or offsets into the caller's flat gradient vector for a table-driven launch)
 template <int KS>
-__global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradDev p) {
+__device__ __forceinline__ void wgrad_body(const WgradDev& p, const int split, const int cicoc, float* dw, float* db) {
     constexpr int KK = KS * KS, TPW = KS == 1 ? 1 : (KK + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;
@@ -31,7 +25,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradDev p) {
     int* pixbase = reinterpret_cast<int*>(smem + p.o_pix);
     const WgradArgs& a = p.a;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int split = blockIdx.x, cic = blockIdx.y % p.nci, coc = blockIdx.y / p.nci;
+    const int cic = cicoc % p.nci, coc = cicoc / p.nci;
     const int ci0 = cic * 32, co0 = coc * 32;
     const int TW = 1 << p.TWl, TH = 1 << p.THl, BM = p.BM;
     const int Hin = a.ups ? 2 * a.Hs : a.Hs, Win = a.ups ? 2 * a.Ws : a.Ws;
@@ -76,7 +70,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradDev p) {
         __syncthreads();
         // bias gradient: every thread folds its share of the tile's rows (row group = tid / 32), the eight groups meet once after the
         // tile loop -- as one 32-lane serial sweep over the BM rows this was 128 dependent LDS reads per tile on the critical path
-        if (a.db && cic == 0) {
+        if (db && cic == 0) {
             const int rg = tid >> 5;
             for (int m = rg; m < BM; m += 8) bsum += ys[m * CS + l31];
         }
@@ -116,7 +110,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradDev p) {
             }
         }
     }
-    if (a.db && cic == 0) {   // the eight row groups of the bias gradient: wave halves by shuffle, waves through LDS
+    if (db && cic == 0) {   // the eight row groups of the bias gradient: wave halves by shuffle, waves through LDS
         bsum += __shfl_xor(bsum, 32);
         __syncthreads();
         if (half == 0) xs[wave * 32 + l31] = bsum;
@@ -136,7 +130,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradDev p) {
                 for (int r = 0; r < 16; ++r) acc[0][r] += xs[(w * 16 + r) * 64 + lane];
         }
     }
-    float* dst = p.nsplit > 1 ? a.ws + (size_t)split * p.part_stride : a.dw;
+    float* dst = p.nsplit > 1 ? a.ws + (size_t)split * p.part_stride : dw;
     const int co = co0 + l31;
     if (co < a.Cout) {
 #pragma unroll
@@ -151,10 +145,25 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradDev p) {
             }
         }
     }
-    if (a.db && cic == 0 && tid < 32 && co0 + tid < a.Cout) {
-        float* bd = p.nsplit > 1 ? a.ws + (size_t)split * p.part_stride + (size_t)a.Cout * a.Cin * KK : a.db;
+    if (db && cic == 0 && tid < 32 && co0 + tid < a.Cout) {
+        float* bd = p.nsplit > 1 ? a.ws + (size_t)split * p.part_stride + (size_t)a.Cout * a.Cin * KK : db;
         bd[co0 + tid] = bsum;
     }
+}
+
+template <int KS>
+__global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradDev p) {
+    wgrad_body<KS>(p, blockIdx.x, blockIdx.y, p.a.dw, p.a.db);
+}
+
+// Every weight gradient of one kernel size in ONE launch: block -> (job, split + nsplit * cicoc) through a table.  At the training
+// shapes a single layer's launch is a few dozen workgroups and ~10-20 us of latency (staging -> MFMA -> store); 70 of them in a row
+// were a quarter of the step, side by side they fill the chip once.
+template <int KS>
+__global__ void __launch_bounds__(256) conv_wgrad_table_kernel(const WgradDev* __restrict__ jobs, const int2* __restrict__ blocks, float* grads) {
+    const int2 bj = blocks[blockIdx.x];
+    const WgradDev p = jobs[bj.x];
+    wgrad_body<KS>(p, bj.y % p.nsplit, bj.y / p.nsplit, grads + p.dw_off, p.db_off >= 0 ? grads + p.db_off : nullptr);
 }
 
 // 256 threads = 64 elements x 4 split lanes (fixed assignment and fixed combine order: bit-reproducible)
@@ -283,7 +292,37 @@ static int wgrad_launch_impl(const WgradArgs& a, bool reduce, hipStream_t s) {
     return FC_OK;
 }
 
+int conv_wgrad_table_entry(const WgradArgs& a, int64_t dw_off, int64_t db_off, WgradDev* out, int* nblocks, size_t* lds_bytes) {
+    WgradArgs b = a;
+    b.dw = nullptr; b.db = nullptr;
+    if (b.ws) b.ws_floats = 0;                // the entry's workspace was sized for its preferred split
+    FC_TRY(wgrad_geometry(b, out));
+    if (out->nsplit > 1 && !a.ws) return fail(FC_E_ARG, "wgrad table: a split entry needs a workspace of its own");
+    out->dw_off = dw_off; out->db_off = db_off;
+    *nblocks = out->nsplit * out->nci * out->nco;
+    *lds_bytes = (size_t)(out->o_pix + 128) * sizeof(float);
+    return FC_OK;
+}
+
+int conv_wgrad_table_launch(int KS, const WgradDev* jobs_dev, const int2* blocks_dev, int nblocks, size_t lds_bytes, float* grads, hipStream_t s) {
+    if (!nblocks) return FC_OK;
+    const dim3 grid(nblocks);
+    switch (KS) {
+        case 1: hipLaunchKernelGGL(conv_wgrad_table_kernel<1>, grid, dim3(256), lds_bytes, s, jobs_dev, blocks_dev, grads); break;
+        case 2: hipLaunchKernelGGL(conv_wgrad_table_kernel<2>, grid, dim3(256), lds_bytes, s, jobs_dev, blocks_dev, grads); break;
+        case 3: hipLaunchKernelGGL(conv_wgrad_table_kernel<3>, grid, dim3(256), lds_bytes, s, jobs_dev, blocks_dev, grads); break;
+        case 5: hipLaunchKernelGGL(conv_wgrad_table_kernel<5>, grid, dim3(256), lds_bytes, s, jobs_dev, blocks_dev, grads); break;
+        default: return fail(FC_E_SHAPE, "wgrad table: kernel size not instantiated");
+    }
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
 int conv_wgrad_init() {
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_table_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_table_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_table_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_table_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     // > 64 KB of dynamic LDS needs the attribute on gfx950 too
     FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -15,6 +15,7 @@
 // vector in the parameter table's layout, each written exactly once.
 #include <cstdlib>
 #include <memory>
+#include <set>
 
 #include "plan.h"
 #include "unet_priv.h"
@@ -50,6 +51,14 @@ struct BwdBuilder : PlanBuilder {
     }
 
     std::vector<WredJob> wred_jobs;         // deferred split reductions of the weight gradients: one table-driven launch at the end
+    // Weight gradients themselves are deferred too (full-batch steps): every layer's launch is recorded as a table entry and all
+    // entries of one kernel size run as ONE launch after the data-gradient chain.  Their operands (the layer input, possibly a
+    // recomputed activation, and the output gradient) therefore stay alive to the end: release() leaves pinned buffers alone.
+    bool batch_wgrad = std::getenv("FLOCODER_AMD_WGRAD_EACH") == nullptr && std::getenv("FLOCODER_AMD_WGRAD_REDUCE_EACH") == nullptr;
+    std::set<const float*> pinned;
+    struct WgradClass { std::vector<WgradDev> jobs; std::vector<int2> blocks; size_t lds = 0; };
+    std::map<int, WgradClass> wclasses;     // by kernel size
+    void release(const Act& a) { if (!pinned.count(a.p)) PlanBuilder::release(a); }
     void wgrad(const std::string& wname, const std::string& bname, const Act& x, const Act* skip, const Act& dy, int KS, int pad, int stride, int ups) {
         if (err) return;
         WgradArgs a;
@@ -70,7 +79,25 @@ struct BwdBuilder : PlanBuilder {
         }
         const int maxB = B;
         const size_t own_floats = (size_t)ns * stride_f;
-        push([a, wo, bo, own, own_floats, maxB](const FwdCtx& c, hipStream_t s) {
+        bool deferred = false;
+        if (batch_wgrad && !no_defer && guard == 0) {
+            WgradArgs e = a;
+            e.ws = own; e.ws_floats = 0;
+            WgradDev d;
+            int nb = 0; size_t lds = 0;
+            if (conv_wgrad_table_entry(e, wo, bo, &d, &nb, &lds) == FC_OK && d.nsplit == ns) {
+                WgradClass& wc = wclasses[KS];
+                const int j = (int)wc.jobs.size();
+                wc.jobs.push_back(d);
+                for (int k = 0; k < nb; ++k) wc.blocks.push_back(make_int2(j, k));
+                if (lds > wc.lds) wc.lds = lds;
+                pinned.insert(x.p); pinned.insert(dy.p);
+                if (skip && skip->p) pinned.insert(skip->p);
+                deferred = true;
+            }
+        }
+        push([a, wo, bo, own, own_floats, maxB, deferred](const FwdCtx& c, hipStream_t s) -> int {
+            if (deferred && c.B == maxB) return FC_OK;      // runs in the table launch at the end of the plan
             WgradArgs b = a;
             b.B = c.B; b.dw = c.grads + wo; b.db = bo >= 0 ? c.grads + bo : nullptr;
             if (own && c.B == maxB) { b.ws = own; b.ws_floats = own_floats; return conv_wgrad_launch_noreduce(b, s); }
@@ -136,7 +163,7 @@ struct BwdBuilder : PlanBuilder {
         wgrad(p + ".block2.proj.weight", p + ".block2.proj.bias", a1, nullptr, dh2, 3, 1, 1, 0);
         dgrad_to(p + ".block2.proj.weight", cout, cout, 3, 1, dh2, 0, da1, nullptr);
         release(a1);
-        Act dh1 = dh2;   // dh2 is dead once conv2's gradients are out
+        Act dh1 = pinned.count(dh2.p) ? act(cout, H, W) : dh2;   // dh2 is dead once conv2's gradients are out (unless a deferred launch still reads it)
         gn_bwd(da1, r.h1, xf1, dh1.p, false, p + ".block1.norm", u->ss_off.at(p));
         release(da1);
         const Act* sk = r.skip.p ? &r.skip : nullptr;
@@ -434,6 +461,23 @@ int build_backward(fc_unet* u) {
         }
     }
     if (b.err) return b.err;
+    // -- the deferred weight gradients: one launch per kernel size --
+    for (auto& kv : b.wclasses) {
+        BwdBuilder::WgradClass& wc = kv.second;
+        if (wc.jobs.empty()) continue;
+        b.scope = "wgrad";
+        WgradDev* jd = reinterpret_cast<WgradDev*>(b.dmalloc((wc.jobs.size() * sizeof(WgradDev) + 3) / 4 + 4));
+        int2* bd = reinterpret_cast<int2*>(b.dmalloc(wc.blocks.size() * 2 + 4));
+        if (b.err) return b.err;
+        FC_HIP(hipMemcpy(jd, wc.jobs.data(), wc.jobs.size() * sizeof(WgradDev), hipMemcpyHostToDevice));
+        FC_HIP(hipMemcpy(bd, wc.blocks.data(), wc.blocks.size() * sizeof(int2), hipMemcpyHostToDevice));
+        const int nblk = (int)wc.blocks.size(), ks = kv.first;
+        const size_t lds = wc.lds;
+        double fl = 0;
+        for (const WgradDev& d : wc.jobs) fl += 2.0 * d.a.H * d.a.W * ks * ks * (double)d.a.Cin * d.a.Cout;
+        b.push([=](const FwdCtx& cx, hipStream_t s) { return cx.B == B ? conv_wgrad_table_launch(ks, jd, bd, nblk, lds, cx.grads, s) : (int)FC_OK; },
+               "conv_wgrad_table", fl);
+    }
     // -- the split partials of every weight gradient above, summed in one launch (full-batch steps; smaller batches reduced per launch) --
     if (!b.wred_jobs.empty()) {
         b.scope = "wgrad";
