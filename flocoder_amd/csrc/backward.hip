@@ -676,8 +676,39 @@ __global__ void __launch_bounds__(256) dense_bwd_x_kernel(const float* dy, int l
         dx[t] = accumulate ? dx[t] + v : v;
     }
 }
+// The same product with one WAVE per output element: the lanes split the reduction over O (lane-strided, coalesced for the transposed
+// weight layout) and meet in a fixed butterfly.  For the FiLM gradient of the whole network (O = every block's scale/shift column,
+// thousands) one thread per output was a serial loop of O steps -- 80 us for 2048 outputs.
+__global__ void __launch_bounds__(256) dense_bwd_x_wave_kernel(const float* dy, int ldy, const float* w, int w_t, int ldw, const float* xpre, int in_act,
+                                                               float* dx, int accumulate, int B, int I, int O) {
+    const int lane = threadIdx.x & 63;
+    const size_t t = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= (size_t)B * I) return;
+    const int i = (int)(t % I), b = (int)(t / I);
+    const float* dyb = dy + (size_t)b * ldy;
+    float acc = 0.f;
+    if (w_t) {
+        const float* wr = w + (size_t)i * ldw;
+        for (int o = lane; o < O; o += 64) acc += dyb[o] * wr[o];
+    } else {
+        for (int o = lane; o < O; o += 64) acc += dyb[o] * w[(size_t)o * I + i];
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
+    if (lane == 0) {
+        float v = acc;
+        if (xpre) v *= act_grad(xpre[t], in_act);
+        dx[t] = accumulate ? dx[t] + v : v;
+    }
+}
 int dense_bwd_x_launch(const float* dy, int ldy, const float* w, int w_t, int ldw, const float* xpre, int in_act, float* dx, int accumulate,
                        int B, int I, int O, hipStream_t s) {
+    if (O >= 256) {
+        hipLaunchKernelGGL(dense_bwd_x_wave_kernel, dim3((unsigned)(((size_t)B * I + 3) / 4)), dim3(256), 0, s, dy, ldy, w, w_t, ldw, xpre, in_act, dx,
+                           accumulate, B, I, O);
+        FC_HIP(hipGetLastError());
+        return FC_OK;
+    }
     hipLaunchKernelGGL(dense_bwd_x_kernel, dim3(grid_1d((size_t)B * I)), dim3(256), 0, s, dy, ldy, w, w_t, ldw, xpre, in_act, dx, accumulate, B, I, O);
     FC_HIP(hipGetLastError());
     return FC_OK;

@@ -130,6 +130,8 @@ struct FinalizeArgs {       // y = act(gn(h)) + res, optional GroupNorm(1) parti
 };
 int finalize_blocks_per_sample(int HW, int C);
 int finalize_launch(const FinalizeArgs& a, hipStream_t s);
+size_t finalize_lds_bytes(const FinalizeArgs& a);
+int finalize_table_launch(const FinalizeArgs* jobs_dev, const int* bps_dev, const int2* blocks_dev, int nblocks, size_t lds_bytes, hipStream_t s);
 int gn_stats_launch(const float* x_nhwc, float* stats /*[B][G][1][2]*/, int B, int HW, int C, int G, hipStream_t s);
 // [B][G][T][2] partials of n_t elements each -> [B][G][1][2] covering n_t*T elements
 int gn_fold_launch(const float* in, float* out, int B, int G, int T, float n_t, hipStream_t s);

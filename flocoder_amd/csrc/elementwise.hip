@@ -8,7 +8,7 @@ namespace fc {
 // ---------------------------------------------------------------------------------------------------
 // y = act(GroupNorm(h) [FiLM]) + res ; optional GroupNorm(1) partials of y.   grid (bps, B)
 // Closes Block/ResnetBlock (unet.py:66-72,96) and Residual(PreNorm(LinearAttention)) (unet.py:39,133).
-__global__ void __launch_bounds__(256) finalize_kernel(const FinalizeArgs a, int bps) {
+__device__ __forceinline__ void finalize_body(const FinalizeArgs& a, const int bps, const int bx, const int b) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* gm = sm;                 // [G][2]
     float* A = sm + 2 * a.xf.G;     // [C]
@@ -17,9 +17,9 @@ __global__ void __launch_bounds__(256) finalize_kernel(const FinalizeArgs a, int
     float* Ar = gr + 2 * (a.xf_res.mode ? a.xf_res.G : 0);
     float* Br = Ar + (a.xf_res.mode ? a.C : 0);
     __shared__ float red[4];
-    const int b = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int per = a.HW * a.C / bps;  // elements of this block (multiple of 4)
-    const size_t base = (size_t)b * a.HW * a.C + (size_t)blockIdx.x * per;
+    const size_t base = (size_t)b * a.HW * a.C + (size_t)bx * per;
     const bool act = a.xf.mode == 2 && !a.act_after_add, act2 = a.act_after_add != 0, nres = a.xf_res.mode != 0;
     // Nothing below depends on an earlier load except through the two tables, so everything is requested up front: the first NPF
     // rounds of h / res and this thread's gamma / beta / FiLM entries travel together with the statistics -- one memory round trip
@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(const FinalizeArgs a, int
     __syncthreads();
     float s = 0.f, q = 0.f;
     auto finish = [&](int i, float4 v, float4 r) {
-        const int c = (int)((blockIdx.x * (size_t)per + i) % a.C);
+        const int c = (int)((bx * (size_t)per + i) % a.C);
         v.x = A[c] * v.x + Bv[c];
         v.y = A[c + 1] * v.y + Bv[c + 1];
         v.z = A[c + 2] * v.z + Bv[c + 2];
@@ -105,11 +105,31 @@ __global__ void __launch_bounds__(256) finalize_kernel(const FinalizeArgs a, int
         const float Q = block_sum_lds(q, red);
         if (tid == 0) {
             const float mean = S / (float)per;
-            float* d = a.stats_out + ((size_t)b * bps + blockIdx.x) * 2;
+            float* d = a.stats_out + ((size_t)b * bps + bx) * 2;
             d[0] = mean;
             d[1] = Q - S * mean;
         }
     }
+}
+__global__ void __launch_bounds__(256) finalize_kernel(const FinalizeArgs a, int bps) { finalize_body(a, bps, blockIdx.x, blockIdx.y); }
+
+// Many finalize passes in one launch (the training backward recomputes every normalised activation a weight gradient reads; none of
+// them is on the data-gradient chain): block -> (job, bx + bps * sample)
+__global__ void __launch_bounds__(256) finalize_table_kernel(const FinalizeArgs* __restrict__ jobs, const int* __restrict__ job_bps,
+                                                             const int2* __restrict__ blocks) {
+    const int2 bj = blocks[blockIdx.x];
+    const FinalizeArgs a = jobs[bj.x];
+    const int bps = job_bps[bj.x];
+    finalize_body(a, bps, bj.y % bps, bj.y / bps);
+}
+size_t finalize_lds_bytes(const FinalizeArgs& a) {
+    return (size_t)(2 * a.xf.G + 2 * a.C + (a.xf_res.mode ? 2 * a.xf_res.G + 2 * a.C : 0)) * sizeof(float);
+}
+int finalize_table_launch(const FinalizeArgs* jobs_dev, const int* bps_dev, const int2* blocks_dev, int nblocks, size_t lds_bytes, hipStream_t s) {
+    if (!nblocks) return FC_OK;
+    hipLaunchKernelGGL(finalize_table_kernel, dim3(nblocks), dim3(256), lds_bytes, s, jobs_dev, bps_dev, blocks_dev);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
 }
 
 int finalize_blocks_per_sample(int HW, int C) {

@@ -142,11 +142,20 @@ struct BwdBuilder : PlanBuilder {
         norm_jobs.push_back({s12l, xf.gamma, xf.beta, xf.ss, off(norm + ".weight"), off(norm + ".bias"), ss_col, h.C});
     }
     std::vector<NormJob> norm_jobs;
-    void materialize(const Act& h, const SrcXform& xf, const Act& y) {   // y = act(gn(h))
+    // y = act(gn(h)).  `for_wgrad`: the only reader is a deferred weight-gradient entry, so at the full batch the pass joins the
+    // table launch in front of the weight gradients instead of sitting on the data-gradient chain
+    std::vector<FinalizeArgs> fin_jobs;
+    void materialize(const Act& h, const SrcXform& xf, const Act& y, bool for_wgrad = false) {
         if (err) return;
         FinalizeArgs f;
         f.h = h.p; f.xf = xf; f.y = y.p; f.HW = h.H * h.W; f.C = h.C;
-        push([f](const FwdCtx& c, hipStream_t s) { FinalizeArgs g = f; g.B = c.B; return finalize_launch(g, s); }, "finalize");
+        const bool deferred = for_wgrad && batch_wgrad && guard == 0;
+        if (deferred) { f.B = B; fin_jobs.push_back(f); pinned.insert(y.p); }
+        const int maxB = B;
+        push([f, deferred, maxB](const FwdCtx& c, hipStream_t s) -> int {
+            if (deferred && c.B == maxB) return FC_OK;
+            FinalizeArgs g = f; g.B = c.B; return finalize_launch(g, s);
+        }, "finalize");
     }
 
     void resblock(const ResRec& r) {
@@ -159,7 +168,7 @@ struct BwdBuilder : PlanBuilder {
         const SrcXform xf1 = xf_of(r.st1, 2, u->R(p + ".block1.norm.weight"), u->R(p + ".block1.norm.bias"), fw->ss + u->ss_off.at(p), u->S);
         Act dh2 = act(cout, H, W), a1 = act(cout, H, W), da1 = act(cout, H, W);
         gn_bwd(g_out, r.h2, xf2, dh2.p, false, p + ".block2.norm", 0);
-        materialize(r.h1, xf1, a1);
+        materialize(r.h1, xf1, a1, true);
         wgrad(p + ".block2.proj.weight", p + ".block2.proj.bias", a1, nullptr, dh2, 3, 1, 1, 0);
         dgrad_to(p + ".block2.proj.weight", cout, cout, 3, 1, dh2, 0, da1, nullptr);
         release(a1);
@@ -187,7 +196,7 @@ struct BwdBuilder : PlanBuilder {
     void qkv_tail(const std::string& wq, const std::string& norm, const Act& x, const Stat& gn1, const Act& dqkv, const Act& g_out) {
         const SrcXform xf = xf_of(gn1, 1, u->R(norm + ".weight"), u->R(norm + ".bias"));
         Act xn = act(x.C, x.H, x.W), dxn = act(x.C, x.H, x.W);
-        materialize(x, xf, xn);
+        materialize(x, xf, xn, true);
         wgrad(wq, "", xn, nullptr, dqkv, 1, 0, 1, 0);
         dgrad_to(wq, dqkv.C, x.C, 1, 0, dqkv, 0, dxn, nullptr);
         release(xn);
@@ -461,6 +470,28 @@ int build_backward(fc_unet* u) {
         }
     }
     if (b.err) return b.err;
+    // -- the activations only the deferred weight gradients read, recomputed in one launch --
+    if (!b.fin_jobs.empty()) {
+        b.scope = "wgrad";
+        std::vector<int> bps;
+        std::vector<int2> blocks;
+        size_t lds = 0;
+        for (size_t j = 0; j < b.fin_jobs.size(); ++j) {
+            const FinalizeArgs& f = b.fin_jobs[j];
+            bps.push_back(finalize_blocks_per_sample(f.HW, f.C));
+            for (int k = 0; k < bps.back() * B; ++k) blocks.push_back(make_int2((int)j, k));
+            if (finalize_lds_bytes(f) > lds) lds = finalize_lds_bytes(f);
+        }
+        FinalizeArgs* jd = reinterpret_cast<FinalizeArgs*>(b.dmalloc((b.fin_jobs.size() * sizeof(FinalizeArgs) + 3) / 4 + 4));
+        int* pd = reinterpret_cast<int*>(b.dmalloc(bps.size() + 4));
+        int2* bd = reinterpret_cast<int2*>(b.dmalloc(blocks.size() * 2 + 4));
+        if (b.err) return b.err;
+        FC_HIP(hipMemcpy(jd, b.fin_jobs.data(), b.fin_jobs.size() * sizeof(FinalizeArgs), hipMemcpyHostToDevice));
+        FC_HIP(hipMemcpy(pd, bps.data(), bps.size() * sizeof(int), hipMemcpyHostToDevice));
+        FC_HIP(hipMemcpy(bd, blocks.data(), blocks.size() * sizeof(int2), hipMemcpyHostToDevice));
+        const int nblk = (int)blocks.size();
+        b.push([=](const FwdCtx& cx, hipStream_t s) { return cx.B == B ? finalize_table_launch(jd, pd, bd, nblk, lds, s) : (int)FC_OK; }, "finalize_table");
+    }
     // -- the deferred weight gradients: one launch per kernel size --
     for (auto& kv : b.wclasses) {
         BwdBuilder::WgradClass& wc = kv.second;
