@@ -137,6 +137,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const GnBwdArgs a, in
         }
         float4* dst = reinterpret_cast<float4*>(a.dh + base + i);
         if (a.accumulate) { const float4 p = *dst; o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w; }
+        if (a.plus) { const float4 p = *reinterpret_cast<const float4*>(a.plus + base + i); o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w; }
         *dst = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
@@ -240,6 +241,7 @@ __global__ void __launch_bounds__(256) gn_bwd_small_kernel(const GnBwdArgs a) {
         for (int j = 0; j < 4; ++j) o[j] = gaj[j] * ds[j] - k1[j] - ((hs[j] - mean4[j]) * rstd4[j]) * k2[j];
         float4* dst = reinterpret_cast<float4*>(a.dh + base + i);
         if (a.accumulate) { const float4 p = *dst; o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w; }
+        if (a.plus) { const float4 p = *reinterpret_cast<const float4*>(a.plus + base + i); o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w; }
         *dst = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
@@ -417,92 +419,63 @@ __global__ void __launch_bounds__(256) linattn_bwd_ctx_kernel(const float* qkv, 
     if ((tid & 7) == 0) rr[(size_t)blockIdx.x * DH + d] = part;
 }
 
-// Kernel 2, grid (ceil(n/64), B), 64*heads threads: wave h owns head h of 64 consecutive pixels, one thread per pixel, so every LDS
-// read of the 32x32 context matrices is a wave-wide broadcast of consecutive addresses (float4 reads, no bank conflicts -- with
-// the heads interleaved across lanes each read hit one bank four times and the kernel took 180 us on average).
+// Kernel 2, grid (ceil(n/32), B*heads), 256 threads: a half-wave per pixel, one lane per channel, eight pixels per wave (two at a time).
+// Every product is a 32 x 32 matrix-vector one: the matrices sit in LDS (ctx and dctx transposed with a padded row, so the lanes of a
+// pixel read consecutive banks), the pixel's three vectors (dout, v, k) are exchanged through a wave-private LDS row and read back as
+// broadcasts.  One THREAD per pixel and head (the first form of this kernel) did the 3072 multiply-adds and 512 LDS reads of a pixel
+// serially: 33 us per launch whatever n was, a quarter of a millisecond per training step.
 __global__ void __launch_bounds__(256) linattn_bwd_apply_kernel(const float* qkv, const float* dout, const float* ctx, const float* dctx,
                                                                 const float* kst, const float* rr, float* dqkv, int n, int heads) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // ctx[heads][32][32] | dctx[...] | kst[heads][32][2] | rr[heads][32]
-    float* cs = sm;
-    float* dcs = cs + heads * DH * DH;
-    float* ks = dcs + heads * DH * DH;
-    float* rs = ks + heads * DH * 2;
-    const int b = blockIdx.y, tid = threadIdx.x, nthr = 64 * heads;
+    __shared__ float ct[DH][DH + 1];     // ct[e][d]  = ctx[d][e]
+    __shared__ float dct[DH][DH + 1];    // dct[e][d] = dctx[d][e]
+    __shared__ float dc[DH][DH + 1];     // dc[d][e]  = dctx[d][e]
+    __shared__ float vec[4][2][3][DH];
+    const int bh = blockIdx.y, b = bh / heads, h = bh % heads, tid = threadIdx.x;
     const int C3 = 3 * heads * DH, CO = heads * DH;
-    for (int i = tid; i < heads * DH * DH; i += nthr) { cs[i] = ctx[(size_t)b * heads * DH * DH + i]; dcs[i] = dctx[(size_t)b * heads * DH * DH + i]; }
-    for (int i = tid; i < heads * DH * 2; i += nthr) ks[i] = kst[(size_t)b * heads * DH * 2 + i];
-    for (int i = tid; i < heads * DH; i += nthr) rs[i] = rr[(size_t)b * heads * DH + i];
-    __syncthreads();
+    for (int i = tid; i < DH * DH; i += 256) {
+        const int d = i >> 5, e = i & 31;
+        const float c = ctx[(size_t)bh * DH * DH + i], g = dctx[(size_t)bh * DH * DH + i];
+        ct[e][d] = c; dct[e][d] = g; dc[d][e] = g;
+    }
+    const int lane = tid & 63, half = lane >> 5, c = lane & 31, w = tid >> 6;
+    const float kmax = kst[((size_t)bh * DH + c) * 2], kinv = kst[((size_t)bh * DH + c) * 2 + 1], rrc = rr[(size_t)bh * DH + c];
     const float scale = 0.17677669529663687f;
-    const int h = tid >> 6, pix = blockIdx.x * 64 + (tid & 63);
-    if (pix >= n) return;
-    const float* base = qkv + ((size_t)b * n + pix) * C3 + h * DH;
-    const float* dop = dout + ((size_t)b * n + pix) * CO + h * DH;
-    float* outp = dqkv + ((size_t)b * n + pix) * C3 + h * DH;
-    const float4* ch = reinterpret_cast<const float4*>(cs + h * DH * DH);
-    const float4* dch = reinterpret_cast<const float4*>(dcs + h * DH * DH);
-    float p[DH], g[DH];
+    __syncthreads();
+    for (int it = 0; it < 4; ++it) {
+        const int pix = blockIdx.x * 32 + w * 8 + it * 2 + half;
+        const bool in = pix < n;
+        const size_t row = (size_t)b * n + (in ? pix : 0);
+        const float* base = qkv + row * C3 + h * DH;
+        const float qraw = base[c], kraw = base[heads * DH + c], v = base[2 * heads * DH + c], g = dout[row * CO + h * DH + c];
+        float m = qraw;
 #pragma unroll
-    for (int i = 0; i < DH; i += 4) {
-        const float4 a4 = *reinterpret_cast<const float4*>(base + i), b4 = *reinterpret_cast<const float4*>(dop + i);
-        p[i] = a4.x; p[i + 1] = a4.y; p[i + 2] = a4.z; p[i + 3] = a4.w;
-        g[i] = b4.x; g[i + 1] = b4.y; g[i + 2] = b4.z; g[i + 3] = b4.w;
-    }
-    // ---- q: p = softmax_d(q_raw); dq = ctx . dout; dq_raw = p (s dq - sum_d p s dq)
-    float m = p[0];
+        for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float p = __expf(qraw - m), sum = p;
 #pragma unroll
-    for (int i = 1; i < DH; ++i) m = fmaxf(m, p[i]);
-    float sum = 0.f;
+        for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        p /= sum;
+        const float k = __expf(kraw - kmax) * kinv;
+        float* vr = &vec[w][half][0][0];
+        vr[c] = g; vr[DH + c] = v; vr[2 * DH + c] = k;
+        __syncthreads();
+        float dq = 0.f, dk = 0.f, dvv = 0.f;
 #pragma unroll
-    for (int i = 0; i < DH; ++i) { p[i] = __expf(p[i] - m); sum += p[i]; }
-    const float inv = 1.0f / sum;
-    float dot = 0.f;
-    float dp[DH];
-#pragma unroll
-    for (int d = 0; d < DH; ++d) {
-        float acc = 0.f;
-#pragma unroll
-        for (int e4 = 0; e4 < DH / 4; ++e4) {
-            const float4 c4 = ch[d * (DH / 4) + e4];
-            acc += c4.x * g[4 * e4] + c4.y * g[4 * e4 + 1] + c4.z * g[4 * e4 + 2] + c4.w * g[4 * e4 + 3];
+        for (int e = 0; e < DH; ++e) {
+            dq += ct[e][c] * vr[e];              // sum_e ctx[c][e] dout[e]
+            dk += dct[e][c] * vr[DH + e];        // sum_e dctx[c][e] v[e]
+            dvv += dc[e][c] * vr[2 * DH + e];    // sum_d dctx[d][c] k[d]
         }
-        p[d] *= inv;
-        dp[d] = acc * scale;
-        dot += p[d] * dp[d];
-    }
+        const float dp = dq * scale;
+        float dot = p * dp;
 #pragma unroll
-    for (int d = 0; d < DH; d += 4)
-        *reinterpret_cast<float4*>(outp + d) = make_float4(p[d] * (dp[d] - dot), p[d + 1] * (dp[d + 1] - dot), p[d + 2] * (dp[d + 2] - dot), p[d + 3] * (dp[d + 3] - dot));
-    // ---- k, v: k = exp(k_raw - max) / Z; dk = dctx . v; dk_raw = k (dk - rr); dv = dctx^T . k
-    const float* kp = base + heads * DH;
-    const float* vp = kp + heads * DH;
-#pragma unroll
-    for (int i = 0; i < DH; i += 4) {
-        const float4 a4 = *reinterpret_cast<const float4*>(kp + i), b4 = *reinterpret_cast<const float4*>(vp + i);
-        p[i] = __expf(a4.x - ks[(h * DH + i) * 2]) * ks[(h * DH + i) * 2 + 1];
-        p[i + 1] = __expf(a4.y - ks[(h * DH + i + 1) * 2]) * ks[(h * DH + i + 1) * 2 + 1];
-        p[i + 2] = __expf(a4.z - ks[(h * DH + i + 2) * 2]) * ks[(h * DH + i + 2) * 2 + 1];
-        p[i + 3] = __expf(a4.w - ks[(h * DH + i + 3) * 2]) * ks[(h * DH + i + 3) * 2 + 1];
-        g[i] = b4.x; g[i + 1] = b4.y; g[i + 2] = b4.z; g[i + 3] = b4.w;
-    }
-    float dv[DH];
-#pragma unroll
-    for (int e = 0; e < DH; ++e) dv[e] = 0.f;
-#pragma unroll
-    for (int d = 0; d < DH; ++d) {
-        float acc = 0.f;
-#pragma unroll
-        for (int e4 = 0; e4 < DH / 4; ++e4) {
-            const float4 c4 = dch[d * (DH / 4) + e4];
-            acc += c4.x * g[4 * e4] + c4.y * g[4 * e4 + 1] + c4.z * g[4 * e4 + 2] + c4.w * g[4 * e4 + 3];
-            dv[4 * e4] += c4.x * p[d]; dv[4 * e4 + 1] += c4.y * p[d]; dv[4 * e4 + 2] += c4.z * p[d]; dv[4 * e4 + 3] += c4.w * p[d];
+        for (int o = 16; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+        if (in) {
+            float* outp = dqkv + row * C3 + h * DH;
+            outp[c] = p * (dp - dot);                      // dq_raw = p (s dq - sum_d p s dq)
+            outp[heads * DH + c] = k * (dk - rrc);         // dk_raw = k (dk - rr)
+            outp[2 * heads * DH + c] = dvv;
         }
-        dp[d] = p[d] * (acc - rs[h * DH + d]);
-    }
-#pragma unroll
-    for (int d = 0; d < DH; d += 4) {
-        *reinterpret_cast<float4*>(outp + heads * DH + d) = make_float4(dp[d], dp[d + 1], dp[d + 2], dp[d + 3]);
-        *reinterpret_cast<float4*>(outp + 2 * heads * DH + d) = make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]);
+        __syncthreads();
     }
 }
 
@@ -511,8 +484,7 @@ int linattn_bwd_launch(const float* qkv, const float* dout, const float* ctx, fl
     hipLaunchKernelGGL(linattn_bwd_ctx_kernel, dim3(B * heads), dim3(256), 0, s, qkv, dout, ctx, dctx, kst, rr, n, heads);
     FC_HIP(hipGetLastError());
     if (heads < 1 || heads > 4) return fail(FC_E_SHAPE, "linattn_bwd: at most 4 heads");
-    const size_t lds = (size_t)(2 * heads * DH * DH + 3 * heads * DH) * sizeof(float);
-    hipLaunchKernelGGL(linattn_bwd_apply_kernel, dim3(cdiv(n, 64), B), dim3(64 * heads), lds, s, qkv, dout, ctx, dctx, kst, rr, dqkv, n, heads);
+    hipLaunchKernelGGL(linattn_bwd_apply_kernel, dim3(cdiv(n, 32), B * heads), dim3(256), 0, s, qkv, dout, ctx, dctx, kst, rr, dqkv, n, heads);
     FC_HIP(hipGetLastError());
     return FC_OK;
 }

@@ -313,6 +313,7 @@ struct GnBwdArgs {          // backward of y = act((gamma xhat + beta)(sc+1) + s
     float* s12p = nullptr;      // [B][gn_bwd_chunks(HW)][C][2]: the same per 64-pixel chunk (scratch between the two passes)
     float* dh = nullptr;        // NHWC [B][HW][C]
     int accumulate = 0;         // dh += instead of dh =
+    const float* plus = nullptr;// optional addend of dh's shape (the residual branch's gradient: one pass instead of this + an axpy)
     int B = 0, HW = 0, C = 0;
 };
 int gn_bwd_chunks(int HW);

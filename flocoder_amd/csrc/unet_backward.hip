@@ -133,9 +133,10 @@ struct BwdBuilder : PlanBuilder {
         t.written = true;
     }
     // GroupNorm(+FiLM)(+SiLU) backward of y = f(h): dh (+)= ..., parameter gradients of the norm, FiLM gradients into dss
-    void gn_bwd(const Act& dy, const Act& h, const SrcXform& xf, float* dh, bool acc, const std::string& norm, int ss_col) {
+    void gn_bwd(const Act& dy, const Act& h, const SrcXform& xf, float* dh, bool acc, const std::string& norm, int ss_col, const float* plus = nullptr) {
         if (err) return;
         GnBwdArgs g;
+        g.plus = plus;
         float* s12l = dmalloc((size_t)B * h.C * 2);      // kept until the batched parameter-gradient launch at the end
         g.dy = dy.p; g.h = h.p; g.xf = xf; g.s12 = s12l; g.s12p = s12p; g.dh = dh; g.accumulate = acc ? 1 : 0; g.HW = h.H * h.W; g.C = h.C;
         push([g](const FwdCtx& c, hipStream_t s) { GnBwdArgs k = g; k.B = c.B; return gn_bwd_launch(k, s); }, "gn_bwd");
@@ -201,10 +202,9 @@ struct BwdBuilder : PlanBuilder {
         dgrad_to(wq, dqkv.C, x.C, 1, 0, dqkv, 0, dxn, nullptr);
         release(xn);
         Slot& t = slot(x);
-        gn_bwd(dxn, x, xf, t.g.p, t.written, norm, 0);
+        gn_bwd(dxn, x, xf, t.g.p, t.written, norm, 0, g_out.p);    // + the residual branch: d(x) (+)= GN'(dxn) + d(out)
         t.written = true;
         release(dxn);
-        accumulate(x, g_out);
     }
 
     void linattn(const LinRec& r) {
