@@ -283,6 +283,7 @@ struct WgradArgs {          // dW[co][ci][ky][kx] (+ db[co]) of a convolution fr
     float* db = nullptr;                       // [Cout] or null
     float* ws = nullptr; size_t ws_floats = 0; // split-reduction workspace
     int B = 0, H = 0, W = 0, Hs = 0, Ws = 0, Cin = 0, Cout = 0, KS = 1, pad = 0, stride = 1, ups = 0;
+    int split_target = 1024;                   // workgroups wanted per launch: the pixel tiles are split until nci * nco * nsplit reaches it
 };
 struct WgradDev {            // a launch's geometry as the device sees it (conv_wgrad.hip)
     WgradArgs a;
@@ -297,7 +298,7 @@ size_t conv_wgrad_workspace(const WgradArgs& a);
 int conv_wgrad_launch(const WgradArgs& a, hipStream_t s);
 // The split partials of MANY weight-gradient launches summed by ONE table-driven launch at the end of the backward (each launch then
 // needs a workspace of its own): 53 five-microsecond reduce launches per training step become one.
-struct WredJob { const float* ws; int nsplit; int nb; size_t stride, nw; int64_t dw, db; };   // dw / db: offsets into the flat gradient vector (db < 0: none)
+struct WredJob { const float* ws; int nsplit; int nb; size_t stride, nw; int64_t dw, db; int cin, kk; };   // dw / db: offsets into the flat gradient vector (db < 0: none)
 int conv_wgrad_split(const WgradArgs& a, int* nsplit, size_t* part_stride);                   // geometry of the launch conv_wgrad_launch would make
 int conv_wgrad_launch_noreduce(const WgradArgs& a, hipStream_t s);                           // partials into a.ws (nsplit > 1), nothing else
 // Every weight gradient of one kernel size in one launch (full-batch training steps): the entries' inputs must all still be alive

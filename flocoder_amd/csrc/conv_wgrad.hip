@@ -140,7 +140,9 @@ __device__ __forceinline__ void wgrad_body(const WgradDev& p, const int split, c
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (ci < a.Cin) dst[((size_t)co * a.Cin + ci) * KK + tap] = acc[t][r];
+                    // partials are kept [tap][ci][co] (the 32 lanes of a store are 32 consecutive floats); the reduction writes the
+                    // reference's [co][ci][tap] order.  In that order a store instruction touched 64 different cache lines.
+                    if (ci < a.Cin) dst[p.nsplit > 1 ? ((size_t)tap * a.Cin + ci) * a.Cout + co : ((size_t)co * a.Cin + ci) * KK + tap] = acc[t][r];
                 }
             }
         }
@@ -166,8 +168,16 @@ __global__ void __launch_bounds__(256) conv_wgrad_table_kernel(const WgradDev* _
     wgrad_body<KS>(p, bj.y % p.nsplit, bj.y / p.nsplit, grads + p.dw_off, p.db_off >= 0 ? grads + p.db_off : nullptr);
 }
 
+// element e of a partial vector ([tap][ci][co] | bias) -> its place in the [co][ci][tap] | bias result
+__device__ __forceinline__ size_t wgrad_final_index(size_t e, size_t nw, int cout, int cin, int kk) {
+    if (e >= nw) return e;
+    const int co = (int)(e % cout), ci = (int)((e / cout) % cin), tap = (int)(e / ((size_t)cout * cin));
+    return ((size_t)co * cin + ci) * kk + tap;
+}
+
 // 256 threads = 64 elements x 4 split lanes (fixed assignment and fixed combine order: bit-reproducible)
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* ws, int nsplit, size_t stride, float* dw, size_t nw, float* db, int nb) {
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* ws, int nsplit, size_t stride, float* dw, size_t nw, float* db, int nb, int cin,
+                                                           int kk) {
     __shared__ float part[4][64];
     const size_t total = nw + (db ? nb : 0);
     const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
@@ -181,13 +191,13 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* ws, int 
         __syncthreads();
         if (sl == 0 && e < total) {
             const float v = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
-            if (e < nw) dw[e] = v;
+            if (e < nw) dw[wgrad_final_index(e, nw, nb, cin, kk)] = v;
             else db[e - nw] = v;
         }
     }
 }
 
-// block (job, chunk): 64 consecutive elements of one job's [dw | db] vector, 4 split lanes each (same fixed order as wgrad_reduce_kernel)
+// block (job, chunk): 64 consecutive elements of one job's partial vector, 4 split lanes each (same fixed order as wgrad_reduce_kernel)
 __global__ void __launch_bounds__(256) wgrad_reduce_table_kernel(const WredJob* jobs, const int2* blocks, float* grads) {
     __shared__ float part[4][64];
     const int2 bj = blocks[blockIdx.x];
@@ -201,7 +211,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_table_kernel(const WredJob* 
     __syncthreads();
     if (sl == 0 && e < total) {
         const float v = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
-        if (e < j.nw) grads[j.dw + e] = v;
+        if (e < j.nw) grads[j.dw + wgrad_final_index(e, j.nw, j.nb, j.cin, j.kk)] = v;
         else grads[j.db + (e - j.nw)] = v;
     }
 }
@@ -233,7 +243,7 @@ static int wgrad_geometry(const WgradArgs& a, WgradDev* d) {
     if (p.P > 1024) return fail(FC_E_SHAPE, "wgrad: patch does not fit in LDS");
     p.mtiles = cdiv(a.B, p.TB) * p.tiles_x * p.tiles_y;
     p.nci = cdiv(a.Cin, 32); p.nco = cdiv(a.Cout, 32);
-    int ns = cdiv(1024, p.nci * p.nco);
+    int ns = cdiv(a.split_target > 0 ? a.split_target : 1024, p.nci * p.nco);
     if (ns > 256) ns = 256;
     if (ns > p.mtiles) ns = p.mtiles;
     p.part_stride = ((size_t)a.Cout * a.Cin * a.KS * a.KS + a.Cout + 3) & ~(size_t)3;
@@ -286,7 +296,7 @@ static int wgrad_launch_impl(const WgradArgs& a, bool reduce, hipStream_t s) {
         const size_t nw = (size_t)a.Cout * a.Cin * a.KS * a.KS;
         const size_t total = nw + (a.db ? a.Cout : 0);
         const int g = (int)((total + 63) / 64 < 4096 ? (total + 63) / 64 : 4096);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g), dim3(256), 0, s, a.ws, d.nsplit, d.part_stride, a.dw, nw, a.db, a.Cout);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g), dim3(256), 0, s, a.ws, d.nsplit, d.part_stride, a.dw, nw, a.db, a.Cout, a.Cin, a.KS * a.KS);
         FC_HIP(hipGetLastError());
     }
     return FC_OK;

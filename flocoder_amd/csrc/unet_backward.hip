@@ -72,15 +72,19 @@ struct BwdBuilder : PlanBuilder {
         int ns = 1; size_t stride_f = 0;
         static const bool no_defer = std::getenv("FLOCODER_AMD_WGRAD_REDUCE_EACH") != nullptr;
         float* own = nullptr;
+        // a table launch runs ~70 layers side by side: a quarter of the stand-alone split fills the chip, with a quarter of the partials
+        static const int table_target = [] { const char* e = std::getenv("FLOCODER_AMD_WGRAD_TABLE_SPLIT"); return e ? std::atoi(e) : 256; }();
+        const bool to_table = batch_wgrad && !no_defer && guard == 0;
+        if (to_table) a.split_target = table_target;
         if (!no_defer && guard == 0 && conv_wgrad_split(a, &ns, &stride_f) == FC_OK && ns > 1) {   // guarded (mask-branch) launches may not run: they reduce on the spot
             own = dmalloc((size_t)ns * stride_f);
             if (err) return;
-            wred_jobs.push_back({own, ns, a.Cout, stride_f, (size_t)a.Cout * a.Cin * KS * KS, wo, bo});
+            wred_jobs.push_back({own, ns, a.Cout, stride_f, (size_t)a.Cout * a.Cin * KS * KS, wo, bo, a.Cin, KS * KS});
         }
         const int maxB = B;
         const size_t own_floats = (size_t)ns * stride_f;
         bool deferred = false;
-        if (batch_wgrad && !no_defer && guard == 0) {
+        if (to_table) {
             WgradArgs e = a;
             e.ws = own; e.ws_floats = 0;
             WgradDev d;
@@ -99,6 +103,7 @@ struct BwdBuilder : PlanBuilder {
         push([a, wo, bo, own, own_floats, maxB, deferred](const FwdCtx& c, hipStream_t s) -> int {
             if (deferred && c.B == maxB) return FC_OK;      // runs in the table launch at the end of the plan
             WgradArgs b = a;
+            if (!(own && c.B == maxB)) b.split_target = 1024;
             b.B = c.B; b.dw = c.grads + wo; b.db = bo >= 0 ? c.grads + bo : nullptr;
             if (own && c.B == maxB) { b.ws = own; b.ws_floats = own_floats; return conv_wgrad_launch_noreduce(b, s); }
             return conv_wgrad_launch(b, s);
