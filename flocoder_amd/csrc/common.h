@@ -73,6 +73,8 @@ struct ConvFin {
     unsigned* sync = nullptr;       // one arrival counter per sample group, never reset: arrival number / group size + 1 = this launch's epoch
     unsigned long long* gran = nullptr;   // [B][G][T][2] tagged granules {epoch << 32 | float bits}: the partials AS the hand-off (no flag, no fence)
     int* err = nullptr;             // set to 1 if a wait ever times out
+    float* raw = nullptr;           // training plans: the convolution output BEFORE the tail (NHWC, the backward's h2) is stored too, and
+                                    // the partial statistics also land in stats_out in the ordinary [B][G][T][2] form
 };
 
 struct ConvArgs {

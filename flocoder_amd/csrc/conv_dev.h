@@ -86,7 +86,7 @@ __device__ __forceinline__ void conv_params_from_lanes(ConvDev& p) {
     a.w = as_global(a.w); a.bias = as_global(a.bias); a.out = as_global(a.out); a.add = as_global(a.add);
     a.stats_out = as_global(a.stats_out); a.res_w = as_global(a.res_w); a.res_b = as_global(a.res_b); a.res_out = as_global(a.res_out);
     a.fin.gamma = as_global(a.fin.gamma); a.fin.beta = as_global(a.fin.beta); a.fin.res = as_global(a.fin.res);
-    a.fin.gn1_out = as_global(a.fin.gn1_out); a.fin.sync = as_global(a.fin.sync); a.fin.gran = as_global(a.fin.gran); a.fin.err = as_global(a.fin.err);
+    a.fin.gn1_out = as_global(a.fin.gn1_out); a.fin.raw = as_global(a.fin.raw); a.fin.sync = as_global(a.fin.sync); a.fin.gran = as_global(a.fin.gran); a.fin.err = as_global(a.fin.err);
     p.zeros16 = as_global(p.zeros16); p.stamps = as_global(p.stamps);
 }
 
@@ -209,6 +209,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
             const unsigned long long tag = (unsigned long long)epoch << 32;
             __hip_atomic_store(gp, tag | __float_as_uint(mean), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(gp + 1, tag | __float_as_uint(q - s * mean), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.fin.raw) { d[0] = mean; d[1] = q - s * mean; }     // the backward reads them in the ordinary form
         } else {
             d[0] = mean;
             d[1] = q - s * mean;
@@ -324,6 +325,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
     }
     conv_stamp(p, 14);
 
+    if (fin && a.fin.raw && owner) {   // training: the pre-norm value stays (GroupNorm backward needs it); issued before the meeting's wait
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = n0 + (wn * NT + nt) * 32 + l31;
+                if (n >= Cout) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int px = pix_of(mt, r);
+                    if (px >= 0) a.fin.raw[(size_t)px * Cout + n] = acc[mt][nt][r];
+                }
+            }
+    }
     if (fin) {
         // ---- meet the other workgroups of this sample group: their partials complete the GroupNorm statistics ----
         // The exchanged bytes (partials, counter) travel as device-scope relaxed atomics -- sc1 accesses that bypass the

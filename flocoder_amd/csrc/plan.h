@@ -256,7 +256,7 @@ struct PlanBuilder {
     // the workgroups of a sample through a counter (ConvFin).  Returns false, emitting nothing, when the launch cannot keep its whole
     // grid resident or the shape is outside the fused tail's conditions -- the caller then emits conv + finalize.
     bool conv_fin(ConvArgs a, const Act& out, int G, const float* gamma, const float* beta, const float* res, bool want_gn1, Stat* gn1,
-                  bool only_local = false) {
+                  bool only_local = false, const Act* raw = nullptr, Stat* st_out = nullptr) {
         if (err) return false;
         a.B = B; a.H = out.H; a.W = out.W; a.Cout = out.C; a.out = out.p;
         a.Cin = a.s0.C + a.s1.C;
@@ -268,6 +268,7 @@ struct PlanBuilder {
         if (only_local && !g.fin_local) return false;    // the cross-workgroup meeting costs what the finalize launch costs; the local form is free
         Stat st = stat(G, g.T, g.n_t);
         a.stats_out = st.p;
+        if (raw) { a.fin.raw = raw->p; if (st_out) *st_out = st; }
         if (want_gn1) { *gn1 = stat(1, g.T1, g.n_t1); a.fin.gn1_out = gn1->p; }
         unsigned* sync = reinterpret_cast<unsigned*>(dmalloc((size_t)g.groups + 1));
         if (err) return false;

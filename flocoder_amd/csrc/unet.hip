@@ -163,9 +163,13 @@ struct Builder : PlanBuilder {
         // Where a tile holds whole GroupNorm groups (dim 32: the 128-channel blocks at 4x4 and 8x8, 32 channels per group) there is nothing to meet
         // for and the tail is always fused (FLOCODER_AMD_FUSED_TAIL=0 turns that off too).
         static const bool no_local = [] { const char* e = std::getenv("FLOCODER_AMD_FUSED_TAIL"); return e && std::string(e) == "0"; }();
-        const bool fused = !u->keep_all && (fused_tail_enabled() || !no_local) &&
+        // training plans can fuse the tail too, keeping what the backward reads (raw h2, its statistics in the ordinary form):
+        // FLOCODER_AMD_TRAIN_FUSED_TAIL=1.  Off by default -- measured on one box (r02): stl_sd step 3.515 ms fused against 3.446 ms
+        // with conv + finalize, flowers-sized step 7.91 against 7.92: at these small grids the meeting costs what the launch it saves does.
+        static const bool train_fused = [] { const char* e = std::getenv("FLOCODER_AMD_TRAIN_FUSED_TAIL"); return e && std::string(e) == "1"; }();
+        const bool fused = (!u->keep_all || train_fused) && (fused_tail_enabled() || !no_local) &&
                            conv_fin(b, out, G, u->R(p + ".block2.norm.weight"), u->R(p + ".block2.norm.bias"), resp, want_gn1, gn1,
-                                    !fused_tail_enabled());
+                                    !fused_tail_enabled(), u->keep_all ? &h2 : nullptr, u->keep_all ? &st2 : nullptr);
         if (!fused) {
             conv(b, h2, G, &st2);
             FinalizeArgs f;
