@@ -59,6 +59,7 @@ SIGNATURES = {
     "fc_unet_arena_serial": (C.c_uint64, [_vp]),
     "fc_unet_class_param_range": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "fc_flow_interp": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _vp]),
+    "fc_flow_prepare": (_i, [_vp, _vp, _vp, _vp, _f, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp]),
     "fc_mse_loss_grad": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "fc_grad_clip_coef": (_i, [_vp, _i64, _vp, _i64, C.c_float, _vp, _vp, _vp]),
     "fc_adam_ema_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, C.c_float, C.c_float, C.c_float, C.c_float, _i, C.c_float, _i, _vp]),

@@ -145,7 +145,8 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const GnBwdArgs a, in
 // The same two passes as ONE launch when a sample's tensor is small (HW*C <= 8192 floats, C a power of two): one workgroup per
 // sample reduces, meets in LDS and applies, re-reading h / dy from cache.  At the training shapes (B = 32, 16x16 latents) the two
 // launches above were pure latency, 55 times per step.  256 threads; thread t owns float4 columns c0 = 4t mod C of rows t*4/C + k*1024/C.
-__global__ void __launch_bounds__(256) gn_bwd_small_kernel(const GnBwdArgs a) {
+template <int NTH>
+__global__ void __launch_bounds__(NTH) gn_bwd_small_kernel(const GnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* gt = sm;                       // [G][4]
     float* A = gt + 4 * a.xf.G;
@@ -153,25 +154,25 @@ __global__ void __launch_bounds__(256) gn_bwd_small_kernel(const GnBwdArgs a) {
     float* ga = Bv + a.C;
     float* f1 = ga + a.C;
     float* f2 = f1 + a.C;
-    float* r1 = f2 + a.C;                 // [256][4]
-    float* r2 = r1 + 1024;
+    float* r1 = f2 + a.C;                 // [NTH][4]
+    float* r2 = r1 + 4 * NTH;
     const int b = blockIdx.x, tid = threadIdx.x, C = a.C, cpg = C / a.xf.G, total = a.HW * C;
     const size_t base = (size_t)b * total;
     const bool act = a.xf.mode == 2;
     // operands that depend on nothing computed here: requested together
     const int c0 = (4 * tid) & (C - 1);
     float4 hv[8], dv[8];                  // up to 8192 / 1024 float4 per thread of each tensor
-    const int nk = (total + 1023) >> 10;
+    const int nk = (total + 4 * NTH - 1) / (4 * NTH);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const int i = 4 * tid + 1024 * k;
+        const int i = 4 * tid + 4 * NTH * k;
         const bool in = k < nk && i < total;
         hv[k] = in ? *reinterpret_cast<const float4*>(a.h + base + i) : make_float4(0.f, 0.f, 0.f, 0.f);
         dv[k] = in ? *reinterpret_cast<const float4*>(a.dy + base + i) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int g = tid; g < a.xf.G; g += 256) combine_partials(a.xf, b, g, &gt[4 * g], &gt[4 * g + 1]);
+    for (int g = tid; g < a.xf.G; g += NTH) combine_partials(a.xf, b, g, &gt[4 * g], &gt[4 * g + 1]);
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
+    for (int c = tid; c < C; c += NTH) {
         const int g = c / cpg;
         const float mean = gt[4 * g], rstd = gt[4 * g + 1];
         float gam = a.xf.gamma[c];
@@ -191,7 +192,7 @@ __global__ void __launch_bounds__(256) gn_bwd_small_kernel(const GnBwdArgs a) {
     for (int j = 0; j < 4; ++j) { const int g = (c0 + j) / cpg; mean4[j] = gt[4 * g]; rstd4[j] = gt[4 * g + 1]; }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        if (k >= nk || 4 * tid + 1024 * k >= total) break;
+        if (k >= nk || 4 * tid + 4 * NTH * k >= total) break;
         float hs[4] = {hv[k].x, hv[k].y, hv[k].z, hv[k].w}, ds[4] = {dv[k].x, dv[k].y, dv[k].z, dv[k].w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -206,8 +207,8 @@ __global__ void __launch_bounds__(256) gn_bwd_small_kernel(const GnBwdArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) { r1[4 * tid + j] = s1[j]; r2[4 * tid + j] = s2[j]; }
     __syncthreads();
-    const int q = C >> 2, rows = 256 / q;          // threads t, t + q, t + 2q ... share the same four channels (C <= 1024: q <= 256)
-    for (int c = tid; c < C; c += 256) {
+    const int q = C >> 2, rows = NTH / q;          // threads t, t + q, t + 2q ... share the same four channels (C <= 1024: q <= 256)
+    for (int c = tid; c < C; c += NTH) {
         float t1 = 0.f, t2 = 0.f;
         for (int r = 0; r < rows; ++r) { t1 += r1[(r * q + (c >> 2)) * 4 + (c & 3)]; t2 += r2[(r * q + (c >> 2)) * 4 + (c & 3)]; }
         f1[c] = t1; f2[c] = t2;
@@ -215,7 +216,7 @@ __global__ void __launch_bounds__(256) gn_bwd_small_kernel(const GnBwdArgs a) {
         a.s12[((size_t)b * C + c) * 2 + 1] = t2;
     }
     __syncthreads();
-    for (int g = tid; g < a.xf.G; g += 256) {
+    for (int g = tid; g < a.xf.G; g += NTH) {
         float p1 = 0.f, p2 = 0.f;
         const float rstd = gt[4 * g + 1];
         for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
@@ -233,7 +234,7 @@ __global__ void __launch_bounds__(256) gn_bwd_small_kernel(const GnBwdArgs a) {
     for (int j = 0; j < 4; ++j) { const int g = (c0 + j) / cpg; k1[j] = gt[4 * g + 2]; k2[j] = gt[4 * g + 3]; gaj[j] = ga[c0 + j]; }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const int i = 4 * tid + 1024 * k;
+        const int i = 4 * tid + 4 * NTH * k;
         if (k >= nk || i >= total) break;
         const float hs[4] = {hv[k].x, hv[k].y, hv[k].z, hv[k].w}, ds[4] = {dv[k].x, dv[k].y, dv[k].z, dv[k].w};
         float o[4];
@@ -254,7 +255,14 @@ int gn_bwd_launch(const GnBwdArgs& a, hipStream_t s) {
     static const bool no_small = std::getenv("FLOCODER_AMD_GN_BWD_SPLIT") != nullptr;
     if (!no_small && a.HW * a.C <= 8192 && (a.C & (a.C - 1)) == 0 && a.C <= 1024 && a.C % a.xf.G == 0) {
         const size_t lds = (size_t)(4 * a.xf.G + 5 * a.C + 2048) * sizeof(float);
-        hipLaunchKernelGGL(gn_bwd_small_kernel, dim3(a.B), dim3(256), lds, s, a);
+        hipLaunchKernelGGL(gn_bwd_small_kernel<256>, dim3(a.B), dim3(256), lds, s, a);
+        FC_HIP(hipGetLastError());
+        return FC_OK;
+    }
+    // up to 32768 elements per sample (32 channels at 32x32): the same one-pass form with 1024 threads instead of reduce + apply
+    if (!no_small && a.HW * a.C <= 32768 && (a.C & (a.C - 1)) == 0 && a.C <= 1024 && a.C % a.xf.G == 0) {
+        const size_t lds = (size_t)(4 * a.xf.G + 5 * a.C + 8192) * sizeof(float);
+        hipLaunchKernelGGL(gn_bwd_small_kernel<1024>, dim3(a.B), dim3(1024), lds, s, a);
         FC_HIP(hipGetLastError());
         return FC_OK;
     }
@@ -342,81 +350,114 @@ int norm_param_grads_table_launch(const NormJob* jobs_dev, int njobs, int maxC, 
 //   dctx[d][e] = sum_n q[d][n] dout[e][n];  dq[d][n] = sum_e ctx[d][e] dout[e][n];  dk[d][n] = sum_e dctx[d][e] v[e][n];
 //   dv[e][n] = sum_d dctx[d][e] k[d][n];   softmax_n backward needs sum_n k dk = sum_e dctx[d][e] ctx[d][e] =: rr[d].
 // Kernel 1, grid (B*heads): column statistics of k_raw, dctx and rr.
-__global__ void __launch_bounds__(256) linattn_bwd_ctx_kernel(const float* qkv, const float* dout, const float* ctx, float* dctx, float* kst,
-                                                              float* rr, int n, int heads) {
-    __shared__ float red[8][DH];
+template <int NW, int KV>        // waves; values of a k column a thread keeps in registers (n <= 2 NW KV runs from registers)
+__global__ void __launch_bounds__(NW * 64) linattn_bwd_ctx_kernel(const float* qkv, const float* dout, const float* ctx, float* dctx, float* kst,
+                                                                  float* rr, int n, int heads) {
+    constexpr int NG = 2 * NW;                     // row groups of the column statistics
+    __shared__ float red[NG][DH];
     __shared__ float kmax[DH];
-    __shared__ float qs[64][DH + 1], ds[64][DH + 1];
+    __shared__ float wred[(NW - 1) * 16 * 64];     // waves 1.. park their accumulators here
     const int b = blockIdx.x / heads, h = blockIdx.x % heads, tid = threadIdx.x;
     const int C3 = 3 * heads * DH, CO = heads * DH;
     const float* qb = qkv + (size_t)b * n * C3 + h * DH;
     const float* kb = qb + heads * DH;
     const float* db = dout + (size_t)b * n * CO + h * DH;
-    {
+    {   // max and 1 / sum exp of every k column over the n pixels.  Up to 1024 pixels a thread's share (n / 16 values) is requested in one
+        // go and both passes run from registers: one memory round trip instead of 2 n / 8 dependent ones.
         const int d = tid & 31, grp = tid >> 5;
+        const bool cached = n <= NG * KV;
+        float kv[KV];
         float m = -INFINITY;
-        for (int i = grp; i < n; i += 8) m = fmaxf(m, kb[(size_t)i * C3 + d]);
+        if (cached) {
+#pragma unroll
+            for (int k = 0; k < KV; ++k) { const int i = grp + NG * k; kv[k] = i < n ? kb[(size_t)i * C3 + d] : -INFINITY; }
+#pragma unroll
+            for (int k = 0; k < KV; ++k) m = fmaxf(m, kv[k]);
+        } else {
+            for (int i = grp; i < n; i += NG) m = fmaxf(m, kb[(size_t)i * C3 + d]);
+        }
         red[grp][d] = m;
         __syncthreads();
         if (tid < DH) {
             float mm = red[0][tid];
-            for (int g = 1; g < 8; ++g) mm = fmaxf(mm, red[g][tid]);
+            for (int g = 1; g < NG; ++g) mm = fmaxf(mm, red[g][tid]);
             kmax[tid] = mm;
         }
         __syncthreads();
         float z = 0.f;
         const float km = kmax[d];
-        for (int i = grp; i < n; i += 8) z += __expf(kb[(size_t)i * C3 + d] - km);
+        if (cached) {
+#pragma unroll
+            for (int k = 0; k < KV; ++k) z += grp + NG * k < n ? __expf(kv[k] - km) : 0.f;
+        } else {
+            for (int i = grp; i < n; i += NG) z += __expf(kb[(size_t)i * C3 + d] - km);
+        }
         __syncthreads();
         red[grp][d] = z;
         __syncthreads();
         if (tid < DH) {
             float zz = 0.f;
-            for (int g = 0; g < 8; ++g) zz += red[g][tid];
+            for (int g = 0; g < NG; ++g) zz += red[g][tid];
             kst[((size_t)blockIdx.x * DH + tid) * 2] = kmax[tid];
             kst[((size_t)blockIdx.x * DH + tid) * 2 + 1] = 1.0f / zz;
         }
     }
+    // dctx = q^T dout as a 32 x 32 x n product on the matrix pipe: k-step j covers pixels 2j, 2j+1 (one per half-wave), a lane holds
+    // q[pix][d = lane & 31] (softmax over the 32 lanes of its half by shuffles) and dout[pix][e = lane & 31].  The eight waves take
+    // every eighth k-step, eight of them (sixteen loads) in flight at a time, and meet in LDS in a fixed order.
     const float scale = 0.17677669529663687f;
-    const int d = tid >> 3, e0 = (tid & 7) * 4;
-    const int r = tid >> 2, c8 = (tid & 3) * 8;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int i0 = 0; i0 < n; i0 += 64) {
-        __syncthreads();
-        {
-            float qv[8], dv[8];
-            const bool in = i0 + r < n;
+    const int lane = tid & 63, half = lane >> 5, l31 = lane & 31, wave = tid >> 6;
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 acc;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                qv[j] = in ? qb[(size_t)(i0 + r) * C3 + c8 + j] : 0.f;
-                dv[j] = in ? db[(size_t)(i0 + r) * CO + c8 + j] : 0.f;
-            }
-            float m = qv[0];
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int npairs = (n + 1) >> 1;
+    constexpr int UB = NW;                         // k-steps (pairs of loads) a wave keeps in flight
+    for (int j0 = wave; j0 < npairs; j0 += NW * UB) {
+        float qv[UB], gv[UB];
 #pragma unroll
-            for (int j = 1; j < 8; ++j) m = fmaxf(m, qv[j]);
-            m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2));
-            float sum = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { qv[j] = __expf(qv[j] - m); sum += qv[j]; }
-            sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
-            const float f = in ? scale / sum : 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { qs[r][c8 + j] = qv[j] * f; ds[r][c8 + j] = dv[j]; }
+        for (int u = 0; u < UB; ++u) {
+            const int j = j0 + NW * u;
+            const bool in = 2 * j + half < n;
+            const size_t pix = (size_t)(in ? 2 * j + half : 0);
+            qv[u] = in ? qb[pix * C3 + l31] : -INFINITY;
+            gv[u] = in ? db[pix * CO + l31] : 0.f;
         }
-        __syncthreads();
-#pragma unroll 8
-        for (int rr_ = 0; rr_ < 64; ++rr_) {
-            const float qd = qs[rr_][d];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] += qd * ds[rr_][e0 + j];
+        for (int u = 0; u < UB; ++u) {
+            if (j0 + NW * u >= npairs) break;                 // wave-uniform
+            const bool in = 2 * (j0 + NW * u) + half < n;
+            float m = qv[u];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            float e = in ? __expf(qv[u] - m) : 0.f, sum = e;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            const float pq = in ? e * (scale / sum) : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pq, gv[u], acc, 0, 0, 0);
         }
     }
-    const size_t o = ((size_t)blockIdx.x * DH + d) * DH + e0;
-    float part = 0.f;
+    __syncthreads();
+    if (wave > 0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { dctx[o + j] = acc[j]; part += acc[j] * ctx[o + j]; }
-    part += __shfl_xor(part, 1); part += __shfl_xor(part, 2); part += __shfl_xor(part, 4);
-    if ((tid & 7) == 0) rr[(size_t)blockIdx.x * DH + d] = part;
+        for (int r = 0; r < 16; ++r) wred[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[r];
+#pragma unroll
+            for (int w = 0; w < NW - 1; ++w) v += wred[(w * 16 + r) * 64 + lane];
+            const int d = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const size_t o = ((size_t)blockIdx.x * DH + d) * DH + l31;
+            dctx[o] = v;
+            float part = v * ctx[o];
+#pragma unroll
+            for (int w = 16; w > 0; w >>= 1) part += __shfl_xor(part, w);
+            if (l31 == 0) rr[(size_t)blockIdx.x * DH + d] = part;
+        }
+    }
 }
 
 // Kernel 2, grid (ceil(n/32), B*heads), 256 threads: a half-wave per pixel, one lane per channel, eight pixels per wave (two at a time).
@@ -481,7 +522,8 @@ __global__ void __launch_bounds__(256) linattn_bwd_apply_kernel(const float* qkv
 
 int linattn_bwd_launch(const float* qkv, const float* dout, const float* ctx, float* dctx, float* kst, float* rr, float* dqkv, int B, int n,
                        int heads, hipStream_t s) {
-    hipLaunchKernelGGL(linattn_bwd_ctx_kernel, dim3(B * heads), dim3(256), 0, s, qkv, dout, ctx, dctx, kst, rr, n, heads);
+    if (n <= 256) hipLaunchKernelGGL((linattn_bwd_ctx_kernel<4, 32>), dim3(B * heads), dim3(256), 0, s, qkv, dout, ctx, dctx, kst, rr, n, heads);
+    else hipLaunchKernelGGL((linattn_bwd_ctx_kernel<8, 64>), dim3(B * heads), dim3(512), 0, s, qkv, dout, ctx, dctx, kst, rr, n, heads);
     FC_HIP(hipGetLastError());
     if (heads < 1 || heads > 4) return fail(FC_E_SHAPE, "linattn_bwd: at most 4 heads");
     hipLaunchKernelGGL(linattn_bwd_apply_kernel, dim3(cdiv(n, 32), B * heads), dim3(256), 0, s, qkv, dout, ctx, dctx, kst, rr, dqkv, n, heads);
@@ -855,6 +897,44 @@ __global__ void __launch_bounds__(256) flow_interp_kernel(const float* src, cons
 int flow_interp_launch(const float* src, const float* tgt, const float* t, float* x, float* v, int B, int per, hipStream_t s) {
     const size_t total = (size_t)B * per;
     hipLaunchKernelGGL(flow_interp_kernel, dim3(grid_1d(total)), dim3(256), 0, s, src, tgt, t, x, v, total, per);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
+// The whole torch prologue of a training step in one launch (train_flow.py:346-357): t = warp_time(u (1 - eps) + eps) with the very
+// operations torch runs (sampling.py:23-33: 4(1-s) t^3 + 6(s-1) t^2 + (3-2s) t, each product and sum rounded once), the U-Net's time
+// input t * t_scale, x = (1 - t) s + t g and v* = g - s with the OT pairing's gather of the target rows folded in, and the range
+// check of the class ids (nn.Embedding raises for an id outside the table: here a sticky device flag the host reads when it next
+// synchronises).   grid (blocks over a row, B)
+__global__ void __launch_bounds__(256) flow_prepare_kernel(const float* src, const float* tgt, const long long* perm, const float* u, float one_minus_eps,
+                                                           float eps, float a3, float a2, float a1, float t_scale, const long long* ids, int n_classes,
+                                                           float* t_out, float* time_out, float* x, float* v, int* flag, int per) {
+    const int b = blockIdx.y;
+    const float t0 = __fadd_rn(__fmul_rn(u[b], one_minus_eps), eps);
+    const float t2 = __fmul_rn(t0, t0), t3 = __fmul_rn(t2, t0);
+    const float tt = __fadd_rn(__fadd_rn(__fmul_rn(a3, t3), __fmul_rn(a2, t2)), __fmul_rn(a1, t0));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        t_out[b] = tt;
+        time_out[b] = __fmul_rn(tt, t_scale);
+        if (ids && flag) { const long long id = ids[b]; if (id < 0 || id >= n_classes) *flag = 1; }
+    }
+    const float* s = src + (size_t)b * per;
+    const float* g = tgt + (size_t)(perm ? perm[b] : b) * per;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < per; i += gridDim.x * 256) {
+        const float sv = s[i], gv = g[i];
+        x[(size_t)b * per + i] = (1.0f - tt) * sv + tt * gv;
+        v[(size_t)b * per + i] = gv - sv;
+    }
+}
+int flow_prepare_launch(const float* src, const float* tgt, const int64_t* perm, const float* u, float t_eps, float warp_s, float t_scale,
+                        const int64_t* ids, int n_classes, float* t_out, float* time_out, float* x, float* v, int* flag, int B, int per, hipStream_t s) {
+    int gx = cdiv(per, 1024);
+    if (gx < 1) gx = 1;
+    if (gx > 64) gx = 64;
+    const double ws = warp_s;
+    hipLaunchKernelGGL(flow_prepare_kernel, dim3(gx, B), dim3(256), 0, s, src, tgt, reinterpret_cast<const long long*>(perm), u, (float)(1.0 - (double)t_eps),
+                       t_eps, (float)(4.0 * (1.0 - ws)), (float)(6.0 * (ws - 1.0)), (float)(3.0 - 2.0 * ws), t_scale,
+                       reinterpret_cast<const long long*>(ids), n_classes, t_out, time_out, x, v, flag, per);
     FC_HIP(hipGetLastError());
     return FC_OK;
 }

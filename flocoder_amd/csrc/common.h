@@ -346,6 +346,8 @@ int bilinear_bwd_launch(const float* gdst, float* gsrc /* += */, int B, int C, i
 int sumpool2_nhwc_launch(const float* src, float* dst, int B, int H, int W, int C, int accumulate, hipStream_t s);
 int depth_to_space_launch(const float* src, float* dst, int B, int H, int W, int C, int accumulate, hipStream_t s);
 int flow_interp_launch(const float* src, const float* tgt, const float* t, float* x, float* v, int B, int per, hipStream_t s);
+int flow_prepare_launch(const float* src, const float* tgt, const int64_t* perm, const float* u, float t_eps, float warp_s, float t_scale,
+                        const int64_t* ids, int n_classes, float* t_out, float* time_out, float* x, float* v, int* flag, int B, int per, hipStream_t s);
 int mse_loss_grad_launch(const float* v, const float* tgt, float* dv, float* loss, float* ws /*256*/, size_t n, hipStream_t s);
 int grad_clip_coef_launch(const float* g, size_t n0, const float* g2, size_t n1, float max_norm, float* out2 /*{norm, coef}*/, float* ws /*256*/,
                           hipStream_t s);

@@ -675,6 +675,16 @@ int fc_flow_interp(const float* source_dev, const float* target_dev, const float
     return flow_interp_launch(source_dev, target_dev, t_dev, x_out_dev, v_out_dev, batch, (int)per_sample, static_cast<hipStream_t>(stream));
 }
 
+int fc_flow_prepare(const float* source_dev, const float* target_dev, const int64_t* pairing_dev, const float* u_dev, float t_eps, float warp_s,
+                    float t_scale, const int64_t* class_ids_dev, int n_classes, float* t_out_dev, float* time_out_dev, float* x_out_dev,
+                    float* v_out_dev, int* id_flag_dev, int batch, int64_t per_sample, void* stream) {
+    if (!source_dev || !target_dev || !u_dev || !t_out_dev || !time_out_dev || !x_out_dev || !v_out_dev || batch < 1 || per_sample < 1)
+        return fail(FC_E_ARG, "fc_flow_prepare: null argument");
+    if (warp_s < 0.f || warp_s > 1.5f) return fail(FC_E_ARG, "fc_flow_prepare: warp parameter s out of bounds (sampling.py:27)");
+    return flow_prepare_launch(source_dev, target_dev, pairing_dev, u_dev, t_eps, warp_s, t_scale, class_ids_dev, n_classes, t_out_dev, time_out_dev,
+                               x_out_dev, v_out_dev, id_flag_dev, batch, (int)per_sample, static_cast<hipStream_t>(stream));
+}
+
 int fc_mse_loss_grad(const float* v_dev, const float* target_dev, float* dv_out_dev, float* loss_out_dev, float* ws256_dev, int64_t numel,
                      void* stream) {
     if (!v_dev || !target_dev || !loss_out_dev || !ws256_dev || numel < 1) return fail(FC_E_ARG, "fc_mse_loss_grad: null argument");

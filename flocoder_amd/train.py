@@ -130,6 +130,7 @@ class FlowTrainer:
         self._lo, self._hi = self._groups["class"]
         self.step_main, self.steps = 0, {k: 0 for k in self._groups}
         self._scal = torch.zeros(4, dtype=torch.float32, device=device)      # loss | grad norm | clip coefficient
+        self._id_flag = torch.zeros(1, dtype=torch.int32, device=device)     # set by the step prologue when a class id is out of range
         self._ws = torch.zeros(256, dtype=torch.float32, device=device)
         self.pg = process_group
         dist = torch.distributed
@@ -146,10 +147,31 @@ class FlowTrainer:
                                        B.current_stream(self.device)))
         return x, v
 
-    def loss_and_grads(self, x, t, cls, v_target, mask=None):
+    def prepare(self, source, target, u, cls=None, pairing=None):
+        """The step's prologue as ONE library call (``fc_flow_prepare``): t = warp_time(u (1 - t_eps) + t_eps), the U-Net's time input
+        t * t_scale, x = (1 - t) source + t target[pairing], v* = target[pairing] - source, and the range check of the class ids
+        into a sticky device flag (``check_class_ids`` reads it).  Returns (t, time, x, v*)."""
+        dev, bsz = self.device, target.shape[0]
+        t, time = torch.empty(bsz, device=dev), torch.empty(bsz, device=dev)
+        x, v = torch.empty_like(source), torch.empty_like(source)
+        ncls = self.model._cfg.n_classes if cls is not None else 0
+        B.check(B.lib().fc_flow_prepare(B.ptr(source), B.ptr(target), B.ptr(pairing), B.ptr(u), self.t_eps, 0.5, self.t_scale, B.ptr(cls), ncls,
+                                        B.ptr(t), B.ptr(time), B.ptr(x), B.ptr(v), self._id_flag.data_ptr() if cls is not None else None, bsz,
+                                        target[0].numel(), B.current_stream(dev)))
+        return t, time, x, v
+
+    def check_class_ids(self) -> None:
+        """Raise IndexError if any step so far was given a class id outside [0, n_classes) (nn.Embedding raises for those, unet.py:205;
+        the kernels treat such a row as unconditional).  One host sync: ``step`` calls it every 64 steps, the state-dict methods always."""
+        if int(self._id_flag.item()):
+            self._id_flag.zero_()
+            raise IndexError(f"class_cond ids must lie in [0, {self.model._cfg.n_classes}) (a training step since the last check was given others)")
+
+    def loss_and_grads(self, x, t, cls, v_target, mask=None, time=None):
         """forward -> loss -> backward; leaves the gradients in ``self.grads`` and returns (loss 0-d tensor, v_model)."""
         m, lib, st = self.model, B.lib(), B.current_stream(self.device)
-        time = (t * self.t_scale).contiguous()
+        if time is None:
+            time = (t * self.t_scale).contiguous()
         v = m._forward_native(x, time, cls, mask, train=True)
         dv = torch.empty_like(v)
         B.check(lib.fc_mse_loss_grad(B.ptr(v), B.ptr(v_target), B.ptr(dv), self._scal.data_ptr(), self._ws.data_ptr(), v.numel(), st))
@@ -221,7 +243,7 @@ class FlowTrainer:
         bsz = target.shape[0]
         if u is None:
             u = torch.rand(bsz, device=dev)
-        t = warp_time(u.to(dev, torch.float32) * (1 - self.t_eps) + self.t_eps).contiguous()
+        u = u.to(dev, torch.float32).contiguous()
         cls = cond.get('class_cond') if isinstance(cond, dict) else None
         mask = cond.get('mask_cond') if isinstance(cond, dict) else None
         if mask is not None and not self.model._cfg.mask_cond:
@@ -233,10 +255,13 @@ class FlowTrainer:
             cls = None
         if cls is not None:
             cls = cls.to(dev, torch.int64).contiguous()
-            self.model.check_class_ids(cls)
-        x, v_target = self.interpolate(source, target, t)
-        loss, _ = self.loss_and_grads(x, t, cls, v_target, mask)
+            if cls.shape != (bsz,):
+                raise ValueError("class_cond must have shape [batch]")
+        t, time, x, v_target = self.prepare(source, target, u, cls)
+        loss, _ = self.loss_and_grads(x, t, cls, v_target, mask, time=time)
         loss = loss.clone()
+        if cls is not None and (self.step_main & 63) == 0:
+            self.check_class_ids()                                   # every 64th step (and from the state-dict methods): one host sync
         fused = mask is not None and not bool(torch.allclose(mask, torch.ones_like(mask)))    # unet.py:301 (host sync, as upstream)
         present = self._agree({"class": cls is not None, "inject": mask is not None, "fusion": fused})
         if self.distributed:                                     # DDP semantics: average the gradients over ranks
@@ -361,6 +386,7 @@ class FlowTrainer:
         self.model.sync_flat()
 
     def state_dict(self):
+        self.check_class_ids()
         return {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "ema": self.ema.clone(),
                 "step_main": self.step_main, "steps": dict(self.steps)}
 

@@ -170,6 +170,14 @@ int fc_unet_class_param_range(const fc_unet* u, int64_t* lo, int64_t* hi);
 /* x = (1-t) source + t target ; v* = target - source   (train_flow.py:350-353), t per sample. */
 int fc_flow_interp(const float* source_dev, const float* target_dev, const float* t_dev, float* x_out_dev, float* v_out_dev, int batch,
                    int64_t per_sample, void* stream);
+/* The per-step prologue of train_flow.py:346-357 in one launch: t = warp_time(u (1 - t_eps) + t_eps, s = warp_s) (sampling.py:23-33,
+ * the same rounded operations torch runs), time = t * t_scale (the U-Net's time input), x / v* as fc_flow_interp with
+ * target row pairing[b] when pairing_dev != NULL (the OT pairing's gather, train_flow.py:350), and the range check of the class ids:
+ * *id_flag_dev is set to 1 (never cleared) when an id lies outside [0, n_classes) -- nn.Embedding's IndexError, reported when the
+ * host next reads the flag.  pairing_dev, class_ids_dev and id_flag_dev may be NULL. */
+int fc_flow_prepare(const float* source_dev, const float* target_dev, const int64_t* pairing_dev, const float* u_dev, float t_eps, float warp_s,
+                    float t_scale, const int64_t* class_ids_dev, int n_classes, float* t_out_dev, float* time_out_dev, float* x_out_dev,
+                    float* v_out_dev, int* id_flag_dev, int batch, int64_t per_sample, void* stream);
 /* loss = mean((v - v*)^2) (train_flow.py:359) and, when dv_out_dev != NULL, its gradient 2 (v - v*) / numel.  ws: 256 floats. */
 int fc_mse_loss_grad(const float* v_dev, const float* target_dev, float* dv_out_dev, float* loss_out_dev, float* ws256_dev, int64_t numel,
                      void* stream);

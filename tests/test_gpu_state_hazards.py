@@ -199,3 +199,29 @@ def test_ot_pairing_stays_a_permutation_with_non_finite_rows():
         if torch.isfinite(d[i]).all():
             assert j == int(torch.argmin(row)), i
         used[j] = True
+
+
+def test_step_prologue_matches_torch_and_flags_bad_class_ids():
+    """fc_flow_prepare = the torch prologue of train_flow.py:346-357 (warp_time with torch's own rounding, interpolation, pairing
+    gather); out-of-range class ids surface as IndexError at the trainer's next check."""
+    from flocoder_amd.sampling import warp_time
+    from flocoder_amd.train import FlowTrainer
+    m = _model(5, n_classes=10).train()
+    tr = FlowTrainer(m)
+    g = torch.Generator().manual_seed(3)
+    src, tgt = torch.randn(6, 4, 16, 16, generator=g).to(DEV), torch.randn(6, 4, 16, 16, generator=g).to(DEV)
+    u = torch.rand(6, generator=g).to(DEV)
+    perm = torch.randperm(6, generator=g).to(DEV)
+    t, time, x, v = tr.prepare(src, tgt, u, None, perm)
+    t_ref = warp_time(u * (1 - tr.t_eps) + tr.t_eps)
+    assert torch.equal(t, t_ref) and torch.equal(time, t_ref * tr.t_scale)
+    x_ref, v_ref = tr.interpolate(src, tgt[perm].contiguous(), t_ref)
+    assert torch.equal(x, x_ref) and torch.equal(v, v_ref)
+    t2, _, x2, _ = tr.prepare(src, tgt, u)                       # no pairing
+    assert torch.equal(t2, t_ref) and torch.equal(x2, tr.interpolate(src, tgt, t_ref)[0])
+    tr.step(src, tgt, {"class_cond": torch.tensor([0, 1, 2, 3, 4, 9], device=DEV)})
+    tr.check_class_ids()                                          # in range: nothing raised
+    with pytest.raises(IndexError):
+        tr.step(src, tgt, {"class_cond": torch.tensor([0, 1, 2, 3, 4, 10], device=DEV)})
+        tr.check_class_ids()
+    tr.check_class_ids()                                          # the flag was cleared by the raise
