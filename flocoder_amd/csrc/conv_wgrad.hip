@@ -26,6 +26,9 @@ __device__ __forceinline__ void wgrad_body(const WgradDev& p, const int split, c
     const WgradArgs& a = p.a;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int cic = cicoc % p.nci, coc = cicoc / p.nci;
+    // which wave takes which taps rotates with the workgroup: 9 taps over 4 waves leaves one wave with three, and wave w of every
+    // resident workgroup shares SIMD w -- unrotated, SIMD 0 carried 4/3 of the average matrix work of the whole chip
+    const int tapw = (wave + split + cicoc) & 3;
     const int ci0 = cic * 32, co0 = coc * 32;
     const int TW = 1 << p.TWl, TH = 1 << p.THl, BM = p.BM;
     const int Hin = a.ups ? 2 * a.Hs : a.Hs, Win = a.ups ? 2 * a.Ws : a.Ws;
@@ -86,7 +89,7 @@ __device__ __forceinline__ void wgrad_body(const WgradDev& p, const int split, c
             int tapoff[TPW];
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
-                const int tap = wave + 4 * t;
+                const int tap = tapw + 4 * t;
                 tapoff[t] = tap < KK ? ((tap / KS) * p.PW + (tap % KS)) * CS + l31 : -1;
             }
             for (int j0 = 0; j0 < BM / 2; j0 += 4) {
@@ -135,7 +138,7 @@ __device__ __forceinline__ void wgrad_body(const WgradDev& p, const int split, c
     if (co < a.Cout) {
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
-            const int tap = KS == 1 ? 0 : wave + 4 * t;
+            const int tap = KS == 1 ? 0 : tapw + 4 * t;
             if (tap < KK && (KS != 1 || wave == 0)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {

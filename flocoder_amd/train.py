@@ -235,8 +235,9 @@ class FlowTrainer:
         return {k: bool(v) for k, v in zip(keys, flags.tolist())}
 
     # ---- the step -------------------------------------------------------------------------------------------------
-    def step(self, source, target, cond=None, u: Optional[torch.Tensor] = None):
-        """train_flow.py:346-397 for one batch: returns the loss as a 0-d device tensor (no host sync)."""
+    def step(self, source, target, cond=None, u: Optional[torch.Tensor] = None, pairing: Optional[torch.Tensor] = None):
+        """train_flow.py:346-397 for one batch: returns the loss as a 0-d device tensor (no host sync).  ``pairing`` (int64 [B], e.g.
+        from ``compute_ot_pairing``) trains against ``target[pairing]`` without materialising the gather (train_flow.py:350)."""
         dev = self.device
         source = source.to(dev, torch.float32).contiguous()
         target = target.to(dev, torch.float32).contiguous()
@@ -257,7 +258,9 @@ class FlowTrainer:
             cls = cls.to(dev, torch.int64).contiguous()
             if cls.shape != (bsz,):
                 raise ValueError("class_cond must have shape [batch]")
-        t, time, x, v_target = self.prepare(source, target, u, cls)
+        if pairing is not None:
+            pairing = pairing.to(dev, torch.int64).contiguous()
+        t, time, x, v_target = self.prepare(source, target, u, cls, pairing)
         loss, _ = self.loss_and_grads(x, t, cls, v_target, mask, time=time)
         loss = loss.clone()
         if cls is not None and (self.step_main & 63) == 0:

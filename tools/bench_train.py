@@ -49,8 +49,7 @@ def main():
 
     def step():
         source = torch.randn_like(target)
-        tgt = target if args.no_ot else target[compute_ot_pairing(source, target)]
-        return tr.step(source, tgt, {"class_cond": cls, "mask_cond": None})
+        return tr.step(source, target, {"class_cond": cls, "mask_cond": None}, pairing=None if args.no_ot else compute_ot_pairing(source, target))
 
     def barrier():
         if world > 1:
