@@ -253,6 +253,39 @@ def two_in_flight(model, noise, ids, device, steps=6):
             "tflops": round(BATCH * steps * N_EULER * model.flops_per_sample / t / 1e12, 2)}
 
 
+def train_step_secondary(device, dim, hw, batch, classes, steps=40, warmup=5):
+    """BASELINE.json configs[3] on this rank alone: one train_flow.py step (OT pairing + prologue + U-Net forward / backward + clip +
+    Adam + EMA) on synthetic latents, timed like tools/bench_train.py."""
+    from flocoder_amd.ot import compute_ot_pairing
+    from flocoder_amd.train import FlowTrainer
+    from flocoder_amd.unet import Unet
+    torch.manual_seed(0)
+    net = Unet(dim=dim, dim_mults=(1, 2, 4, 8), channels=4, n_classes=classes).to(device)
+    tr = FlowTrainer(net, lr=1e-4, distributed=False)
+    g = torch.Generator().manual_seed(99)
+    target = torch.randn(batch, 4, hw, hw, generator=g).to(device)
+    cls = torch.randint(classes, (batch,), generator=g).to(device)
+
+    def one():
+        source = torch.randn_like(target)
+        return tr.step(source, target, {"class_cond": cls, "mask_cond": None}, pairing=compute_ot_pairing(source, target))
+
+    for _ in range(warmup):
+        loss = one()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = one()
+    torch.cuda.synchronize(device)
+    t = (time.perf_counter() - t0) / steps
+    assert torch.isfinite(loss)
+    out = {"workload": f"train_flow step: batch {batch}, latents 4x{hw}x{hw}, U-Net dim={dim} dim_mults [1,2,4,8] n_classes={classes}, greedy OT pairing, "
+                       f"Adam lr 1e-4, EMA 0.999; {steps} steps timed on one GPU",
+           "ms_per_step": round(1e3 * t, 3), "samples_per_s": round(batch / t, 1), "step_tflops_3x_fwd": round(3 * net.flops_per_sample * batch / t / 1e12, 2)}
+    del tr, net
+    return out
+
+
 def secondary(model, noise, ids, device):
     from flocoder_amd.codecs import SD_VAE_Wrapper
     from flocoder_amd.sampling import decode_latents, euler_sampler
@@ -288,6 +321,8 @@ def secondary(model, noise, ids, device):
     out["euler64_plus_decode"] = {"workload": "64-step Euler + SD-VAE decode (decoded images/s, SURVEY 8d secondary metric)",
                                   "images_per_s": round(BATCH / (t_ode + t_dec), 1), "ode_ms": round(t_ode * 1e3, 1), "decode_ms": round(t_dec * 1e3, 1)}
     del vae
+    out["train_step_stl_sd"] = train_step_secondary(device, dim=16, hw=16, batch=32, classes=10)
+    out["train_step_flowers_sized"] = train_step_secondary(device, dim=32, hw=32, batch=64, classes=102)
     return out
 
 

@@ -26,7 +26,11 @@ for s in $STEPS; do
     mfma)      (cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_mfma -- python3 $GRAFT_REPO_ROOT/tools/pmc_forward.py 3 > $GRAFT_REPO_ROOT/$OUT/pmc_mfma.log 2>&1) || { tail -20 $OUT/pmc_mfma.log; exit 1; }
                python tools/pmc_mfma_summary.py $(find $OUT/pmc_mfma -name '*counter_collection.csv') > $OUT/pmc_mfma.json; head -30 $OUT/pmc_mfma.json ;;
     trainprof) (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/trainprof -- python3 $GRAFT_REPO_ROOT/tools/bench_train.py --steps 25 --warmup 5 > $GRAFT_REPO_ROOT/$OUT/trainprof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/trainprof.err) || { tail -20 $OUT/trainprof.err; exit 1; }
-               find $OUT/trainprof -name '*kernel_stats.csv' -exec cp {} $OUT/train_kernel_stats.csv \; ; head -30 $OUT/train_kernel_stats.csv | cut -c1-150 ;;
+               find $OUT/trainprof -name '*kernel_stats.csv' -exec cp {} $OUT/train_kernel_stats.csv \; ; python tools/train_profile_summary.py $OUT/trainprof 40 > $OUT/train_step_summary.txt; head -12 $OUT/train_step_summary.txt ;;
+    trainprof32) (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/trainprof32 -- python3 $GRAFT_REPO_ROOT/tools/bench_train.py --steps 25 --warmup 5 --dim 32 --hw 32 --batch 64 --classes 102 > $GRAFT_REPO_ROOT/$OUT/trainprof32_bench.json 2> $GRAFT_REPO_ROOT/$OUT/trainprof32.err) || { tail -20 $OUT/trainprof32.err; exit 1; }
+               find $OUT/trainprof32 -name '*kernel_stats.csv' -exec cp {} $OUT/train32_kernel_stats.csv \; ; python tools/train_profile_summary.py $OUT/trainprof32 40 > $OUT/train32_step_summary.txt; head -12 $OUT/train32_step_summary.txt ;;
+    train32)   timeout -k 10 300 python tools/bench_train.py --dim 32 --hw 32 --batch 64 --classes 102 > $OUT/train32_bench.json 2> $OUT/train32.err || { tail -20 $OUT/train32.err; exit 1; }; cat $OUT/train32_bench.json ;;
+    phases)    timeout -k 10 300 python tools/train_phases.py > $OUT/train_phases.txt 2>&1 && timeout -k 10 300 python tools/train_phases.py --dim 32 --hw 32 --batch 64 --classes 102 >> $OUT/train_phases.txt 2>&1; grep -v amdgpu.ids $OUT/train_phases.txt ;;
     train)     timeout -k 10 300 python tools/bench_train.py > $OUT/train_bench.json 2> $OUT/train.err || { tail -20 $OUT/train.err; exit 1; }; cat $OUT/train_bench.json ;;
     *)         echo "unknown step $s"; exit 2 ;;
   esac

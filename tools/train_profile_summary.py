@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Per-step kernel breakdown of a `rocprofv3 --kernel-trace` run of tools/bench_train.py: the last ten steps (delimited by the OT distance
+kernel that opens each step), time per kernel name per step, launches per step and the step span on the device.
+
+    python tools/train_profile_summary.py <rocprof output dir> [rows]"""
 import csv,re,glob,collections,sys
 f=glob.glob(sys.argv[1]+"/*/*_kernel_trace.csv")[0]
 rows=list(csv.DictReader(open(f)))
