@@ -59,9 +59,10 @@ def synthetic_inputs(rank, world, device, per_rank=BATCH):
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
     tools/pmc_forward.py, summarised by tools/pmc_summary.py with the guide's gfx950 correction).  A process cannot collect
-    hardware counters on itself, so the figure comes from the newest profiles/*pmc_traffic.json; null when there is none."""
+    hardware counters on itself, so the figure comes from the latest profiles/*pmc_traffic.json (the files are named per round and build, so the
+    last one by name; a checkout does not preserve modification times); null when there is none."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), key=os.path.basename)
     if not files:
         return None, None
     try:
