@@ -417,7 +417,11 @@ def main():
                                "dim_mults [1,2,4,8] n_classes=102, class-conditional, no CFG, ODE loop only (no VAE decode)",
                    "global_batch": BATCH * world, "nfe_per_sample": N_EULER, "parallelism": f"sample-shard x{world}, weights broadcast once",
                    "gflop_per_sample": round(model.flops_per_sample * N_EULER / 1e9, 3),
-                   "launches_per_forward": model.launches_per_forward},
+                   # plan entries of one forward; the nine attention entries are two kernels each, and inside the integrator the two
+                   # conditioning entries are replaced by a table computed once per call
+                   "plan_entries_per_forward": model.launches_per_forward,
+                   "kernel_launches_per_forward": model.launches_per_forward + 9,
+                   "kernel_launches_per_euler_step": model.launches_per_forward + 9 - 2},
     }
     line["ode_tflops"] = round(line["value"] * model.flops_per_sample * N_EULER / 1e12, 3)
     line["frac_of_fp32_mfma_peak_end_to_end"] = round(line["ode_tflops"] / (PEAK_FP32_MFMA_TFLOPS * world), 4)
