@@ -294,6 +294,7 @@ struct WgradDev {            // a launch's geometry as the device sees it (conv_
     int o_ys, o_pix;          // LDS offsets (floats)
     size_t part_stride;       // floats per split in the workspace
     int64_t dw_off = 0, db_off = -1;   // table-driven launches: where dw / db live in the caller's flat gradient vector
+    int direct1 = 0;                   // 1x1, stride 1: operands straight from global memory in MFMA layout (no LDS staging)
 };
 int conv_wgrad_init();
 size_t conv_wgrad_workspace(const WgradArgs& a);

@@ -156,8 +156,76 @@ __device__ __forceinline__ void wgrad_body(const WgradDev& p, const int split, c
     }
 }
 
+// 1x1, stride 1: dW[co][ci] = sum over pixels of X[pix][ci] dY[pix][co] needs no window -- a k-step is two pixels, and a lane's MFMA
+// operands are X[pix][ci0 + lane & 31] and dY[pix][co0 + lane & 31] for pix = 2j + (lane >> 5): two coalesced 128-byte rows per
+// operand straight from global memory, eight k-steps in flight per wave.  The LDS-staged form above spent its time staging 128-pixel
+// tiles for 16 MFMAs per wave (0.41 ms of the flowers-sized training step in one table launch).
+__device__ __forceinline__ void wgrad1x1_body(const WgradDev& p, const int split, const int cicoc, float* dw, float* db) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const WgradArgs& a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int cic = cicoc % p.nci, coc = cicoc / p.nci;
+    const int ci = cic * 32 + l31, co = coc * 32 + l31;
+    const long NP = (long)a.B * a.H * a.W;
+    const bool ciok = ci < a.Cin, cook = co < a.Cout, first = ci < a.C0;
+    const float* xb = !ciok ? nullptr : (first ? a.x0 + ci : a.x1 + (ci - a.C0));
+    const long xs = first ? a.C0 : a.C1;
+    const float* yb = cook ? a.dy + co : nullptr;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bsum = 0.f;
+    const int BM = p.BM;
+    constexpr int UB = 8;
+    for (int tile = split; tile < p.mtiles; tile += p.nsplit) {
+        const long p0 = (long)tile * BM;
+        for (int j0 = wave; j0 < BM / 2; j0 += 4 * UB) {
+            float xv[UB], yv[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const long pix = p0 + 2 * (j0 + 4 * u) + half;
+                const bool in = (j0 + 4 * u) < BM / 2 && pix < NP;
+                xv[u] = (in && ciok) ? xb[pix * xs] : 0.f;
+                yv[u] = (in && cook) ? yb[pix * a.Cout] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                if (j0 + 4 * u >= BM / 2) break;           // wave-uniform
+                bsum += yv[u];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[u], yv[u], acc, 0, 0, 0);
+            }
+        }
+    }
+    float* red = smem;                                      // 3 x 16 x 64 floats, then 4 x 32 for the bias
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+    }
+    bsum += __shfl_xor(bsum, 32);
+    if (half == 0) red[3 * 16 * 64 + wave * 32 + l31] = bsum;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = ((acc[r] + red[r * 64 + lane]) + red[(16 + r) * 64 + lane]) + red[(32 + r) * 64 + lane];
+        float* dst = p.nsplit > 1 ? a.ws + (size_t)split * p.part_stride : dw;
+        if (cook) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = cic * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (c < a.Cin) dst[p.nsplit > 1 ? (size_t)c * a.Cout + co : (size_t)co * a.Cin + c] = acc[r];
+            }
+        }
+        if (db && cic == 0 && half == 0 && cook) {
+            const float* br = red + 3 * 16 * 64;
+            float* bd = p.nsplit > 1 ? a.ws + (size_t)split * p.part_stride + (size_t)a.Cout * a.Cin : db;
+            bd[co] = (br[l31] + br[32 + l31]) + (br[64 + l31] + br[96 + l31]);
+        }
+    }
+}
+
 template <int KS>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradDev p) {
+    if (KS == 1 && p.direct1) { wgrad1x1_body(p, blockIdx.x, blockIdx.y, p.a.dw, p.a.db); return; }
     wgrad_body<KS>(p, blockIdx.x, blockIdx.y, p.a.dw, p.a.db);
 }
 
@@ -168,6 +236,7 @@ template <int KS>
 __global__ void __launch_bounds__(256) conv_wgrad_table_kernel(const WgradDev* __restrict__ jobs, const int2* __restrict__ blocks, float* grads) {
     const int2 bj = blocks[blockIdx.x];
     const WgradDev p = jobs[bj.x];
+    if (KS == 1 && p.direct1) { wgrad1x1_body(p, bj.y % p.nsplit, bj.y / p.nsplit, grads + p.dw_off, p.db_off >= 0 ? grads + p.db_off : nullptr); return; }
     wgrad_body<KS>(p, bj.y % p.nsplit, bj.y / p.nsplit, grads + p.dw_off, p.db_off >= 0 ? grads + p.db_off : nullptr);
 }
 
@@ -256,6 +325,8 @@ static int wgrad_geometry(const WgradArgs& a, WgradDev* d) {
     }
     p.nsplit = ns < 1 ? 1 : ns;
     const int xs_floats = p.P * CS > 3 * 1024 ? p.P * CS : 3 * 1024;
+    static const bool no_direct = std::getenv("FLOCODER_AMD_WGRAD_1X1_STAGED") != nullptr;
+    p.direct1 = (!no_direct && a.KS == 1 && a.stride == 1 && !a.ups && a.pad == 0 && a.Hs == a.H && a.Ws == a.W) ? 1 : 0;
     p.o_ys = (xs_floats + 3) & ~3;
     p.o_pix = (p.o_ys + p.BM * CS + 3) & ~3;
     return FC_OK;

@@ -225,3 +225,23 @@ def test_step_prologue_matches_torch_and_flags_bad_class_ids():
         tr.step(src, tgt, {"class_cond": torch.tensor([0, 1, 2, 3, 4, 10], device=DEV)})
         tr.check_class_ids()
     tr.check_class_ids()                                          # the flag was cleared by the raise
+
+
+def test_step_with_pairing_equals_step_on_gathered_targets():
+    """FlowTrainer.step(pairing=perm) trains against target[perm] without materialising it: same loss, same parameters."""
+    from flocoder_amd.train import FlowTrainer
+    g = torch.Generator().manual_seed(11)
+    src, tgt = torch.randn(6, 4, 16, 16, generator=g).to(DEV), torch.randn(6, 4, 16, 16, generator=g).to(DEV)
+    u = torch.rand(6, generator=g).to(DEV)
+    perm = torch.randperm(6, generator=g).to(DEV)
+    ids = torch.tensor([0, 1, 2, 3, 4, 9], device=DEV)
+    out = []
+    for use_pairing in (True, False):
+        m = _model(5, n_classes=10).train()
+        tr = FlowTrainer(m)
+        if use_pairing:
+            loss = tr.step(src, tgt, {"class_cond": ids}, u=u, pairing=perm)
+        else:
+            loss = tr.step(src, tgt[perm].contiguous(), {"class_cond": ids}, u=u)
+        out.append((float(loss), tr.params.clone()))
+    assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1])
