@@ -245,3 +245,24 @@ def test_step_with_pairing_equals_step_on_gathered_targets():
             loss = tr.step(src, tgt[perm].contiguous(), {"class_cond": ids}, u=u)
         out.append((float(loss), tr.params.clone()))
     assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1])
+
+
+def test_backward_of_a_batch_smaller_than_the_plan_matches_a_plan_of_that_size():
+    """A plan reserved for B rows serves smaller batches (the last batch of an epoch): the backward then launches every weight
+    gradient on its own instead of through the table launches of the full-batch path.  Same gradients either way."""
+    from flocoder_amd.train import FlowTrainer
+    g = torch.Generator().manual_seed(21)
+    src, tgt = torch.randn(6, 4, 16, 16, generator=g).to(DEV), torch.randn(6, 4, 16, 16, generator=g).to(DEV)
+    t = (torch.rand(6, generator=g) * 0.9 + 0.05).to(DEV)
+    ids = torch.randint(0, 10, (6,), generator=g).to(DEV)
+    big = FlowTrainer(_model(7, n_classes=10).train())
+    x6, v6 = big.interpolate(src, tgt, t)
+    big.loss_and_grads(x6, t, ids, v6)                                   # plan (and backward plan) for 6 rows
+    x4, v4 = big.interpolate(src[:4].contiguous(), tgt[:4].contiguous(), t[:4].contiguous())
+    loss_a, _ = big.loss_and_grads(x4, t[:4].contiguous(), ids[:4].contiguous(), v4)
+    ga = big.grads.clone()
+    small = FlowTrainer(_model(7, n_classes=10).train())                 # same weights, plan for 4 rows: the table path
+    loss_b, _ = small.loss_and_grads(x4, t[:4].contiguous(), ids[:4].contiguous(), v4)
+    gb = small.grads
+    assert abs(float(loss_a) - float(loss_b)) <= 1e-6 * abs(float(loss_b))
+    assert float((ga - gb).norm() / gb.norm()) < 2e-6
