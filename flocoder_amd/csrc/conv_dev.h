@@ -35,7 +35,11 @@ struct ConvDev {
 __device__ __forceinline__ void conv_stamp(const ConvDev& p, int slot) {
     if (p.stamps) {
         const unsigned long long t = __builtin_amdgcn_s_memtime();
-        if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 8) p.stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + slot] = t;
+        if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 8) {
+            p.stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + slot] = t;
+            // slot 15: the device-wide 100 MHz clock at the wave's first stamp (the shader clock is not comparable between workgroups)
+            if (slot == 0) p.stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + 15] = __builtin_amdgcn_s_memrealtime();
+        }
     }
 }
 

@@ -36,3 +36,10 @@ for name, c0, c1, co, H, ks, pad, stride, ups, G in LAYERS:
     print(f"   consumers: stats barrier + emit {int((st[:, 0:4, 14] - st[:, 0:4, 7]).median())} cycles, output stores {int((st[:, 0:4, 8] - st[:, 0:4, 14]).median())}")
     span = (st[:, :, 8].max(dim=1).values - st[:, :, 0].min(dim=1).values)
     print(f"   workgroup lifetime: median {int(span.median())} cycles, max {int(span.max())}")
+    # the launch as a whole on the device-wide 100 MHz clock (slot 15 = that clock at each wave's start): when workgroups start relative
+    # to the first one, and first start -> last end taking each workgroup's own lifetime at 2.4 GHz
+    rt = st[:, :, 15].min(dim=1).values * 10.0                       # ns
+    t0 = rt.min()
+    ends = rt + span / 2.4
+    print(f"   launch: workgroup starts spread over {float(rt.max() - t0) / 1e3:.2f} us (90 % started after {float((rt - t0).quantile(0.9)) / 1e3:.2f} us); "
+          f"first start -> last end {float(ends.max() - t0) / 1e3:.2f} us; median workgroup lifetime {float(span.median()) / 2.4e3:.2f} us")
