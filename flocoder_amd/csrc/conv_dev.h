@@ -95,7 +95,12 @@ __device__ __forceinline__ void conv_params_from_lanes(ConvDev& p) {
 }
 
 // Shared epilogue: K-split reduction through LDS, + bias, GroupNorm partials, optional SiLU / residual, stores.
-template <int WM, int WN, int WK, int MT, int NT>
+// FL: what this instantiation can do, as a bit mask -- 1 fused Block tail, 2 fused res_conv output, 4 statistics of the final value.
+// A launch goes to the smallest flavour that covers it (conv_pipe.hip).  Not a matter of taste: a path that is compiled in but never
+// taken still costs -- the taken path then jumps over it, every jump lands on a cold instruction-cache line (the cache is invalidated
+// at every launch), and a launch is short.  Measured: with the tail code merely compiled OUT the un-fused sampler ran 2.9 % faster.
+constexpr int FL_FIN = 1, FL_RES = 2, FL_POST = 4, FL_ALL = 7;
+template <int WM, int WN, int WK, int MT, int NT, int FL = FL_ALL>
 __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT][NT], f32x16 (&accr)[MT][NT], float* smem, int tid, int lane,
                                               int wave, int b0, int y0, int x0, int n0, int tx, int ty, bool active = true,
                                               int nthr = 256, const float* pre = nullptr) {
@@ -108,7 +113,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
     const int half = lane >> 5, l31 = lane & 31;
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
     const int TW = 1 << p.TWl, TH = 1 << p.THl, Cout = a.Cout;
-    const bool has_res = a.res_out != nullptr;
+    const bool has_res = (FL & FL_RES) && a.res_out != nullptr;
+    const bool stats_post = (FL & FL_POST) && a.stats_post;
     if (WK > 1) {  // meet the K-split partials in LDS (patch/wl are dead now)
         __syncthreads();
         float* red = smem + p.o_red;
@@ -159,7 +165,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
     };
     conv_stamp(p, 6);
     const bool owner = active && (wk == 0);
-    const bool fin = a.fin.gamma != nullptr;
+    const bool fin = (FL & FL_FIN) && a.fin.gamma != nullptr;
     // this launch's epoch of the fused tail (drawn from the sample group's arrival counter at kernel start, parked in LDS)
     const unsigned epoch = (fin && !p.fin_local) ? __float_as_uint(smem[p.o_epoch]) : 0u;
     float* partS = smem + p.o_part;               // [BM/16][BN]
@@ -299,7 +305,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                 const float bias = pre ? pre[nt] : ((a.bias && nok) ? a.bias[n] : 0.f);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mt][nt][r] += bias;
-                if (a.stats_post) {   // statistics of the FINAL value (activation and residual included): pre-norm resnets (SD-VAE)
+                if (stats_post) {   // statistics of the FINAL value (activation and residual included): pre-norm resnets (SD-VAE)
                     // all sixteen residual values requested before the first is used (row by row it was sixteen dependent round trips)
                     float ad[16];
                     const bool addp = a.add && nok;
@@ -443,7 +449,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
     // instructions of two 128-byte segments each -- store-ISSUE bound (3.9 k cycles of a 32x32 layer).  Through an LDS image
     // [row][BN + 4] every thread of the workgroup (the staging waves too) then writes whole 16-byte channel quads: a quarter of the
     // store instructions, each 1 KiB contiguous when Cout == BN.
-    const bool post = !a.stats_post && !fin;                // activation / residual still to apply (else already in the accumulators)
+    const bool post = !stats_post && !fin;                // activation / residual still to apply (else already in the accumulators)
     const bool act = post && a.out_act;
     const float* addp = post ? a.add : nullptr;
     if (owner) {
@@ -501,7 +507,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                         }
                     }
             }
+            if (active && !pass) conv_stamp(p, 9);
             lds_only_barrier();
+            if (active && !pass) conv_stamp(p, 10);
             float* gout = pass ? a.res_out : a.out;
             for (int i = tid; i < BM * Q4; i += nthr) {
                 const int m = i / Q4, c4 = (i - m * Q4) * 4, n = n0 + c4;

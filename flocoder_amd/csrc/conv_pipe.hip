@@ -16,6 +16,8 @@
 // VALU/VMEM work of staging overlap inside a workgroup instead of relying on a lucky phase shift between workgroups.
 // A loader thread's patch elements are the same pixels for every chunk (only the channel base moves): their source
 // offsets live in registers and the per-(sample, channel) affine table is built once for all Cin.
+#include <cstdlib>
+#include <string>
 #include "conv_dev.h"
 #include "stats_dev.h"
 
@@ -75,7 +77,7 @@ __device__ __forceinline__ void loader_handover() {   // LDS stores of this wave
 // NL = loader waves (4 or 8).  The small-M tiles stream a whole weight slab per 32 or 64 output rows: with four loader waves the
 // slab's LDS-DMA issue (~190 cycles per 1 KB piece per wave) took 1.65x the consumers' MFMA time per chunk and the consumers sat
 // at the chunk barrier half of the time (profiles/r01_c_stamps.txt); eight loader waves halve the issue time per wave.
-template <int WM, int WN, int WK, int MT, int NT, int CC, int NPL, int KS, int NL>
+template <int WM, int WN, int WK, int MT, int NT, int CC, int NPL, int KS, int NL, int FL = FL_ALL>
 __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev p_kernarg) {
     ConvDev p;
     conv_params_from_lanes(p);       // p_kernarg itself is never touched: see conv_dev.h
@@ -111,12 +113,12 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
     const int b0 = bg * p.TB, y0 = ty * TH, x0 = tx * TW, n0 = nt_i * BN;
     const int PW = p.PW, PHW = p.PH * p.PW;
     const int C0 = a.s0.C, C1 = a.s1.C, Cin = a.Cin, Cout = a.Cout;
-    const bool has_res = a.res_out != nullptr;
+    const bool has_res = (FL & FL_RES) && a.res_out != nullptr;
     const int nchunks = p.nchunks;
     conv_stamp(p, 0);
     // Fused tail across workgroups: draw this launch's epoch from the sample group's arrival counter NOW -- the round trip hides behind
     // the whole main loop; every workgroup of the group gets the same quotient because launches of one op never overlap.
-    const bool meet = a.fin.gamma != nullptr && !p.fin_local;
+    const bool meet = (FL & FL_FIN) && a.fin.gamma != nullptr && !p.fin_local;
     // Inline asm on purpose: through the builtin, hipcc's atomic optimizer waits for the returned value on the spot (a cold round trip
     // in front of everything else); here the wait sits where the value is used, after the GroupNorm tables.
     unsigned arrival = 0;
@@ -449,7 +451,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
         if (p.stamps && lane == 0) p.stamps[((size_t)blockIdx.x * 8 + wave8) * 16 + 11] = dbg_cbar;
         conv_stamp(p, 5);
     }
-    conv_epilogue<WM, WN, WK, MT, NT>(p, acc, accr, smem, tid, lane, wave, b0, y0, x0, n0, tx, ty, consumer, NTHR, pre);
+    conv_epilogue<WM, WN, WK, MT, NT, FL>(p, acc, accr, smem, tid, lane, wave, b0, y0, x0, n0, tx, ty, consumer, NTHR, pre);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -474,6 +476,36 @@ static int pipe_attr_ks() {
     return FC_OK;
 }
 
+// Lean flavours (conv_dev.h FL_*) of the tiles the U-Net runs on: 3x3 as plain / + fused res_conv / + fused tail, 1x1 and 2x2 plain.
+// Everything else goes to the FL_ALL instantiation above.
+#define FC_LEAN_TILES(X, KS)               \
+    X(TILE_M128N32, 4, 1, 1, 1, 1, 16, KS, 4)  \
+    X(TILE_M64N32K2, 2, 1, 2, 1, 1, 32, KS, (KS == 1 ? 4 : 8)) \
+    X(TILE_M32N32K4, 1, 1, 4, 1, 1, 32, KS, (KS == 1 ? 4 : 8))
+
+template <int KS, int FL>
+static int lean_attr() {
+#define X(T, WM, WN, WK, MT, NT, CC, K, NL)                                                                               \
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pipe_kernel<WM, WN, WK, MT, NT, CC, 8, K, NL, FL>),    \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FC_LEAN_TILES(X, KS)
+#undef X
+    return FC_OK;
+}
+
+template <int KS, int FL>
+static int lean_launch(const ConvDev& d, int tile, int grid, size_t lds, hipStream_t s) {
+    switch (tile) {
+#define X(T, WM, WN, WK, MT, NT, CC, K, NL) \
+    case T: hipLaunchKernelGGL((conv_pipe_kernel<WM, WN, WK, MT, NT, CC, 8, K, NL, FL>), dim3(grid), dim3(256 + 64 * NL), lds, s, d); break;
+        FC_LEAN_TILES(X, KS)
+#undef X
+        default: return -1;      // no lean flavour of this tile
+    }
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+
 int conv_pipe_init() {
     static bool done = false;
     if (done) return FC_OK;
@@ -483,6 +515,8 @@ int conv_pipe_init() {
     FC_TRY(pipe_attr_ks<2>());
     FC_TRY(pipe_attr_ks<3>());
     FC_TRY(pipe_attr_ks<5>());
+    FC_TRY((lean_attr<3, 0>())); FC_TRY((lean_attr<3, FL_RES>())); FC_TRY((lean_attr<3, FL_FIN>()));
+    FC_TRY((lean_attr<1, 0>())); FC_TRY((lean_attr<2, 0>()));
     done = true;
     return FC_OK;
 }
@@ -503,6 +537,17 @@ static int pipe_launch_ks(const ConvDev& d, int tile, int grid, size_t lds, hipS
 }
 
 int conv_pipe_launch(const ConvDev& d, int tile, int grid, size_t lds, hipStream_t s) {
+    static const bool lean = [] { const char* e = std::getenv("FLOCODER_AMD_LEAN_KERNELS"); return !(e && std::string(e) == "0"); }();
+    if (lean) {                  // the smallest flavour that covers this launch
+        const int need = (d.a.fin.gamma ? FL_FIN : 0) | (d.a.res_out ? FL_RES : 0) | (d.a.stats_post ? FL_POST : 0);
+        int r = -1;
+        if (d.a.KS == 3 && need == 0) r = lean_launch<3, 0>(d, tile, grid, lds, s);
+        else if (d.a.KS == 3 && need == FL_RES) r = lean_launch<3, FL_RES>(d, tile, grid, lds, s);
+        else if (d.a.KS == 3 && need == FL_FIN) r = lean_launch<3, FL_FIN>(d, tile, grid, lds, s);
+        else if (d.a.KS == 1 && need == 0) r = lean_launch<1, 0>(d, tile, grid, lds, s);
+        else if (d.a.KS == 2 && need == 0) r = lean_launch<2, 0>(d, tile, grid, lds, s);
+        if (r != -1) return r;
+    }
     switch (d.a.KS) {
         case 1: return pipe_launch_ks<1>(d, tile, grid, lds, s);
         case 2: return pipe_launch_ks<2>(d, tile, grid, lds, s);

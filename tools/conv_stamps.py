@@ -33,7 +33,9 @@ for name, c0, c1, co, H, ks, pad, stride, ups, G in LAYERS:
         print(f"   {role:8s} median timeline (cycles since wave start): " + ", ".join(f"{n}={int(v)}" for n, v in zip(NAMES, med.tolist())))
     print(f"   consumer cycles at chunk barriers (sum): {int(st[:, 0:4, 11].median())};  loader: vmcnt-wait {int(st[:, 4:8, 9].median())}, "
           f"LDS stores {int(st[:, 4:8, 10].median())}, barrier {int(st[:, 4:8, 11].median())}, patch issue {int(st[:, 4:8, 12].median())}, dma issue {int(st[:, 4:8, 13].median())}")
-    print(f"   consumers: stats barrier + emit {int((st[:, 0:4, 14] - st[:, 0:4, 7]).median())} cycles, output stores {int((st[:, 0:4, 8] - st[:, 0:4, 14]).median())}")
+    print(f"   consumers: stats barrier + emit {int((st[:, 0:4, 14] - st[:, 0:4, 7]).median())} cycles, output stores {int((st[:, 0:4, 8] - st[:, 0:4, 14]).median())}"
+          f" (activation / residual + LDS image {int((st[:, 0:4, 9] - st[:, 0:4, 14]).median())}, barrier {int((st[:, 0:4, 10] - st[:, 0:4, 9]).median())}, "
+          f"LDS read + global stores {int((st[:, 0:4, 8] - st[:, 0:4, 10]).median())})")
     span = (st[:, :, 8].max(dim=1).values - st[:, :, 0].min(dim=1).values)
     print(f"   workgroup lifetime: median {int(span.median())} cycles, max {int(span.max())}")
     # the launch as a whole on the device-wide 100 MHz clock (slot 15 = that clock at each wave's start): when workgroups start relative
