@@ -99,7 +99,8 @@ __device__ __forceinline__ void conv_params_from_lanes(ConvDev& p) {
 // A launch goes to the smallest flavour that covers it (conv_pipe.hip).  Not a matter of taste: a path that is compiled in but never
 // taken still costs -- the taken path then jumps over it, every jump lands on a cold instruction-cache line (the cache is invalidated
 // at every launch), and a launch is short.  Measured: with the tail code merely compiled OUT the un-fused sampler ran 2.9 % faster.
-constexpr int FL_FIN = 1, FL_RES = 2, FL_POST = 4, FL_ALL = 7;
+constexpr int FL_FIN = 1, FL_RES = 2, FL_POST = 4, FL_XF = 8, FL_CAT = 16, FL_STAMP = 32, FL_ALL = 63;
+// (8: the input may carry a GroupNorm / FiLM / SiLU transform, 16: a second, concatenated source, 32: diagnostic phase stamps)
 template <int WM, int WN, int WK, int MT, int NT, int FL = FL_ALL>
 __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT][NT], f32x16 (&accr)[MT][NT], float* smem, int tid, int lane,
                                               int wave, int b0, int y0, int x0, int n0, int tx, int ty, bool active = true,
@@ -163,7 +164,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
         const int b = b0 + tb;
         return b < a.B ? (b * a.H + y0 + th) * a.W + x0 + tw : -1;
     };
-    conv_stamp(p, 6);
+    if (FL & FL_STAMP) conv_stamp(p, 6);
     const bool owner = active && (wk == 0);
     const bool fin = (FL & FL_FIN) && a.fin.gamma != nullptr;
     // this launch's epoch of the fused tail (drawn from the sample group's arrival counter at kernel start, parked in LDS)
@@ -325,7 +326,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
     }
     if (a.stats_out && !fast_stats) block_sums();
 
-    conv_stamp(p, 7);
+    if (FL & FL_STAMP) conv_stamp(p, 7);
     if (a.stats_out) {
         if (fast_stats) stats_fast(a.stats_out, a.Gout, p.cpg, p.cpgt, p.NPG, fin && !p.fin_local, (fin && p.fin_local) ? smem + p.o_fin : nullptr);
         else {
@@ -333,7 +334,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
             emit(a.stats_out, a.Gout, p.cpg, p.cpgt, p.NPG, fin && !p.fin_local, (fin && p.fin_local) ? smem + p.o_fin : nullptr);
         }
     }
-    conv_stamp(p, 14);
+    if (FL & FL_STAMP) conv_stamp(p, 14);
 
     if (fin && a.fin.raw && owner) {   // training: the pre-norm value stays (GroupNorm backward needs it); issued before the meeting's wait
 #pragma unroll
@@ -522,7 +523,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
             }
         }
     }
-    conv_stamp(p, 8);
+    if (FL & FL_STAMP) conv_stamp(p, 8);
 }
 
 int conv_pipe_launch(const ConvDev& d, int tile, int grid, size_t lds, hipStream_t s);

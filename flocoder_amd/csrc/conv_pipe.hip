@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
     const int C0 = a.s0.C, C1 = a.s1.C, Cin = a.Cin, Cout = a.Cout;
     const bool has_res = (FL & FL_RES) && a.res_out != nullptr;
     const int nchunks = p.nchunks;
-    conv_stamp(p, 0);
+    if (FL & FL_STAMP) conv_stamp(p, 0);
     // Fused tail across workgroups: draw this launch's epoch from the sample group's arrival counter NOW -- the round trip hides behind
     // the whole main loop; every workgroup of the group gets the same quotient because launches of one op never overlap.
     const bool meet = (FL & FL_FIN) && a.fin.gamma != nullptr && !p.fin_local;
@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
     // Run by the consumers at once and by the loaders AFTER they have put the first weight slabs in flight (two dependent
     // global round trips that the slab transfer overlaps); both sides meet in the same two barriers.
     auto gn_tables = [&]() {
-      if (p.any_xf) {
+      if ((FL & FL_XF) && p.any_xf) {
         const int G0 = a.s0.xf.mode ? a.s0.xf.G : 0, G1 = a.s1.xf.mode ? a.s1.xf.G : 0;
         // second-phase operands (gamma, beta, FiLM scale / shift of this thread's first (sample, channel) entry) are requested
         // together with the statistics: one memory round trip for the two tables instead of two dependent ones
@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
                 }
             }
         }
-        conv_stamp(p, 1);
+        if (FL & FL_STAMP) conv_stamp(p, 1);
         const int nwb = p.nwb;                    // weight stages in LDS: 3 = slabs run two chunks ahead, 2 = one ahead
         // LDS-DMA plan of this lw: piece j = lw + 4m covers 256 floats of the slab = (256/BN) rows x BN columns.  A lane's
         // source pointer at chunk 0 is fixed for the whole kernel and advances by CC*Cout floats per chunk, so issuing a slab
@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
         const int nk = __builtin_amdgcn_readfirstlane((p.P * Q + LT - 1) / LT);   // element slots in use (scalar: cheap loop exits)
         auto issue_patch = [&](int i) {           // input window of chunk i -> registers, every load issued back to back
             const int c = i * CC + q4;
-            const bool live = c < Cin, first = c < C0;
+            const bool live = c < Cin, first = !(FL & FL_CAT) || c < C0;
             const float* base = first ? a.s0.p + c : a.s1.p + (c - C0);
             const int Cs = first ? C0 : C1;
 #pragma unroll
@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
                 if (k >= nk) break;
                 if (e_lds[k] < 0) continue;
                 f32x4 x = pv[k];
-                if (p.any_xf && live && e_po[k] >= 0) {
+                if ((FL & FL_XF) && p.any_xf && live && e_po[k] >= 0) {
                     const float2* ab = aff + e_tb[k] * Cin + c;
                     x.x = ab[0].x * x.x + ab[0].y; x.y = ab[1].x * x.y + ab[1].y;
                     x.z = ab[2].x * x.z + ab[2].y; x.w = ab[3].x * x.w + ab[3].y;
@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
         {   // window 0 does not depend on the tables: request it first, so that its round trip overlaps theirs.  Ordinary loads --
             // the compiler must see them pending across gn_tables() (hidden loads are only safe in straight-line code).
             const int c = q4;
-            const bool live = c < Cin, first = c < C0;
+            const bool live = c < Cin, first = !(FL & FL_CAT) || c < C0;
             const float* base = first ? a.s0.p + c : a.s1.p + (c - C0);
             const int Cs = first ? C0 : C1;
 #pragma unroll
@@ -334,26 +334,26 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
         }
         gn_tables();
         store_patch(0);
-        conv_stamp(p, 3);
+        if (FL & FL_STAMP) conv_stamp(p, 3);
         loader_handover();                        // stage 0 ready
         for (int g = 0; g < nchunks; ++g) {       // consumers are on chunk g
             const bool next = g + 1 < nchunks;
             int ahead = 0;
-            unsigned long long ta = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+            unsigned long long ta = ((FL & FL_STAMP) && p.stamps) ? __builtin_amdgcn_s_memtime() : 0ull;
             if (!DB && next && nwb == 2) dma_weights(g + 1);
             if (next) issue_patch(g + 1);
-            unsigned long long tb_ = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+            unsigned long long tb_ = ((FL & FL_STAMP) && p.stamps) ? __builtin_amdgcn_s_memtime() : 0ull;
             if (!DB && nwb == 3 && g + 2 < nchunks) { dma_weights(g + 2); ahead = my_pieces; }
-            unsigned long long t0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-            if (p.stamps) { dbg_issue += tb_ - ta; dbg_dma += t0 - tb_; }
+            unsigned long long t0 = ((FL & FL_STAMP) && p.stamps) ? __builtin_amdgcn_s_memtime() : 0ull;
+            if ((FL & FL_STAMP) && p.stamps) { dbg_issue += tb_ - ta; dbg_dma += t0 - tb_; }
             wait_vmcnt(ahead);                    // window g+1 in registers, slab g+1 landed; slab g+2 stays in flight across the barrier
-            unsigned long long t1 = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+            unsigned long long t1 = ((FL & FL_STAMP) && p.stamps) ? __builtin_amdgcn_s_memtime() : 0ull;
             if (next) store_patch(g + 1);
-            unsigned long long t2 = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+            unsigned long long t2 = ((FL & FL_STAMP) && p.stamps) ? __builtin_amdgcn_s_memtime() : 0ull;
             loader_handover();
-            if (p.stamps) { dbg_mem += t1 - t0; dbg_store += t2 - t1; dbg_bar += __builtin_amdgcn_s_memtime() - t2; }
+            if ((FL & FL_STAMP) && p.stamps) { dbg_mem += t1 - t0; dbg_store += t2 - t1; dbg_bar += __builtin_amdgcn_s_memtime() - t2; }
         }
-        if (p.stamps && lane == 0) {
+        if ((FL & FL_STAMP) && p.stamps && lane == 0) {
             unsigned long long* d = p.stamps + ((size_t)blockIdx.x * 8 + (wave8 < 8 ? wave8 : 7)) * 16;
             d[9] = dbg_mem; d[10] = dbg_store; d[11] = dbg_bar; d[12] = dbg_issue; d[13] = dbg_dma;
         }
@@ -389,14 +389,14 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
             }
         };
         if (DB) fetch_w(0, wcur, rcur);
-        conv_stamp(p, 1);
+        if (FL & FL_STAMP) conv_stamp(p, 1);
         gn_tables();
         if (meet && tid == 0) {
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(arrival) :: "memory");
             smem[p.o_epoch] = __uint_as_float(arrival / (unsigned)p.gsz + 1u);
         }
         __syncthreads();        // stage 0 ready
-        conv_stamp(p, 4);
+        if (FL & FL_STAMP) conv_stamp(p, 4);
         for (int i = 0; i < nchunks; ++i) {
             const float* patch = patch0 + (i & 1) * p.patch_stride;
             const float* wl = wl0 + (i % p.nwb) * p.wl_stride + bbase;
@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
                             accr[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], accr[mt][nt], 0, 0, 0);
                 }
             }
-            unsigned long long t0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+            unsigned long long t0 = ((FL & FL_STAMP) && p.stamps) ? __builtin_amdgcn_s_memtime() : 0ull;
             if (DB) {
                 loader_handover();                       // not __syncthreads(): its vmcnt(0) would wait for the slab prefetched above
 #pragma unroll
@@ -446,10 +446,10 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
             } else {
                 __syncthreads();    // stage i consumed; stage i+1 (if any) ready
             }
-            if (p.stamps) dbg_cbar += __builtin_amdgcn_s_memtime() - t0;
+            if ((FL & FL_STAMP) && p.stamps) dbg_cbar += __builtin_amdgcn_s_memtime() - t0;
         }
-        if (p.stamps && lane == 0) p.stamps[((size_t)blockIdx.x * 8 + wave8) * 16 + 11] = dbg_cbar;
-        conv_stamp(p, 5);
+        if ((FL & FL_STAMP) && p.stamps && lane == 0) p.stamps[((size_t)blockIdx.x * 8 + wave8) * 16 + 11] = dbg_cbar;
+        if (FL & FL_STAMP) conv_stamp(p, 5);
     }
     conv_epilogue<WM, WN, WK, MT, NT, FL>(p, acc, accr, smem, tid, lane, wave, b0, y0, x0, n0, tx, ty, consumer, NTHR, pre);
 }
@@ -515,8 +515,9 @@ int conv_pipe_init() {
     FC_TRY(pipe_attr_ks<2>());
     FC_TRY(pipe_attr_ks<3>());
     FC_TRY(pipe_attr_ks<5>());
-    FC_TRY((lean_attr<3, 0>())); FC_TRY((lean_attr<3, FL_RES>())); FC_TRY((lean_attr<3, FL_FIN>()));
-    FC_TRY((lean_attr<1, 0>())); FC_TRY((lean_attr<2, 0>()));
+    FC_TRY((lean_attr<3, 0>())); FC_TRY((lean_attr<3, FL_RES>())); FC_TRY((lean_attr<3, FL_CAT>())); FC_TRY((lean_attr<3, FL_RES | FL_CAT>()));
+    FC_TRY((lean_attr<3, FL_FIN | FL_XF>())); FC_TRY((lean_attr<3, FL_XF>()));
+    FC_TRY((lean_attr<1, 0>())); FC_TRY((lean_attr<1, FL_XF>())); FC_TRY((lean_attr<2, 0>()));
     done = true;
     return FC_OK;
 }
@@ -539,13 +540,22 @@ static int pipe_launch_ks(const ConvDev& d, int tile, int grid, size_t lds, hipS
 int conv_pipe_launch(const ConvDev& d, int tile, int grid, size_t lds, hipStream_t s) {
     static const bool lean = [] { const char* e = std::getenv("FLOCODER_AMD_LEAN_KERNELS"); return !(e && std::string(e) == "0"); }();
     if (lean) {                  // the smallest flavour that covers this launch
-        const int need = (d.a.fin.gamma ? FL_FIN : 0) | (d.a.res_out ? FL_RES : 0) | (d.a.stats_post ? FL_POST : 0);
+        const int need = (d.a.fin.gamma ? FL_FIN : 0) | (d.a.res_out ? FL_RES : 0) | (d.a.stats_post ? FL_POST : 0) | (d.any_xf ? FL_XF : 0) |
+                         (d.a.s1.C ? FL_CAT : 0) | (d.stamps ? FL_STAMP : 0);
         int r = -1;
-        if (d.a.KS == 3 && need == 0) r = lean_launch<3, 0>(d, tile, grid, lds, s);
-        else if (d.a.KS == 3 && need == FL_RES) r = lean_launch<3, FL_RES>(d, tile, grid, lds, s);
-        else if (d.a.KS == 3 && need == FL_FIN) r = lean_launch<3, FL_FIN>(d, tile, grid, lds, s);
-        else if (d.a.KS == 1 && need == 0) r = lean_launch<1, 0>(d, tile, grid, lds, s);
-        else if (d.a.KS == 2 && need == 0) r = lean_launch<2, 0>(d, tile, grid, lds, s);
+        if (d.a.KS == 3) {
+            if (need == 0) r = lean_launch<3, 0>(d, tile, grid, lds, s);
+            else if (need == FL_RES) r = lean_launch<3, FL_RES>(d, tile, grid, lds, s);
+            else if (need == FL_CAT) r = lean_launch<3, FL_CAT>(d, tile, grid, lds, s);
+            else if (need == (FL_RES | FL_CAT)) r = lean_launch<3, FL_RES | FL_CAT>(d, tile, grid, lds, s);
+            else if (need == FL_XF) r = lean_launch<3, FL_XF>(d, tile, grid, lds, s);
+            else if ((need | FL_XF) == (FL_FIN | FL_XF)) r = lean_launch<3, FL_FIN | FL_XF>(d, tile, grid, lds, s);
+        } else if (d.a.KS == 1) {
+            if (need == 0) r = lean_launch<1, 0>(d, tile, grid, lds, s);
+            else if (need == FL_XF) r = lean_launch<1, FL_XF>(d, tile, grid, lds, s);
+        } else if (d.a.KS == 2 && need == 0) {
+            r = lean_launch<2, 0>(d, tile, grid, lds, s);
+        }
         if (r != -1) return r;
     }
     switch (d.a.KS) {
