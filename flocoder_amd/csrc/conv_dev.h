@@ -99,8 +99,11 @@ __device__ __forceinline__ void conv_params_from_lanes(ConvDev& p) {
 // A launch goes to the smallest flavour that covers it (conv_pipe.hip).  Not a matter of taste: a path that is compiled in but never
 // taken still costs -- the taken path then jumps over it, every jump lands on a cold instruction-cache line (the cache is invalidated
 // at every launch), and a launch is short.  Measured: with the tail code merely compiled OUT the un-fused sampler ran 2.9 % faster.
-constexpr int FL_FIN = 1, FL_RES = 2, FL_POST = 4, FL_XF = 8, FL_CAT = 16, FL_STAMP = 32, FL_ALL = 63;
-// (8: the input may carry a GroupNorm / FiLM / SiLU transform, 16: a second, concatenated source, 32: diagnostic phase stamps)
+constexpr int FL_FIN = 1, FL_RES = 2, FL_POST = 4, FL_XF = 8, FL_CAT = 16, FL_STAMP = 32, FL_STATS = 64, FL_GN1 = 128, FL_POSTOP = 256,
+              FL_NARROW = 512, FL_MULTI = 1024, FL_ALL = 2047;
+// (8: the input may carry a GroupNorm / FiLM / SiLU transform, 16: a second, concatenated source, 32: diagnostic phase stamps, 64: GroupNorm
+// partials of the output, 128: GroupNorm(1) partials of the tail's result, 256: activation / addend on the output, 512: per-lane dword
+// stores when the LDS image for the wide stores does not fit, 1024: several samples per tile -- always on for the 32-row tile)
 template <int WM, int WN, int WK, int MT, int NT, int FL = FL_ALL>
 __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT][NT], f32x16 (&accr)[MT][NT], float* smem, int tid, int lane,
                                               int wave, int b0, int y0, int x0, int n0, int tx, int ty, bool active = true,
@@ -171,7 +174,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
     const unsigned epoch = (fin && !p.fin_local) ? __float_as_uint(smem[p.o_epoch]) : 0u;
     float* partS = smem + p.o_part;               // [BM/16][BN]
     float* partQ = partS + (BM / 16) * BN;        // [BM/16][BN]
-    if (a.stats_out) __syncthreads();             // patch/wl (aliased by part*) are dead for every wave
+    const bool do_stats = (FL & FL_STATS) && a.stats_out != nullptr;
+    if (do_stats) __syncthreads();                // patch/wl (aliased by part*) are dead for every wave
 
     // per-(16-row half-block, column) sums of the accumulators -> LDS
     auto block_sums = [&]() {
@@ -201,7 +205,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
     // group -- consecutive lanes of one wave, cpgt a power of two <= 64 -- meet by xor-shuffles; the group's first lane writes
     // (mean_t, M2_t) of this tile's share of group g of sample b.
     // (sum, sum of squares) of this tile's share of group (tb, gl) -> its (mean_t, M2_t) partial slot (or granules / the local table)
-    auto publish = [&](float* dst, int G, int cpg, int cpgt, int NPG, bool coherent, float* ltab, int tb, int gl, float s, float q) {
+    auto publish = [&](float* dst, int G, int cpg, int cpgt, int NPG, bool coherent, bool ltab_on, int tb, int gl, float s, float q) {
         const int b = b0 + tb;
         const float n = (float)(p.rps * cpgt), mean = s / n;
         const int g = n0 / cpg + (cpg >= BN ? 0 : gl);
@@ -209,7 +213,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
         const int msub = (p.TB > 1) ? 0 : ty * p.tiles_x + tx;
         const int T = (p.TB > 1 ? 1 : p.tiles_x * p.tiles_y) * NPG;
         float* d = dst + ((size_t)(b * G + g) * T + msub * NPG + nsub) * 2;
-        if (ltab) {       // the tile holds the whole group: (mean, rstd) for the tail below, no trip through memory
+        if (ltab_on) {    // the tile holds the whole group: (mean, rstd) for the tail below, no trip through memory
+            float* ltab = smem + p.o_fin;
             const int ngt = cpg >= BN ? 1 : BN / cpg;
             ltab[2 * (tb * ngt + gl)] = mean;
             ltab[2 * (tb * ngt + gl) + 1] = 1.0f / sqrtf((q - s * mean) / n + a.fin.eps);
@@ -229,7 +234,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
     // thread i <-> (sample tb, column col) sums its column over the sample's 16-row half-blocks, then the cpgt columns of a
     // group -- consecutive lanes of one wave, cpgt a power of two <= 64 -- meet by xor-shuffles; the group's first lane writes
     // (mean_t, M2_t) of this tile's share of group g of sample b.
-    auto emit = [&](float* dst, int G, int cpg, int cpgt, int NPG, bool coherent, float* ltab) {
+    auto emit = [&](float* dst, int G, int cpg, int cpgt, int NPG, bool coherent, bool ltab) {
         const int hb_per = p.rps >> 4;
         const int ncols = min(BN, Cout - n0);
         for (int i0 = 0; i0 < p.TB * BN; i0 += nthr) {
@@ -249,7 +254,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
     // folds its own rows and its group's columns in registers (shuffles only), one LDS word pair per (wave row, group) crosses to the
     // publishing thread.  The general form above goes through [BM/16][BN] LDS tables and sums them again per thread: 5 k cycles of the
     // 10 k-cycle epilogue of a 32x32 layer, this is 2 k.
-    auto stats_fast = [&](float* dst, int G, int cpg, int cpgt, int NPG, bool coherent, float* ltab) {
+    auto stats_fast = [&](float* dst, int G, int cpg, int cpgt, int NPG, bool coherent, bool ltab) {
         const int lanes = cpgt < 32 ? cpgt : 32;          // columns of a group inside one 32-column accumulator block
         const int per = cpgt <= 32 ? 1 : cpgt / 32;       // accumulator blocks a group spans (cpgt == 64 with NT == 2)
         if (owner) {
@@ -292,7 +297,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
             publish(dst, G, cpg, cpgt, NPG, coherent, ltab, 0, i, s_, q_);
         }
     };
-    const bool fast_stats = p.TB == 1;
+    constexpr bool CAN_MULTI = (FL & FL_MULTI) || (WM * MT == 1);     // the 32-row tile is the small-image tile: samples share it
+    const bool fast_stats = !CAN_MULTI || p.TB == 1;
 
     // Statistics first, stores last: a workgroup barrier waits for every outstanding global store (s_waitcnt vmcnt(0)), so a
     // barrier AFTER the output stores would park the whole workgroup for the store round trip.
@@ -324,14 +330,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                 }
             }
     }
-    if (a.stats_out && !fast_stats) block_sums();
+    if (do_stats && !fast_stats) block_sums();
 
     if (FL & FL_STAMP) conv_stamp(p, 7);
-    if (a.stats_out) {
-        if (fast_stats) stats_fast(a.stats_out, a.Gout, p.cpg, p.cpgt, p.NPG, fin && !p.fin_local, (fin && p.fin_local) ? smem + p.o_fin : nullptr);
+    if (do_stats) {
+        if (fast_stats) stats_fast(a.stats_out, a.Gout, p.cpg, p.cpgt, p.NPG, fin && !p.fin_local, fin && p.fin_local);
         else {
             __syncthreads();
-            emit(a.stats_out, a.Gout, p.cpg, p.cpgt, p.NPG, fin && !p.fin_local, (fin && p.fin_local) ? smem + p.o_fin : nullptr);
+            emit(a.stats_out, a.Gout, p.cpg, p.cpgt, p.NPG, fin && !p.fin_local, fin && p.fin_local);
         }
     }
     if (FL & FL_STAMP) conv_stamp(p, 14);
@@ -430,14 +436,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                     }
                 }
         }
-        if (a.fin.gn1_out) {   // GroupNorm(1) partials of the final value for the PreNorm that follows (unet.py:156-160)
+        if ((FL & FL_GN1) && a.fin.gn1_out) {   // GroupNorm(1) partials of the final value for the PreNorm that follows (unet.py:156-160)
             lds_only_barrier();                    // every reader of part* / tab is done
             const int cpg1 = Cout, cpgt1 = Cout < BN ? Cout : BN, NPG1 = Cout >= BN ? Cout / BN : 1;
-            if (fast_stats) stats_fast(a.fin.gn1_out, 1, cpg1, cpgt1, NPG1, false, nullptr);
+            if (fast_stats) stats_fast(a.fin.gn1_out, 1, cpg1, cpgt1, NPG1, false, false);
             else {
                 block_sums();
                 lds_only_barrier();
-                emit(a.fin.gn1_out, 1, cpg1, cpgt1, NPG1, false, nullptr);
+                emit(a.fin.gn1_out, 1, cpg1, cpgt1, NPG1, false, false);
             }
         }
     }
@@ -451,8 +457,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
     // [row][BN + 4] every thread of the workgroup (the staging waves too) then writes whole 16-byte channel quads: a quarter of the
     // store instructions, each 1 KiB contiguous when Cout == BN.
     const bool post = !stats_post && !fin;                // activation / residual still to apply (else already in the accumulators)
-    const bool act = post && a.out_act;
-    const float* addp = post ? a.add : nullptr;
+    const bool act = (FL & FL_POSTOP) && post && a.out_act;
+    const float* addp = ((FL & FL_POSTOP) && post) ? a.add : nullptr;
     if (owner) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -489,7 +495,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
             }
         }
     }
-    if (p.o_out >= 0) {
+    if (p.o_out >= 0) {      // (stripping the narrow path per flavour trips a code-generation error in hipcc 7.2: both stay)
         constexpr int OS = BN + 4, Q4 = BN / 4;
         float* ot = smem + p.o_out;
         for (int pass = 0; pass < (has_res ? 2 : 1); ++pass) {
