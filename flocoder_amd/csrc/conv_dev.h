@@ -100,10 +100,11 @@ __device__ __forceinline__ void conv_params_from_lanes(ConvDev& p) {
 // taken still costs -- the taken path then jumps over it, every jump lands on a cold instruction-cache line (the cache is invalidated
 // at every launch), and a launch is short.  Measured: with the tail code merely compiled OUT the un-fused sampler ran 2.9 % faster.
 constexpr int FL_FIN = 1, FL_RES = 2, FL_POST = 4, FL_XF = 8, FL_CAT = 16, FL_STAMP = 32, FL_STATS = 64, FL_GN1 = 128, FL_POSTOP = 256,
-              FL_NARROW = 512, FL_MULTI = 1024, FL_ALL = 2047;
+              FL_NARROW = 512, FL_MULTI = 1024, FL_MEET = 2048, FL_ALL = 4095;
 // (8: the input may carry a GroupNorm / FiLM / SiLU transform, 16: a second, concatenated source, 32: diagnostic phase stamps, 64: GroupNorm
 // partials of the output, 128: GroupNorm(1) partials of the tail's result, 256: activation / addend on the output, 512: per-lane dword
-// stores when the LDS image for the wide stores does not fit, 1024: several samples per tile -- always on for the 32-row tile)
+// stores when the LDS image for the wide stores does not fit, 1024: several samples per tile -- always on for the 32-row tile,
+// 2048: the fused tail may have to meet other workgroups (without it: only tails whose tile holds whole GroupNorm groups))
 template <int WM, int WN, int WK, int MT, int NT, int FL = FL_ALL>
 __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT][NT], f32x16 (&accr)[MT][NT], float* smem, int tid, int lane,
                                               int wave, int b0, int y0, int x0, int n0, int tx, int ty, bool active = true,
@@ -171,7 +172,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
     const bool owner = active && (wk == 0);
     const bool fin = (FL & FL_FIN) && a.fin.gamma != nullptr;
     // this launch's epoch of the fused tail (drawn from the sample group's arrival counter at kernel start, parked in LDS)
-    const unsigned epoch = (fin && !p.fin_local) ? __float_as_uint(smem[p.o_epoch]) : 0u;
+    const bool meeting = (FL & FL_MEET) && fin && !p.fin_local;
+    const unsigned epoch = meeting ? __float_as_uint(smem[p.o_epoch]) : 0u;
     float* partS = smem + p.o_part;               // [BM/16][BN]
     float* partQ = partS + (BM / 16) * BN;        // [BM/16][BN]
     const bool do_stats = (FL & FL_STATS) && a.stats_out != nullptr;
@@ -334,10 +336,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
 
     if (FL & FL_STAMP) conv_stamp(p, 7);
     if (do_stats) {
-        if (fast_stats) stats_fast(a.stats_out, a.Gout, p.cpg, p.cpgt, p.NPG, fin && !p.fin_local, fin && p.fin_local);
+        if (fast_stats) stats_fast(a.stats_out, a.Gout, p.cpg, p.cpgt, p.NPG, meeting, fin && !meeting);
         else {
             __syncthreads();
-            emit(a.stats_out, a.Gout, p.cpg, p.cpgt, p.NPG, fin && !p.fin_local, fin && p.fin_local);
+            emit(a.stats_out, a.Gout, p.cpg, p.cpgt, p.NPG, meeting, fin && !meeting);
         }
     }
     if (FL & FL_STAMP) conv_stamp(p, 14);
@@ -363,7 +365,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
         // a release/acquire fence pair would cost every workgroup (measured: 120 us per launch instead of 25).
         float* tab = smem + p.o_fin;
         const int ngt = p.cpg >= BN ? 1 : BN / p.cpg;
-        if (!p.fin_local) {
+        if (meeting) {
             // One round trip when the others have already published: every thread polls ONE granule (sc1 loads that bypass this CU's
             // L1) until its tag is this launch's epoch, parks the value in LDS; then the Chan combination runs from LDS.  Bounded:
             // a residency mistake must not hang the device (err is checked by the host: fc_unet_fused_tail_errors).

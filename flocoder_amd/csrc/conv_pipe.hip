@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
     if (FL & FL_STAMP) conv_stamp(p, 0);
     // Fused tail across workgroups: draw this launch's epoch from the sample group's arrival counter NOW -- the round trip hides behind
     // the whole main loop; every workgroup of the group gets the same quotient because launches of one op never overlap.
-    const bool meet = (FL & FL_FIN) && a.fin.gamma != nullptr && !p.fin_local;
+    const bool meet = (FL & FL_FIN) && (FL & FL_MEET) && a.fin.gamma != nullptr && !p.fin_local;
     // Inline asm on purpose: through the builtin, hipcc's atomic optimizer waits for the returned value on the spot (a cold round trip
     // in front of everything else); here the wait sits where the value is used, after the GroupNorm tables.
     unsigned arrival = 0;
@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
     // global round trips that the slab transfer overlaps); both sides meet in the same two barriers.
     auto gn_tables = [&]() {
       if ((FL & FL_XF) && p.any_xf) {
-        const int G0 = a.s0.xf.mode ? a.s0.xf.G : 0, G1 = a.s1.xf.mode ? a.s1.xf.G : 0;
+        const int G0 = a.s0.xf.mode ? a.s0.xf.G : 0, G1 = ((FL & FL_CAT) && a.s1.xf.mode) ? a.s1.xf.G : 0;
         // second-phase operands (gamma, beta, FiLM scale / shift of this thread's first (sample, channel) entry) are requested
         // together with the statistics: one memory round trip for the two tables instead of two dependent ones
         float pg = 1.f, pbt = 0.f, psc = 0.f, psh = 0.f;
@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
         int p_gs = 0;
         if (tid < p.TB * Cin) {
             const int tb = tid / Cin, c = tid - tb * Cin, b = b0 + tb;
-            const bool first = c < C0;
+            const bool first = !(FL & FL_CAT) || c < C0;
             const SrcXform& xf = first ? a.s0.xf : a.s1.xf;
             if (b < a.B && xf.mode) {
                 const int cs = first ? c : c - C0, Cs = first ? C0 : C1;
@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
             }
         }
         for (int i = tid; i < p.TB * (G0 + G1); i += NTHR) {
-            const bool first = i < p.TB * G0;
+            const bool first = !(FL & FL_CAT) || i < p.TB * G0;
             const SrcXform& xf = first ? a.s0.xf : a.s1.xf;
             const int j = first ? i : i - p.TB * G0;
             const int tb = j / xf.G, g = j - tb * xf.G, b = b0 + tb;
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
         for (int i = tid + NTHR; i < p.TB * Cin; i += NTHR) {
             const int tb = i / Cin, c = i - tb * Cin, b = b0 + tb;
             float A = 1.f, Bv = 0.f;
-            const bool first = c < C0;
+            const bool first = !(FL & FL_CAT) || c < C0;
             const SrcXform& xf = first ? a.s0.xf : a.s1.xf;
             if (b < a.B && xf.mode) {
                 const int cs = first ? c : c - C0, Cs = first ? C0 : C1;
@@ -484,9 +484,9 @@ static int pipe_attr_ks() {
     X(TILE_M32N32K4, 1, 1, 4, 1, 1, 32, KS, (KS == 1 ? 4 : 8))
 
 #define FC_LEAN_FLAVOURS_3(X) X(FL_STATS) X(FL_STATS | FL_RES) X(FL_STATS | FL_CAT) X(FL_STATS | FL_RES | FL_CAT) X(FL_STATS | FL_XF) \
-    X(FL_STATS | FL_XF | FL_FIN) X(FL_STATS | FL_XF | FL_FIN | FL_GN1)
+    X(FL_STATS | FL_XF | FL_FIN) X(FL_STATS | FL_XF | FL_FIN | FL_GN1) X(FL_STATS | FL_XF | FL_FIN | FL_MEET) X(FL_STATS | FL_XF | FL_FIN | FL_GN1 | FL_MEET)
 // the 2x2 stride-2 kernel (Downsample) keeps the epilogue options in: stripping them trips a code-generation error in hipcc 7.2
-constexpr int FL_LEAN2 = FL_STATS | FL_GN1 | FL_POSTOP | FL_MULTI | FL_NARROW;
+constexpr int FL_LEAN2 = FL_STATS | FL_GN1 | FL_POSTOP | FL_MULTI | FL_NARROW | FL_MEET;
 #define FC_LEAN_FLAVOURS_1(X) X(FL_STATS) X(FL_STATS | FL_XF)
 
 template <int KS, int FL>
@@ -554,7 +554,8 @@ int conv_pipe_launch(const ConvDev& d, int tile, int grid, size_t lds, hipStream
         const int need = (d.a.fin.gamma ? FL_FIN : 0) | (d.a.res_out ? FL_RES : 0) | (d.a.stats_post ? FL_POST : 0) | (d.any_xf ? FL_XF : 0) |
                          (d.a.s1.C ? FL_CAT : 0) | (d.stamps ? FL_STAMP : 0) | FL_STATS |   // (a flavour without the statistics code trips a code-generation error in hipcc 7.2: always in)
                          (d.a.fin.gn1_out ? FL_GN1 : 0) |
-                         ((d.a.out_act || d.a.add) ? FL_POSTOP : 0) | ((d.TB > 1 && !small_tile) ? FL_MULTI : 0);
+                         ((d.a.out_act || d.a.add) ? FL_POSTOP : 0) | ((d.TB > 1 && !small_tile) ? FL_MULTI : 0) |
+                         ((d.a.fin.gamma && !d.fin_local) ? FL_MEET : 0);
         int r = -1;
         if (d.a.KS == 3) {
 #define X(F) if (r == -1 && need == (F)) r = lean_launch<3, (F)>(d, tile, grid, lds, s);
