@@ -483,11 +483,11 @@ static int pipe_attr_ks() {
     X(TILE_M64N32K2, 2, 1, 2, 1, 1, 32, KS, (KS == 1 ? 4 : 8)) \
     X(TILE_M32N32K4, 1, 1, 4, 1, 1, 32, KS, (KS == 1 ? 4 : 8))
 
-#define FC_LEAN_FLAVOURS_3(X) X(FL_STATS) X(FL_STATS | FL_RES) X(FL_STATS | FL_CAT) X(FL_STATS | FL_RES | FL_CAT) X(FL_STATS | FL_XF) \
+#define FC_LEAN_FLAVOURS_3(X) X(FL_STATS) X(FL_STATS | FL_POSTOP) X(FL_STATS | FL_RES) X(FL_STATS | FL_CAT) X(FL_STATS | FL_RES | FL_CAT) X(FL_STATS | FL_XF) \
     X(FL_STATS | FL_XF | FL_FIN) X(FL_STATS | FL_XF | FL_FIN | FL_GN1) X(FL_STATS | FL_XF | FL_FIN | FL_MEET) X(FL_STATS | FL_XF | FL_FIN | FL_GN1 | FL_MEET)
 // the 2x2 stride-2 kernel (Downsample) keeps the epilogue options in: stripping them trips a code-generation error in hipcc 7.2
 constexpr int FL_LEAN2 = FL_STATS | FL_GN1 | FL_POSTOP | FL_MULTI | FL_NARROW | FL_MEET;
-#define FC_LEAN_FLAVOURS_1(X) X(FL_STATS) X(FL_STATS | FL_XF)
+#define FC_LEAN_FLAVOURS_1(X) X(FL_STATS) X(FL_STATS | FL_POSTOP) X(FL_STATS | FL_XF)
 
 template <int KS, int FL>
 static int lean_attr() {
