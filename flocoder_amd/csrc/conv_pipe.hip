@@ -29,8 +29,10 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // M0).  Inline asm on purpose (cdna_hip_programming.md 5.7): hipcc then keeps these out of its vmcnt bookkeeping, so the
 // waits it inserts for the loaders' ordinary register loads do not drain a slab that was issued for a LATER stage; we
 // count them by hand (explicit vmcnt(0) before a stage is handed over).  M0 is saved/restored inside the statement.
-__device__ __forceinline__ void lds_dma16(const float* gsrc, float* lds_dst) {
-    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)lds_dst);
+// (the destination travels as an LDS byte address, not as a generic pointer: casting a generic pointer back to LDS at every site made
+// hipcc 7.2 emit an illegal aperture test -- "V_CMP_NE_U32 0, $src_shared_base" -- in some instantiations)
+__device__ __forceinline__ void lds_dma16(const float* gsrc, unsigned lds_byte) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte);
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
@@ -96,6 +98,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
     float2* aff = reinterpret_cast<float2*>(smem + p.o_aff);   // [TB][Cin]
     float* patch0 = smem + p.o_patch;
     float* wl0 = smem + p.o_wl;
+    const unsigned smem_lds = (unsigned)(size_t)(lptr_t)smem;      // LDS byte address of the dynamic segment
 
     const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6;
     const bool consumer = wave8 < 4;
@@ -274,13 +277,13 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
         auto dma_weights = [&](int i) {
             const int c0 = i * CC;
             const size_t adv = (size_t)c0 * Cout;
-            float* wb = wl0 + (i % nwb) * p.wl_stride + lw * 256;
+            const unsigned wb = smem_lds + 4u * (unsigned)(p.o_wl + (i % nwb) * p.wl_stride + lw * 256);
             const bool tail = c0 + CC > Cin;            // only the last chunk can run past Cin
 #pragma unroll
             for (int m = 0; m < MAXP; ++m) {
                 if (m >= my_pieces) break;
                 const bool ok = d_ptr[m] != nullptr && (!tail || c0 + d_row[m] < Cin);
-                lds_dma16(ok ? d_ptr[m] + adv : p.zeros16, wb + m * (NL * 256));
+                lds_dma16(ok ? d_ptr[m] + adv : p.zeros16, wb + 4u * (unsigned)(m * (NL * 256)));
             }
         };
         f32x4 pv[NPL];
@@ -489,10 +492,13 @@ static int pipe_attr_ks() {
 constexpr int FL_LEAN2 = FL_STATS | FL_GN1 | FL_POSTOP | FL_MULTI | FL_NARROW | FL_MEET;
 #define FC_LEAN_FLAVOURS_1(X) X(FL_STATS) X(FL_STATS | FL_POSTOP) X(FL_STATS | FL_XF)
 
+// the lean kernels keep four window elements per staging thread (the all-in-one ones eight): every U-Net layer needs at most four, and
+// the staging code is unrolled per element
+constexpr int kLeanNPL = 4;
 template <int KS, int FL>
 static int lean_attr() {
 #define X(T, WM, WN, WK, MT, NT, CC, K, NL)                                                                               \
-    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pipe_kernel<WM, WN, WK, MT, NT, CC, 8, K, NL, FL>),    \
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pipe_kernel<WM, WN, WK, MT, NT, CC, kLeanNPL, K, NL, FL>),  \
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     FC_LEAN_TILES(X, KS)
 #undef X
@@ -502,8 +508,11 @@ static int lean_attr() {
 template <int KS, int FL>
 static int lean_launch(const ConvDev& d, int tile, int grid, size_t lds, hipStream_t s) {
     switch (tile) {
-#define X(T, WM, WN, WK, MT, NT, CC, K, NL) \
-    case T: hipLaunchKernelGGL((conv_pipe_kernel<WM, WN, WK, MT, NT, CC, 8, K, NL, FL>), dim3(grid), dim3(256 + 64 * NL), lds, s, d); break;
+#define X(T, WM, WN, WK, MT, NT, CC, K, NL)                                                                                       \
+    case T:                                                                                                                       \
+        if (d.P * (CC / 4) > 64 * NL * kLeanNPL) return -1;    /* more window elements per staging thread than a lean kernel keeps */ \
+        hipLaunchKernelGGL((conv_pipe_kernel<WM, WN, WK, MT, NT, CC, kLeanNPL, K, NL, FL>), dim3(grid), dim3(256 + 64 * NL), lds, s, d); \
+        break;
         FC_LEAN_TILES(X, KS)
 #undef X
         default: return -1;      // no lean flavour of this tile
