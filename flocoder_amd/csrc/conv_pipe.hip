@@ -486,11 +486,9 @@ static int pipe_attr_ks() {
     X(TILE_M64N32K2, 2, 1, 2, 1, 1, 32, KS, (KS == 1 ? 4 : 8)) \
     X(TILE_M32N32K4, 1, 1, 4, 1, 1, 32, KS, (KS == 1 ? 4 : 8))
 
-#define FC_LEAN_FLAVOURS_3(X) X(FL_STATS) X(FL_STATS | FL_POSTOP) X(FL_STATS | FL_RES) X(FL_STATS | FL_CAT) X(FL_STATS | FL_RES | FL_CAT) X(FL_STATS | FL_XF) \
+#define FC_LEAN_FLAVOURS_3(X) X(0) X(FL_POSTOP) X(FL_STATS) X(FL_STATS | FL_RES) X(FL_STATS | FL_CAT) X(FL_STATS | FL_RES | FL_CAT) X(FL_STATS | FL_XF) \
     X(FL_STATS | FL_XF | FL_FIN) X(FL_STATS | FL_XF | FL_FIN | FL_GN1) X(FL_STATS | FL_XF | FL_FIN | FL_MEET) X(FL_STATS | FL_XF | FL_FIN | FL_GN1 | FL_MEET)
-// the 2x2 stride-2 kernel (Downsample) keeps the epilogue options in: stripping them trips a code-generation error in hipcc 7.2
-constexpr int FL_LEAN2 = FL_STATS | FL_GN1 | FL_POSTOP | FL_MULTI | FL_NARROW | FL_MEET;
-#define FC_LEAN_FLAVOURS_1(X) X(FL_STATS) X(FL_STATS | FL_POSTOP) X(FL_STATS | FL_XF)
+#define FC_LEAN_FLAVOURS_1(X) X(0) X(FL_POSTOP) X(FL_XF) X(FL_STATS) X(FL_STATS | FL_XF)
 
 // the lean kernels keep four window elements per staging thread (the all-in-one ones eight): every U-Net layer needs at most four, and
 // the staging code is unrolled per element
@@ -536,7 +534,7 @@ int conv_pipe_init() {
 #define X(F) FC_TRY((lean_attr<1, (F)>()));
     FC_LEAN_FLAVOURS_1(X)
 #undef X
-    FC_TRY((lean_attr<2, FL_LEAN2>()));
+    FC_TRY((lean_attr<2, 0>()));
     done = true;
     return FC_OK;
 }
@@ -561,8 +559,7 @@ int conv_pipe_launch(const ConvDev& d, int tile, int grid, size_t lds, hipStream
     if (lean) {                  // the smallest flavour that covers this launch
         const bool small_tile = tile == TILE_M32N32K4;
         const int need = (d.a.fin.gamma ? FL_FIN : 0) | (d.a.res_out ? FL_RES : 0) | (d.a.stats_post ? FL_POST : 0) | (d.any_xf ? FL_XF : 0) |
-                         (d.a.s1.C ? FL_CAT : 0) | (d.stamps ? FL_STAMP : 0) | FL_STATS |   // (a flavour without the statistics code trips a code-generation error in hipcc 7.2: always in)
-                         (d.a.fin.gn1_out ? FL_GN1 : 0) |
+                         (d.a.s1.C ? FL_CAT : 0) | (d.stamps ? FL_STAMP : 0) | (d.a.stats_out ? FL_STATS : 0) | (d.a.fin.gn1_out ? FL_GN1 : 0) |
                          ((d.a.out_act || d.a.add) ? FL_POSTOP : 0) | ((d.TB > 1 && !small_tile) ? FL_MULTI : 0) |
                          ((d.a.fin.gamma && !d.fin_local) ? FL_MEET : 0);
         int r = -1;
@@ -574,8 +571,8 @@ int conv_pipe_launch(const ConvDev& d, int tile, int grid, size_t lds, hipStream
 #define X(F) if (r == -1 && need == (F)) r = lean_launch<1, (F)>(d, tile, grid, lds, s);
             FC_LEAN_FLAVOURS_1(X)
 #undef X
-        } else if (d.a.KS == 2 && (need & ~FL_LEAN2) == 0) {
-            r = lean_launch<2, FL_LEAN2>(d, tile, grid, lds, s);
+        } else if (d.a.KS == 2 && need == 0) {
+            r = lean_launch<2, 0>(d, tile, grid, lds, s);
         }
         if (r != -1) return r;
     }
