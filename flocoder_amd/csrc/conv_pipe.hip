@@ -130,10 +130,11 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
         asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(arrival) : "v"(cnt), "v"(1u) : "memory");
     }
 
-    // ---- GroupNorm tables: moments per (sample, group), then the folded affine per (sample, channel) -- all 512 threads.
-    // Run by the consumers at once and by the loaders AFTER they have put the first weight slabs in flight (two dependent
-    // global round trips that the slab transfer overlaps); both sides meet in the same two barriers.
-    auto gn_tables = [&]() {
+    // ---- GroupNorm tables: moments per (sample, group), then the folded affine per (sample, channel).  The staging waves build them
+    // AFTER they have put the first weight slabs in flight (two dependent global round trips that the slab transfer overlaps).
+    // The tables are built by the staging waves alone (`worker`, thread `id` of `nthr`): the accumulator waves never read them, and a
+    // second inlined copy of this code in their path was a few KB of cold instruction fetches per launch.  Both roles meet in the two barriers.
+    auto gn_tables = [&](const bool worker, const int id, const int nthr) {
       if ((FL & FL_XF) && p.any_xf) {
         const int G0 = a.s0.xf.mode ? a.s0.xf.G : 0, G1 = ((FL & FL_CAT) && a.s1.xf.mode) ? a.s1.xf.G : 0;
         // second-phase operands (gamma, beta, FiLM scale / shift of this thread's first (sample, channel) entry) are requested
@@ -141,8 +142,9 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
         float pg = 1.f, pbt = 0.f, psc = 0.f, psh = 0.f;
         bool p_on = false, p_ss = false;
         int p_gs = 0;
-        if (tid < p.TB * Cin) {
-            const int tb = tid / Cin, c = tid - tb * Cin, b = b0 + tb;
+       if (worker) {
+        if (id < p.TB * Cin) {
+            const int tb = id / Cin, c = id - tb * Cin, b = b0 + tb;
             const bool first = !(FL & FL_CAT) || c < C0;
             const SrcXform& xf = first ? a.s0.xf : a.s1.xf;
             if (b < a.B && xf.mode) {
@@ -158,7 +160,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
                 }
             }
         }
-        for (int i = tid; i < p.TB * (G0 + G1); i += NTHR) {
+        for (int i = id; i < p.TB * (G0 + G1); i += nthr) {
             const bool first = !(FL & FL_CAT) || i < p.TB * G0;
             const SrcXform& xf = first ? a.s0.xf : a.s1.xf;
             const int j = first ? i : i - p.TB * G0;
@@ -168,8 +170,10 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
             gstat[2 * i] = mean;
             gstat[2 * i + 1] = rstd;
         }
+       }
         __syncthreads();
-        if (tid < p.TB * Cin) {
+       if (worker) {
+        if (id < p.TB * Cin) {
             float A = 1.f, Bv = 0.f;
             if (p_on) {
                 A = gstat[p_gs + 1] * pg;
@@ -180,9 +184,9 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
                     Bv = Bv * sc + psh;
                 }
             }
-            aff[tid] = make_float2(A, Bv);
+            aff[id] = make_float2(A, Bv);
         }
-        for (int i = tid + NTHR; i < p.TB * Cin; i += NTHR) {
+        for (int i = id + nthr; i < p.TB * Cin; i += nthr) {
             const int tb = i / Cin, c = i - tb * Cin, b = b0 + tb;
             float A = 1.f, Bv = 0.f;
             const bool first = !(FL & FL_CAT) || c < C0;
@@ -200,6 +204,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
             }
             aff[i] = make_float2(A, Bv);
         }
+       }
         __syncthreads();
       }
     };
@@ -335,7 +340,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
                 pv[k] = *reinterpret_cast<const f32x4*>((live && e_po[k] >= 0) ? base + (size_t)e_po[k] * Cs : p.zeros16);
             }
         }
-        gn_tables();
+        gn_tables(true, ltid, LT);
         store_patch(0);
         if (FL & FL_STAMP) conv_stamp(p, 3);
         loader_handover();                        // stage 0 ready
@@ -393,7 +398,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
         };
         if (DB) fetch_w(0, wcur, rcur);
         if (FL & FL_STAMP) conv_stamp(p, 1);
-        gn_tables();
+        gn_tables(false, 0, 1);
         if (meet && tid == 0) {
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(arrival) :: "memory");
             smem[p.o_epoch] = __uint_as_float(arrival / (unsigned)p.gsz + 1u);
