@@ -118,7 +118,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
     const int half = lane >> 5, l31 = lane & 31;
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
     const int TW = 1 << p.TWl, TH = 1 << p.THl, Cout = a.Cout;
-    const bool has_res = (FL & FL_RES) && a.res_out != nullptr;
+    // a lean flavour is only ever launched for an exact match of its mask (conv_pipe.hip), so there a set bit means "on", not "possible"
+    constexpr bool LEAN = FL != FL_ALL;
+    const bool has_res = LEAN ? bool(FL & FL_RES) : a.res_out != nullptr;
     const bool stats_post = (FL & FL_POST) && a.stats_post;
     if (WK > 1) {  // meet the K-split partials in LDS (patch/wl are dead now)
         __syncthreads();
@@ -170,13 +172,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
     };
     if (FL & FL_STAMP) conv_stamp(p, 6);
     const bool owner = active && (wk == 0);
-    const bool fin = (FL & FL_FIN) && a.fin.gamma != nullptr;
+    const bool fin = LEAN ? bool(FL & FL_FIN) : a.fin.gamma != nullptr;
     // this launch's epoch of the fused tail (drawn from the sample group's arrival counter at kernel start, parked in LDS)
-    const bool meeting = (FL & FL_MEET) && fin && !p.fin_local;
+    const bool meeting = LEAN ? bool(FL & FL_MEET) : (fin && !p.fin_local);
     const unsigned epoch = meeting ? __float_as_uint(smem[p.o_epoch]) : 0u;
     float* partS = smem + p.o_part;               // [BM/16][BN]
     float* partQ = partS + (BM / 16) * BN;        // [BM/16][BN]
-    const bool do_stats = (FL & FL_STATS) && a.stats_out != nullptr;
+    const bool do_stats = LEAN ? bool(FL & FL_STATS) : a.stats_out != nullptr;
     if (do_stats) __syncthreads();                // patch/wl (aliased by part*) are dead for every wave
 
     // per-(16-row half-block, column) sums of the accumulators -> LDS
@@ -438,7 +440,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                     }
                 }
         }
-        if ((FL & FL_GN1) && a.fin.gn1_out) {   // GroupNorm(1) partials of the final value for the PreNorm that follows (unet.py:156-160)
+        if (LEAN ? bool(FL & FL_GN1) : a.fin.gn1_out != nullptr) {   // GroupNorm(1) partials of the final value for the PreNorm that follows (unet.py:156-160)
             lds_only_barrier();                    // every reader of part* / tab is done
             const int cpg1 = Cout, cpgt1 = Cout < BN ? Cout : BN, NPG1 = Cout >= BN ? Cout / BN : 1;
             if (fast_stats) stats_fast(a.fin.gn1_out, 1, cpg1, cpgt1, NPG1, false, false);

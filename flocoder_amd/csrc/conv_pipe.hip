@@ -116,12 +116,14 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
     const int b0 = bg * p.TB, y0 = ty * TH, x0 = tx * TW, n0 = nt_i * BN;
     const int PW = p.PW, PHW = p.PH * p.PW;
     const int C0 = a.s0.C, C1 = a.s1.C, Cin = a.Cin, Cout = a.Cout;
-    const bool has_res = (FL & FL_RES) && a.res_out != nullptr;
+    constexpr bool LEAN = FL != FL_ALL;        // launched for an exact match of the mask only: a set bit means "on"
+    const bool has_res = LEAN ? bool(FL & FL_RES) : a.res_out != nullptr;
+    const bool xf_on = LEAN ? bool(FL & FL_XF) : p.any_xf != 0;
     const int nchunks = p.nchunks;
     if (FL & FL_STAMP) conv_stamp(p, 0);
     // Fused tail across workgroups: draw this launch's epoch from the sample group's arrival counter NOW -- the round trip hides behind
     // the whole main loop; every workgroup of the group gets the same quotient because launches of one op never overlap.
-    const bool meet = (FL & FL_FIN) && (FL & FL_MEET) && a.fin.gamma != nullptr && !p.fin_local;
+    const bool meet = LEAN ? bool(FL & FL_MEET) : (a.fin.gamma != nullptr && !p.fin_local);
     // Inline asm on purpose: through the builtin, hipcc's atomic optimizer waits for the returned value on the spot (a cold round trip
     // in front of everything else); here the wait sits where the value is used, after the GroupNorm tables.
     unsigned arrival = 0;
@@ -135,7 +137,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
     // The tables are built by the staging waves alone (`worker`, thread `id` of `nthr`): the accumulator waves never read them, and a
     // second inlined copy of this code in their path was a few KB of cold instruction fetches per launch.  Both roles meet in the two barriers.
     auto gn_tables = [&](const bool worker, const int id, const int nthr) {
-      if ((FL & FL_XF) && p.any_xf) {
+      if (xf_on) {
         const int G0 = a.s0.xf.mode ? a.s0.xf.G : 0, G1 = ((FL & FL_CAT) && a.s1.xf.mode) ? a.s1.xf.G : 0;
         // second-phase operands (gamma, beta, FiLM scale / shift of this thread's first (sample, channel) entry) are requested
         // together with the statistics: one memory round trip for the two tables instead of two dependent ones
@@ -313,7 +315,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
                 if (k >= nk) break;
                 if (e_lds[k] < 0) continue;
                 f32x4 x = pv[k];
-                if ((FL & FL_XF) && p.any_xf && live && e_po[k] >= 0) {
+                if (xf_on && live && e_po[k] >= 0) {
                     const float2* ab = aff + e_tb[k] * Cin + c;
                     x.x = ab[0].x * x.x + ab[0].y; x.y = ab[1].x * x.y + ab[1].y;
                     x.z = ab[2].x * x.z + ab[2].y; x.w = ab[3].x * x.w + ab[3].y;
