@@ -484,7 +484,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mt][nt][r] = silu_f(acc[mt][nt][r]);
                 }
-                if (p.o_out < 0) {
+                if (!LEAN && p.o_out < 0) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         if (pix[r] >= 0) op[(size_t)pix[r] * Cout] = acc[mt][nt][r];
@@ -499,7 +499,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
             }
         }
     }
-    if (p.o_out >= 0) {      // (stripping the narrow path per flavour trips a code-generation error in hipcc 7.2: both stay)
+    if (LEAN || p.o_out >= 0) {      // lean flavours are only launched when the LDS image fits
         constexpr int OS = BN + 4, Q4 = BN / 4;
         float* ot = smem + p.o_out;
         for (int pass = 0; pass < (has_res ? 2 : 1); ++pass) {
