@@ -229,7 +229,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
             const unsigned long long tag = (unsigned long long)epoch << 32;
             __hip_atomic_store(gp, tag | __float_as_uint(mean), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(gp + 1, tag | __float_as_uint(q - s * mean), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a.fin.raw) { d[0] = mean; d[1] = q - s * mean; }     // the backward reads them in the ordinary form
+            if (!LEAN && a.fin.raw) { d[0] = mean; d[1] = q - s * mean; }     // the backward reads them in the ordinary form
         } else {
             d[0] = mean;
             d[1] = q - s * mean;
@@ -346,7 +346,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
     }
     if (FL & FL_STAMP) conv_stamp(p, 14);
 
-    if (fin && a.fin.raw && owner) {   // training: the pre-norm value stays (GroupNorm backward needs it); issued before the meeting's wait
+    if (!LEAN && fin && a.fin.raw && owner) {   // training: the pre-norm value stays (GroupNorm backward needs it); issued before the meeting's wait
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll

@@ -567,7 +567,8 @@ int conv_pipe_launch(const ConvDev& d, int tile, int grid, size_t lds, hipStream
         const bool small_tile = tile == TILE_M32N32K4;
         const int need = (d.a.fin.gamma ? FL_FIN : 0) | (d.a.res_out ? FL_RES : 0) | (d.a.stats_post ? FL_POST : 0) | (d.any_xf ? FL_XF : 0) |
                          (d.a.s1.C ? FL_CAT : 0) | (d.stamps ? FL_STAMP : 0) | (d.a.stats_out ? FL_STATS : 0) | (d.a.fin.gn1_out ? FL_GN1 : 0) |
-                         ((d.a.out_act || d.a.add) ? FL_POSTOP : 0) | (d.o_out < 0 ? FL_NARROW : 0) | ((d.TB > 1 && !small_tile) ? FL_MULTI : 0) |
+                         ((d.a.out_act || d.a.add) ? FL_POSTOP : 0) | ((d.o_out < 0 || d.a.fin.raw) ? FL_NARROW : 0) |   // (a training tail that keeps its raw output also goes to the all-in-one kernel)
+                         ((d.TB > 1 && !small_tile) ? FL_MULTI : 0) |
                          ((d.a.fin.gamma && !d.fin_local) ? FL_MEET : 0);
         int r = -1;
         if (d.a.KS == 3) {
