@@ -497,6 +497,11 @@ static int pipe_attr_ks() {
     X(FL_STATS | FL_XF | FL_FIN) X(FL_STATS | FL_XF | FL_FIN | FL_GN1) X(FL_STATS | FL_XF | FL_FIN | FL_MEET) X(FL_STATS | FL_XF | FL_FIN | FL_GN1 | FL_MEET)
 #define FC_LEAN_FLAVOURS_1(X) X(0) X(FL_POSTOP) X(FL_XF) X(FL_STATS) X(FL_STATS | FL_XF)
 
+// the 64-column tiles the 1x1 projections of the larger models run on (to_qkv and its data gradient): lean flavours for 1x1 only
+#define FC_LEAN_TILES_WIDE1(X)             \
+    X(TILE_M128N64, 4, 1, 1, 1, 2, 16, 1, 4)   \
+    X(TILE_M256N64, 4, 1, 1, 2, 2, 16, 1, 4)
+
 // the lean kernels keep four window elements per staging thread (the all-in-one ones eight): every U-Net layer needs at most four, and
 // the staging code is unrolled per element
 constexpr int kLeanNPL = 4;
@@ -507,6 +512,31 @@ static int lean_attr() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     FC_LEAN_TILES(X, KS)
 #undef X
+    return FC_OK;
+}
+
+template <int FL>
+static int lean_attr_wide1() {
+#define X(T, WM, WN, WK, MT, NT, CC, K, NL)                                                                               \
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pipe_kernel<WM, WN, WK, MT, NT, CC, kLeanNPL, K, NL, FL>),  \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FC_LEAN_TILES_WIDE1(X)
+#undef X
+    return FC_OK;
+}
+template <int FL>
+static int lean_launch_wide1(const ConvDev& d, int tile, int grid, size_t lds, hipStream_t s) {
+    switch (tile) {
+#define X(T, WM, WN, WK, MT, NT, CC, K, NL)                                                                                       \
+    case T:                                                                                                                       \
+        if (d.P * (CC / 4) > 64 * NL * kLeanNPL) return -1;                                                                       \
+        hipLaunchKernelGGL((conv_pipe_kernel<WM, WN, WK, MT, NT, CC, kLeanNPL, K, NL, FL>), dim3(grid), dim3(256 + 64 * NL), lds, s, d); \
+        break;
+        FC_LEAN_TILES_WIDE1(X)
+#undef X
+        default: return -1;
+    }
+    FC_HIP(hipGetLastError());
     return FC_OK;
 }
 
@@ -538,7 +568,7 @@ int conv_pipe_init() {
 #define X(F) FC_TRY((lean_attr<3, (F)>()));
     FC_LEAN_FLAVOURS_3(X)
 #undef X
-#define X(F) FC_TRY((lean_attr<1, (F)>()));
+#define X(F) FC_TRY((lean_attr<1, (F)>())); FC_TRY((lean_attr_wide1<(F)>()));
     FC_LEAN_FLAVOURS_1(X)
 #undef X
     FC_TRY((lean_attr<2, 0>()));
@@ -576,7 +606,7 @@ int conv_pipe_launch(const ConvDev& d, int tile, int grid, size_t lds, hipStream
             FC_LEAN_FLAVOURS_3(X)
 #undef X
         } else if (d.a.KS == 1) {
-#define X(F) if (r == -1 && need == (F)) r = lean_launch<1, (F)>(d, tile, grid, lds, s);
+#define X(F) if (r == -1 && need == (F)) { r = lean_launch<1, (F)>(d, tile, grid, lds, s); if (r == -1) r = lean_launch_wide1<(F)>(d, tile, grid, lds, s); }
             FC_LEAN_FLAVOURS_1(X)
 #undef X
         } else if (d.a.KS == 2 && need == 0) {
