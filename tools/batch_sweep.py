@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """The sampler's time per forward against the batch size (bench model, 64-step Euler): the intercept is the fixed cost of the launch
-chain, the slope the work.  Measured r02: 1.17 ms per forward at B = 8, 1.19 at 16, 1.25 at 32, 1.51 at 64, 2.34 at 128.
+chain, the slope the work.  Measured r02: 1.17 ms per forward at B = 8, 1.19 at 16, 1.25 at 32, 1.51 at 64, 2.34 at 128 before the lean kernel
+flavours; 1.04 / 1.07 / 1.12 / 1.37 / 2.16 with them.
 
     python tools/batch_sweep.py"""
 import sys, os, time, torch
