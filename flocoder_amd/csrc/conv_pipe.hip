@@ -493,7 +493,7 @@ static int pipe_attr_ks() {
     X(TILE_M64N32K2, 2, 1, 2, 1, 1, 32, KS, (KS == 1 ? 4 : 8)) \
     X(TILE_M32N32K4, 1, 1, 4, 1, 1, 32, KS, (KS == 1 ? 4 : 8))
 
-#define FC_LEAN_FLAVOURS_3(X) X(0) X(FL_POSTOP) X(FL_STATS) X(FL_STATS | FL_RES) X(FL_STATS | FL_CAT) X(FL_STATS | FL_RES | FL_CAT) X(FL_STATS | FL_XF) \
+#define FC_LEAN_FLAVOURS_3(X) X(0) X(FL_POSTOP) X(FL_STATS) X(FL_STATS | FL_STAMP) X(FL_STATS | FL_CAT | FL_STAMP) X(FL_STATS | FL_RES) X(FL_STATS | FL_CAT) X(FL_STATS | FL_RES | FL_CAT) X(FL_STATS | FL_XF) \
     X(FL_STATS | FL_XF | FL_FIN) X(FL_STATS | FL_XF | FL_FIN | FL_GN1) X(FL_STATS | FL_XF | FL_FIN | FL_MEET) X(FL_STATS | FL_XF | FL_FIN | FL_GN1 | FL_MEET)
 #define FC_LEAN_FLAVOURS_1(X) X(0) X(FL_POSTOP) X(FL_XF) X(FL_STATS) X(FL_STATS | FL_XF)
 
