@@ -108,7 +108,7 @@ constexpr int FL_FIN = 1, FL_RES = 2, FL_POST = 4, FL_XF = 8, FL_CAT = 16, FL_ST
 template <int WM, int WN, int WK, int MT, int NT, int FL = FL_ALL>
 __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT][NT], f32x16 (&accr)[MT][NT], float* smem, int tid, int lane,
                                               int wave, int b0, int y0, int x0, int n0, int tx, int ty, bool active = true,
-                                              int nthr = 256, const float* pre = nullptr) {
+                                              int nthr = 256, const float* pre = nullptr, bool staged_dead = false) {
     // `pre` (optional, 4*NT floats in the caller's registers): bias | res_conv bias | tail gamma | tail beta of this lane's columns,
     // requested before the main loop -- loaded here they are a cold miss on the epilogue's critical path (~2 k cycles per launch).
     // `active` = this wave holds accumulators (false for the loader waves of the producer/consumer kernel, which only
@@ -122,8 +122,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
     constexpr bool LEAN = FL != FL_ALL;
     const bool has_res = LEAN ? bool(FL & FL_RES) : a.res_out != nullptr;
     const bool stats_post = (FL & FL_POST) && a.stats_post;
+    // `staged_dead`: the caller's main loop ended with a workgroup barrier (the pipelined kernel hands every stage over through one), so
+    // the staging buffers the epilogue's scratch aliases are dead already and the barriers that only said so are skipped
     if (WK > 1) {  // meet the K-split partials in LDS (patch/wl are dead now)
-        __syncthreads();
+        if (!staged_dead) __syncthreads();
         float* red = smem + p.o_red;
         constexpr int TILE = 16 * 64;
         const int slot = ((wm * WN + wn) * (WK - 1) + (wk - 1)) * MT * NT * (has_res ? 2 : 1);
@@ -179,7 +181,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
     float* partS = smem + p.o_part;               // [BM/16][BN]
     float* partQ = partS + (BM / 16) * BN;        // [BM/16][BN]
     const bool do_stats = LEAN ? bool(FL & FL_STATS) : a.stats_out != nullptr;
-    if (do_stats) __syncthreads();                // patch/wl (aliased by part*) are dead for every wave
+    if (do_stats && !staged_dead) __syncthreads();   // patch/wl (aliased by part*) are dead for every wave
 
     // per-(16-row half-block, column) sums of the accumulators -> LDS
     auto block_sums = [&]() {

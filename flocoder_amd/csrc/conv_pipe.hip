@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
         if ((FL & FL_STAMP) && p.stamps && lane == 0) p.stamps[((size_t)blockIdx.x * 8 + wave8) * 16 + 11] = dbg_cbar;
         if (FL & FL_STAMP) conv_stamp(p, 5);
     }
-    conv_epilogue<WM, WN, WK, MT, NT, FL>(p, acc, accr, smem, tid, lane, wave, b0, y0, x0, n0, tx, ty, consumer, NTHR, pre);
+    conv_epilogue<WM, WN, WK, MT, NT, FL>(p, acc, accr, smem, tid, lane, wave, b0, y0, x0, n0, tx, ty, consumer, NTHR, pre, true);
 }
 
 // ---------------------------------------------------------------------------------------------------
