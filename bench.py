@@ -56,52 +56,90 @@ def synthetic_inputs(rank, world, device, per_rank=BATCH):
     return noise[lo:hi].to(device).contiguous(), ids[lo:hi].to(device)
 
 
-def pmc_traffic(kernel):
+PEAK_HBM_GBS = 8000.0             # same guide, HBM3E
+
+
+def pmc_traffic(kernel, pattern="*pmc_traffic.json"):
     """HBM bytes per launch of `kernel` from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
-    tools/pmc_forward.py, summarised by tools/pmc_summary.py with the guide's gfx950 correction).  A process cannot collect
-    hardware counters on itself, so the figure comes from the latest profiles/*pmc_traffic.json (the files are named per round and build, so the
-    last one by name; a checkout does not preserve modification times); null when there is none."""
+    tools/pmc_forward.py or tools/pmc_codec.py, summarised by tools/pmc_summary.py with the guide's gfx950 correction).  A process
+    cannot collect hardware counters on itself, so the figure comes from the latest profiles/<pattern> (named per round and build, so
+    the last one by name; a checkout does not preserve modification times); null when there is none.  The summary is keyed exactly like
+    this file's per-kernel table: the tile family (all its launch sites, Block-closing ones included), "<family>+fin" and
+    "<family> (plain)" for the two slices of a family."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), key=os.path.basename)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=os.path.basename)
     if not files:
         return None, None
     try:
         d = json.load(open(files[-1]))
         return d["per_kernel"][kernel]["traffic_bytes_per_launch"], os.path.basename(files[-1])
     except (KeyError, ValueError, OSError):
-        return None, None
+        return None, os.path.basename(files[-1])
 
 
-def _by_kernel(rows):
+def _family(kernel):
+    """Plan-entry kernel name -> tile family: a convolution that also closes its Block ('+fin') is the same kernel family."""
+    return kernel[:-4] if kernel.endswith("+fin") else kernel
+
+
+def _acc(by, key, r):
+    k = by.setdefault(key, dict(ms=0.0, flops=0.0, launches=0, bytes=0.0))
+    k["ms"] += r["ms"]; k["flops"] += r["flops_per_sample"] * r["rows"]; k["launches"] += 1; k["bytes"] += r.get("bytes", 0.0)
+
+
+def _by_kernel(rows, families=True):
     by = {}
     for r in rows:
-        k = by.setdefault(r["kernel"], dict(ms=0.0, flops=0.0, launches=0))
-        k["ms"] += r["ms"]; k["flops"] += r["flops_per_sample"] * r["rows"]; k["launches"] += 1
+        _acc(by, _family(r["kernel"]) if families else r["kernel"], r)
     return by
 
 
+def _slices(rows, fam):
+    """The family's launches split into the ones that close their Block and the plain ones (same keys as tools/pmc_summary.py)."""
+    by = {}
+    for r in rows:
+        if _family(r["kernel"]) == fam:
+            _acc(by, fam + ("+fin" if r["kernel"].endswith("+fin") else " (plain)"), r)
+    return by
+
+
+def _entry(v, traffic_key, pattern="*pmc_traffic.json"):
+    ach = v["flops"] / (v["ms"] * 1e-3) / 1e12
+    traffic, src = pmc_traffic(traffic_key, pattern)
+    alg = v["bytes"] / v["launches"] if v["bytes"] else None
+    us = 1e3 * v["ms"] / v["launches"]
+    return {"achieved": round(ach, 3), "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "launches": v["launches"], "avg_launch_us": round(us, 2),
+            "flops_per_launch_avg": v["flops"] / v["launches"], "algorithmic_bytes_per_launch": round(alg) if alg else None,
+            "traffic": traffic, "traffic_source": src,
+            "hbm_gbs_algorithmic": round(alg / us / 1e3, 1) if alg else None}
+
+
 def roofline(model, batch):
+    """The dominant kernel FAMILY of the forward (largest share of device time over all its launch sites -- a convolution that closes
+    its Block is the same kernel, so '+fin' launches count in) priced against the exact-fp32 MFMA peak.  `achieved`, `frac` and
+    `traffic` all cover the same launch set; `slices` splits it into Block-closing and plain launches."""
     rows = model.profile_ops(batch, repeats=20)
     by = _by_kernel(rows)
     name, dom = max(by.items(), key=lambda kv: kv[1]["ms"])
     total_ms = sum(v["ms"] for v in by.values())
     rows_timed = rows[0]["rows"]
-    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-    traffic, traffic_src = pmc_traffic(name)
-    return {
-        "bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (avg over the kernel's launch sites)",
-        "traffic_source": traffic_src,
+    e = _entry(dom, name)
+    out = {
+        "bound": "mfma", "kernel": name, "achieved": e["achieved"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": e["frac"],
+        "traffic": e["traffic"], "traffic_unit": "HBM bytes/launch, averaged over the same launch sites as achieved / frac",
+        "traffic_source": e["traffic_source"],
         "traffic_note": "HBM bytes from the committed rocprofv3 PMC passes named in traffic_source (a process cannot read its own counters); "
-                        "duration / achieved are measured live in this run",
-        "launches_per_forward": dom["launches"], "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
-        "flops_per_launch_avg": dom["flops"] / dom["launches"], "share_of_forward_time": round(dom["ms"] / total_ms, 3),
-        "forward_sum_of_kernels_ms": round(total_ms, 4),
+                        "duration / achieved are measured live in this run by HIP events on the launching stream",
+        "algorithmic_bytes_per_launch": e["algorithmic_bytes_per_launch"],
+        "launches_per_forward": dom["launches"], "avg_launch_us": e["avg_launch_us"], "flops_per_launch_avg": e["flops_per_launch_avg"],
+        "share_of_forward_time": round(dom["ms"] / total_ms, 3), "forward_sum_of_kernels_ms": round(total_ms, 4),
         "rows_per_launch": rows_timed, "chains": model.chains[0],
         "forward_tflops_all_kernels": round(model.flops_per_sample * rows_timed / (total_ms * 1e-3) / 1e12, 3),
+        "slices": {k: _entry(v, k) for k, v in _slices(rows, name).items()},
         "per_kernel": {k: dict(ms=round(v["ms"], 4), launches=v["launches"], tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 3))
                        for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])},
     }
+    return out
 
 
 # --------------------------------------------------------------------------------------------------- CPU baseline
@@ -225,6 +263,10 @@ def two_in_flight(model, noise, ids, device, steps=6):
     from flocoder_amd.sampling import euler_sampler
     twin = build_model(device)
     twin.load_state_dict(model.state_dict())
+    # two replicas meant to overlap share the device: both take the plan without cross-workgroup waits (fc_unet_set_shared; the caller's
+    # non-default streams would select it anyway).  Left on the exclusive plan the library would order the two trajectories one behind
+    # the other (the meeting guard), which is safe but not what this mode measures.
+    model.set_shared_device(True); twin.set_shared_device(True)
     shape = (BATCH,) + LATENT
     streams = [torch.cuda.Stream(device), torch.cuda.Stream(device)]
     models = [model, twin]
@@ -248,6 +290,10 @@ def two_in_flight(model, noise, ids, device, steps=6):
     torch.cuda.synchronize(device)
     t = time.perf_counter() - t0
     assert all(torch.isfinite(o).all() for o in outs) and torch.equal(outs[0], outs[1])     # both replicas integrate the same samples
+    assert model.meeting_launches == 0 and twin.meeting_launches == 0
+    model.check_errors(); twin.check_errors()
+    assert model.fused_tail_errors() == 0 and twin.fused_tail_errors() == 0
+    model.set_shared_device(None)            # back to the per-call decision (exclusive on the default stream)
     del twin
     return {"workload": f"64-step Euler, B={BATCH} per call, TWO calls in flight (two streams, two model replicas), {steps} calls timed",
             "samples_per_s": round(BATCH * steps / t, 1), "ms_per_call_amortised": round(1e3 * t / steps, 2),
@@ -308,12 +354,16 @@ def secondary(model, noise, ids, device):
     name, dom = max(by.items(), key=lambda kv: kv[1]["ms"])
     tot = sum(v["ms"] for v in by.values())
     ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    dec_traffic, dec_src = pmc_traffic(name, "*pmc_traffic_sdvae_decode.json")
     out["sdvae_decode"] = {
         "workload": f"SD-VAE decode 4x32x32 -> 3x256x256, B={BATCH} in chunks of {DECODE_CHUNK}, seeded random weights", "ms": round(t_dec * 1e3, 1),
         "images_per_s": round(BATCH / t_dec, 1), "gflop_per_image": round(gf_dec, 1), "tflops": round(BATCH * gf_dec / t_dec / 1e3, 1),
         "frac_of_fp32_mfma_peak": round(BATCH * gf_dec / t_dec / 1e3 / PEAK_FP32_MFMA_TFLOPS, 3),
         "roofline": {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "launches_per_decode": dom["launches"],
+                     "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": dec_traffic, "traffic_source": dec_src,
+                     "traffic_unit": "HBM bytes/launch (rocprofv3 PMC passes over tools/pmc_codec.py, same launch set)",
+                     "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]) if dom["bytes"] else None,
+                     "launches_per_decode": dom["launches"],
                      "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 1), "share_of_decode_time": round(dom["ms"] / tot, 3),
                      "decode_sum_of_kernels_ms": round(tot, 3), "rows_per_launch": DECODE_CHUNK}}
     out["sdvae_encode"] = {"workload": f"SD-VAE encode 3x256x256 -> 4x32x32, B={BATCH} in chunks of {DECODE_CHUNK}", "ms": round(t_enc * 1e3, 1),
@@ -324,6 +374,68 @@ def secondary(model, noise, ids, device):
     del vae
     out["train_step_stl_sd"] = train_step_secondary(device, dim=16, hw=16, batch=32, classes=10)
     out["train_step_flowers_sized"] = train_step_secondary(device, dim=32, hw=32, batch=64, classes=102)
+    out["config5_midi"] = config5(device)
+    return out
+
+
+def config5(device):
+    """BASELINE.json configs[4]: the VQGAN codec's encode / decode at the midi_vqgan.yaml shape (in=3, hidden 256,
+    3 downsamples, internal 128, 4x16x16 latents), B=64 at 128x128, and the mask-conditioned RK4 inpainting sampler at the
+    midi_inpainting.yaml flow shape (dim 8, latents 4x8x8, masks through the MaskEncoder).  Seeded default-initialised weights."""
+    from flocoder_amd.codecs import VQVAE
+    from flocoder_amd.inpainting import MaskEncoder, mask_blending
+    from flocoder_amd.sampling import generate_latents_rk4
+    from flocoder_amd.unet import Unet
+    out = {}
+    torch.manual_seed(5)
+    vq = VQVAE(in_channels=3, hidden_channels=256, num_downsamples=3, internal_dim=128, vq_embedding_dim=4, codebook_levels=4,
+               vq_num_embeddings=96).eval().to(device)
+    g = torch.Generator().manual_seed(55)
+    x = torch.rand(BATCH, 3, 128, 128, generator=g).to(device)
+    t_enc, z = _gpu_time(lambda: vq.encode(x), device, 3)
+    t_dec, y = _gpu_time(lambda: vq.decode(z), device, 3)
+    assert torch.isfinite(z).all() and torch.isfinite(y).all() and tuple(z.shape) == (BATCH, 4, 16, 16) and y.shape == x.shape
+    for tag, t, dec, inp, res in (("vqvae_encode", t_enc, False, x, z), ("vqvae_decode", t_dec, True, z, y)):
+        gf = vq.flops_per_sample(dec) / 1e9
+        rows = vq.profile_ops(inp, torch.empty_like(res), decode=dec, repeats=3)
+        by = _by_kernel(rows)
+        name, dom = max(by.items(), key=lambda kv: kv[1]["ms"])
+        tot = sum(v["ms"] for v in by.values())
+        e = _entry(dom, name, "*pmc_traffic_" + tag + ".json")
+        out[tag] = {"workload": f"VQVAE {'decode 4x16x16 -> 3x128x128' if dec else 'encode 3x128x128 -> 4x16x16'} (midi_vqgan.yaml shape), B={BATCH} in one batch",
+                    "ms": round(t * 1e3, 2), "images_per_s": round(BATCH / t, 1), "gflop_per_image": round(gf, 1),
+                    "tflops": round(BATCH * gf / t / 1e3, 1), "frac_of_fp32_mfma_peak": round(BATCH * gf / t / 1e3 / PEAK_FP32_MFMA_TFLOPS, 3),
+                    "launches": len(rows), "sum_of_kernels_ms": round(tot, 3),
+                    "roofline": dict(bound="mfma", kernel=name, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", share_of_time=round(dom["ms"] / tot, 3), **e),
+                    "per_kernel": {k: dict(ms=round(v["ms"], 4), launches=v["launches"], tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2))
+                                   for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])}}
+    del vq
+    # inpainting sampler: flow dim 8 on 4x8x8 latents (midi_inpainting.yaml: 128x128 gray rolls, 4 downsamples), mask-conditioned
+    torch.manual_seed(6)
+    unet = Unet(dim=8, dim_mults=(1, 2, 4, 8), channels=4, n_classes=0, mask_cond=True).eval().to(device)
+    me = MaskEncoder().eval().to(device)
+    pix = torch.zeros(BATCH, 1, 128, 128)
+    for b in range(BATCH):                                  # rectangular holes of varying size / position (inpainting.py's simplest generator)
+        h0, w0 = 8 + (b * 7) % 64, 8 + (b * 13) % 64
+        pix[b, :, h0:h0 + 24 + b % 32, w0:w0 + 24 + (3 * b) % 32] = 1.0
+    pix = pix.to(device)
+    src_lat = torch.randn(BATCH, 4, 8, 8, generator=g).to(device)
+    noise = torch.randn(BATCH, 4, 8, 8, generator=g).to(device)
+    n_steps = RK4_STEPS
+
+    def run():
+        with torch.no_grad():
+            mask = me(pix)
+            source = mask_blending(src_lat, mask, noise)
+            return generate_latents_rk4(unet, (BATCH, 4, 8, 8), n_steps, {"mask_cond": mask}, 0.0, source=source)[0]
+    t_inp, lat = _gpu_time(run, device, 2)
+    assert torch.isfinite(lat).all()
+    evals = (n_steps - 1) * 4
+    out["inpaint_rk4"] = {"workload": f"mask-conditioned inpainting sampler: MaskEncoder + blend + {n_steps}-step RK4 ({evals} evaluations), U-Net dim 8 "
+                                      f"mask_cond, latents 4x8x8, B={BATCH}", "ms": round(t_inp * 1e3, 1), "samples_per_s": round(BATCH / t_inp, 1),
+                          "us_per_evaluation": round(1e6 * t_inp / evals, 1), "gflop_per_sample_per_evaluation": round(unet.flops_per_sample / 1e9, 4),
+                          "tflops": round(BATCH * evals * unet.flops_per_sample / t_inp / 1e12, 3), "plan_entries_per_forward": unet.launches_per_forward,
+                          "note": "0.06 GFLOP per evaluation over ~90 launches: launch-latency bound by construction, not an MFMA or HBM roofline case"}
     return out
 
 
@@ -375,6 +487,8 @@ def main():
     torch.cuda.set_device(device)
 
     model = build_model(device)
+    if os.environ.get("FLOCODER_AMD_SINGLE_GPU") and world > 1:
+        model.set_shared_device(True)                # the rehearsal puts every rank's process on one GPU: not an exclusive device
     moved = fdist.broadcast_weights(model, src=0)    # the one collective: frozen weights over xGMI
     comm = None
     if world > 1:
@@ -406,6 +520,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(out).all()
+    model.check_errors()                             # (every euler_sampler call above checked already: Unet.integrate(check=True))
     assert model.fused_tail_errors() == 0, "a fused Block tail timed out waiting for its sample group: results invalid"
 
     line = {
@@ -421,12 +536,14 @@ def main():
                    # conditioning entries are replaced by a table computed once per call
                    "plan_entries_per_forward": model.launches_per_forward,
                    "kernel_launches_per_forward": model.launches_per_forward + 9,
-                   "kernel_launches_per_euler_step": model.launches_per_forward + 9 - 2},
+                   "kernel_launches_per_euler_step": model.launches_per_forward + 9 - 2,
+                   "plan": "exclusive device (cross-workgroup Block tails)" if model.meeting_launches else "shared device (no cross-workgroup waits)"},
     }
     line["ode_tflops"] = round(line["value"] * model.flops_per_sample * N_EULER / 1e12, 3)
     line["frac_of_fp32_mfma_peak_end_to_end"] = round(line["ode_tflops"] / (PEAK_FP32_MFMA_TFLOPS * world), 4)
     if comm:
-        line["rccl_ranks"] = comm["ranks_counted_by_allreduce"]
+        # the count is what the collective library itself summed; it is RCCL's only when the backend is "nccl" (= RCCL on ROCm)
+        line["rccl_ranks" if comm["backend"] == "nccl" else comm["backend"] + "_ranks"] = comm["ranks_counted_by_allreduce"]
         line["comm"] = comm
     sec = {}
     if not args.no_secondary:

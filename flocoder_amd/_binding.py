@@ -53,6 +53,10 @@ SIGNATURES = {
     "fc_debug_conv": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _pi, _pf, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _pf, _vp]),
     "fc_debug_set_fused_tail": (_i, [_i]),
     "fc_unet_fused_tail_errors": (_i, [_vp, C.POINTER(_i)]),
+    "fc_unet_set_shared": (_i, [_vp, _i]),
+    "fc_unet_meeting_launches": (_i, [_vp]),
+    "fc_unet_check": (_i, [_vp, _vp, _i]),
+    "fc_debug_unet_break_meeting": (_i, [_vp]),
     "fc_unet_train_reserve": (_i, [_vp, _i, _i, _i]),
     "fc_unet_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "fc_unet_backward_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _vp]),
@@ -63,6 +67,7 @@ SIGNATURES = {
     "fc_mse_loss_grad": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "fc_grad_clip_coef": (_i, [_vp, _i64, _vp, _i64, C.c_float, _vp, _vp, _vp]),
     "fc_adam_ema_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, C.c_float, C.c_float, C.c_float, C.c_float, _i, C.c_float, _i, _vp]),
+    "fc_adam_ema_step_guarded": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, C.c_float, C.c_float, C.c_float, C.c_float, _i, C.c_float, _i, _vp, _vp]),
     "fc_debug_conv_wgrad": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "fc_vae_create": (_i, [_i, C.POINTER(_vp)]),
     "fc_vae_destroy": (None, [_vp]),
@@ -90,6 +95,11 @@ SIGNATURES = {
     "fc_vqvae_decode": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "fc_vqvae_flops_per_sample": (C.c_double, [_vp, _i]),
     "fc_vae_op_info": (_i, [_vp, _i, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_double)]),
+    "fc_vae_op_bytes": (_i, [_vp, _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "fc_unet_op_bytes": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "fc_vqvae_plan_launches": (_i, [_vp, _i]),
+    "fc_vqvae_op_info": (_i, [_vp, _i, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "fc_vqvae_profile_ops": (_i, [_vp, _i, _vp, _vp, _i, _i, C.POINTER(C.c_float), _i, _vp]),
     "fc_vae_profile_ops": (_i, [_vp, _i, _vp, _vp, _i, _i, C.POINTER(C.c_float), _i, _vp]),
     "fc_rvq_quantize": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "fc_mask_encoder_create": (_i, [_i, C.POINTER(_vp)]),

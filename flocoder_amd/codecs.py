@@ -242,7 +242,12 @@ class SD_VAE_Wrapper(nn.Module):
         ms = (C.c_float * len(ops))()
         B.check(lib.fc_vae_profile_ops(h, int(decode), B.ptr(inp.contiguous()), B.ptr(out), inp.shape[0], repeats, ms, len(ops),
                                        B.current_stream(inp.device)))
-        return [dict(kernel=k, module=m, flops_per_sample=f, ms=float(ms[i]), rows=inp.shape[0]) for i, (k, m, f) in enumerate(ops)]
+        rows = []
+        for i, (k, m, f) in enumerate(ops):
+            bp, bf = C.c_double(), C.c_double()
+            B.check(lib.fc_vae_op_bytes(h, int(decode), i, C.byref(bp), C.byref(bf)))
+            rows.append(dict(kernel=k, module=m, flops_per_sample=f, ms=float(ms[i]), rows=inp.shape[0], bytes=bp.value * inp.shape[0] + bf.value))
+        return rows
 
 
 class _NoiseInjectionParams(nn.Module):
@@ -489,6 +494,23 @@ class VQVAE(nn.Module):
 
     def flops_per_sample(self, decode=True) -> float:
         return float(B.lib().fc_vqvae_flops_per_sample(self._handle, int(decode))) if self._handle else 0.0
+
+    def profile_ops(self, inp: torch.Tensor, out: torch.Tensor, decode=True, repeats: int = 5):
+        """Per-launch device milliseconds of the decode (or encode) plan for the batch ``inp`` -> ``out`` with each launch's kernel
+        family, algorithmic FLOPs per sample and algorithmic HBM bytes (bench.py's config-5 leg).  Run decode()/encode() at this
+        batch first so the plan exists."""
+        lib, h = B.lib(), self._handle
+        n = lib.fc_vqvae_plan_launches(h, int(decode)) if h else 0
+        ms = (C.c_float * max(n, 1))()
+        B.check(lib.fc_vqvae_profile_ops(h, int(decode), B.ptr(inp.contiguous()), B.ptr(out), inp.shape[0], repeats, ms, n,
+                                         B.current_stream(inp.device)))
+        rows = []
+        for i in range(n):
+            k, m, f, bp, bf = C.c_char_p(), C.c_char_p(), C.c_double(), C.c_double(), C.c_double()
+            B.check(lib.fc_vqvae_op_info(h, int(decode), i, C.byref(k), C.byref(m), C.byref(f), C.byref(bp), C.byref(bf)))
+            rows.append(dict(kernel=k.value.decode(), module=m.value.decode(), flops_per_sample=f.value, ms=float(ms[i]), rows=inp.shape[0],
+                             bytes=bp.value * inp.shape[0] + bf.value))
+        return rows
 
 
 def _read_weights(path: str) -> Dict[str, torch.Tensor]:

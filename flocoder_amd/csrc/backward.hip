@@ -916,10 +916,17 @@ __global__ void __launch_bounds__(256) flow_prepare_kernel(const float* src, con
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         t_out[b] = tt;
         time_out[b] = __fmul_rn(tt, t_scale);
-        if (ids && flag) { const long long id = ids[b]; if (id < 0 || id >= n_classes) *flag = 1; }
+        if (ids && flag) { const long long id = ids[b]; if (id < 0 || id >= n_classes) atomicOr(flag, 1); }
+    }
+    // a pairing entry outside [0, B) would be an out-of-bounds read (target[ot_indices] raises IndexError in torch): the row falls back to
+    // its own target and the sticky flag's bit 1 tells the host
+    long long pb = perm ? perm[b] : b;
+    if (pb < 0 || pb >= (long long)gridDim.y) {
+        if (flag && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(flag, 2);
+        pb = b;
     }
     const float* s = src + (size_t)b * per;
-    const float* g = tgt + (size_t)(perm ? perm[b] : b) * per;
+    const float* g = tgt + (size_t)pb * per;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < per; i += gridDim.x * 256) {
         const float sv = s[i], gv = g[i];
         x[(size_t)b * per + i] = (1.0f - tt) * sv + tt * gv;
@@ -992,7 +999,8 @@ int grad_clip_coef_launch(const float* g, size_t n0, const float* g2, size_t n1,
 // Adam as torch.optim.Adam computes it (no weight decay, no amsgrad), on g*coef, followed by the EMA recurrence of train_flow.py:46-54.
 __global__ void __launch_bounds__(256) adam_ema_kernel(float* p, const float* g, float* m, float* v, float* ema, size_t n, const float* coef_ptr,
                                                        float lr_over_bc1, float b1, float b2, float inv_sqrt_bc2, float eps, float decay,
-                                                       float one_minus_decay, int do_adam) {
+                                                       float one_minus_decay, int do_adam, const int* skip) {
+    if (skip && *skip) return;   // a step whose inputs were flagged invalid (class id / pairing out of range) updates nothing
     const float coef = coef_ptr ? *coef_ptr : 1.0f;
     for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         float pv = p[i];
@@ -1009,13 +1017,13 @@ __global__ void __launch_bounds__(256) adam_ema_kernel(float* p, const float* g,
     }
 }
 int adam_ema_launch(float* p, const float* g, float* m, float* v, float* ema, size_t n, const float* coef_dev, float lr, float b1, float b2,
-                    float eps, int step, float ema_decay, int do_adam, hipStream_t s) {
+                    float eps, int step, float ema_decay, int do_adam, hipStream_t s, const int* skip_flag_dev) {
     if (!n) return FC_OK;
     const double bc1 = 1.0 - std::pow((double)b1, step), bc2 = 1.0 - std::pow((double)b2, step);
     const float lr_over_bc1 = do_adam ? (float)((double)lr / bc1) : 0.f;
     const float inv_sqrt_bc2 = do_adam ? (float)(1.0 / std::sqrt(bc2)) : 0.f;
     hipLaunchKernelGGL(adam_ema_kernel, dim3(grid_1d(n, 2048)), dim3(256), 0, s, p, g, m, v, ema, n, coef_dev, lr_over_bc1, b1, b2, inv_sqrt_bc2,
-                       eps, ema_decay, (float)(1.0 - (double)ema_decay), do_adam);
+                       eps, ema_decay, (float)(1.0 - (double)ema_decay), do_adam, skip_flag_dev);
     FC_HIP(hipGetLastError());
     return FC_OK;
 }

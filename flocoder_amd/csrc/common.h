@@ -353,7 +353,7 @@ int mse_loss_grad_launch(const float* v, const float* tgt, float* dv, float* los
 int grad_clip_coef_launch(const float* g, size_t n0, const float* g2, size_t n1, float max_norm, float* out2 /*{norm, coef}*/, float* ws /*256*/,
                           hipStream_t s);
 int adam_ema_launch(float* p, const float* g, float* m, float* v, float* ema, size_t n, const float* coef_dev, float lr, float b1, float b2,
-                    float eps, int step, float ema_decay, int do_adam, hipStream_t s);
+                    float eps, int step, float ema_decay, int do_adam, hipStream_t s, const int* skip_flag_dev = nullptr);
 
 // ---- OT (ot.hip) ------------------------------------------------------------------------------
 int ot_launch(const float* src, const float* tgt, int B, int64_t D, float* dist, int64_t* perm, hipStream_t s);

@@ -385,7 +385,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                     unsigned long long v = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     int spins = 0;
                     while ((unsigned)(v >> 32) != epoch) {
-                        if (++spins > (1 << 20)) { if (a.fin.err) *a.fin.err = 1; break; }
+                        // A wait that gives up must not leave finite garbage behind: the statistic becomes NaN, so every value of this
+                        // sample group is NaN from here to the sampler's output, and the handle's error word is set for the host
+                        // (fc_unet_check / the next call on the handle return FC_E_STATE).
+                        if (++spins > (1 << 20)) { if (a.fin.err) *a.fin.err = 1; v = 0x7fc00000ull; break; }
                         __builtin_amdgcn_s_sleep(2);
                         v = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
@@ -539,6 +542,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
 }
 
 int conv_pipe_launch(const ConvDev& d, int tile, int grid, size_t lds, hipStream_t s);
+int conv_pipe_blocks_per_cu(const ConvDev& d, int tile, size_t lds);   // occupancy of the instantiation that launch would use (0: unknown)
 int conv_pipe_init();
 bool conv_pipe_supports_ks(int ks);
 const float* conv_zeros16();

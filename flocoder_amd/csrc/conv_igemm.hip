@@ -354,11 +354,19 @@ static int conv_geometry(const ConvArgs& a, int tile, bool pipe, ConvDev* d, Con
             const int cpgt1 = a.Cout < t.BN ? a.Cout : t.BN, NPG1 = a.Cout >= t.BN ? a.Cout / t.BN : 1;
             g->T1 = (TB > 1 ? 1 : p.tiles_x * p.tiles_y) * NPG1;
             g->n_t1 = (float)(p.rps * cpgt1);
-            // two 512-thread workgroups share a CU only when both fit in LDS (and the kernels stay under 128 VGPRs: NT = 1 tiles)
-            const int per_cu = (g->lds <= 80 * 1024 && t.MTNT == 1 && a.KS <= 3) ? 2 : 1;   // those instantiations stay <= 110 VGPRs
             p.fin_local = g->fin_local = (g->T == 1) ? 1 : 0;   // whole groups per tile: nothing to meet for
             if (p.fin_local) p.gsz = 1;
-            else if (p.nblocks > conv_cu_count() * per_cu) return fail(FC_E_SHAPE, "conv: fused tail needs the whole grid resident");
+            else {
+                // Workgroups that wait for each other must all be resident.  How many of THIS instantiation one CU holds (registers,
+                // waves, LDS) is asked of the runtime per flavour -- round 2 assumed "two when the LDS fits and NT = 1", an unverified
+                // register-count claim -- and never counted above two.  This proves residency on a device the launch has to itself;
+                // what keeps other work of this process away from it is the meeting guard in unet.hip, and a handle that shares the
+                // device with anything else takes the plan without meetings (fc_unet_set_shared).
+                int per_cu = conv_pipe_blocks_per_cu(p, tile, g->lds);
+                if (per_cu <= 0) return fail(FC_E_SHAPE, "conv: fused tail: occupancy of the kernel unknown");
+                if (per_cu > 2) per_cu = 2;
+                if (p.nblocks > conv_cu_count() * per_cu) return fail(FC_E_SHAPE, "conv: fused tail needs the whole grid resident");
+            }
         }
         return FC_OK;
     }

@@ -17,7 +17,10 @@
 // A loader thread's patch elements are the same pixels for every chunk (only the channel base moves): their source
 // offsets live in registers and the per-(sample, channel) affine table is built once for all Cin.
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <string>
+#include <tuple>
 #include "conv_dev.h"
 #include "stats_dev.h"
 
@@ -524,36 +527,43 @@ static int lean_attr_wide1() {
 #undef X
     return FC_OK;
 }
+
+// Either launches `kernel` or, when `occ` is given, asks the runtime how many workgroups of it one CU holds at this LDS size (the
+// fused tail's residency condition is derived from that, per instantiation -- conv_igemm.hip).
+template <class K>
+static int launch_or_query(K kernel, int nthr, const ConvDev& d, int grid, size_t lds, hipStream_t s, int* occ) {
+    if (occ) {
+        FC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, kernel, nthr, lds));
+        return FC_OK;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(nthr), lds, s, d);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
 template <int FL>
-static int lean_launch_wide1(const ConvDev& d, int tile, int grid, size_t lds, hipStream_t s) {
+static int lean_launch_wide1(const ConvDev& d, int tile, int grid, size_t lds, hipStream_t s, int* occ) {
     switch (tile) {
 #define X(T, WM, WN, WK, MT, NT, CC, K, NL)                                                                                       \
     case T:                                                                                                                       \
         if (d.P * (CC / 4) > 64 * NL * kLeanNPL) return -1;                                                                       \
-        hipLaunchKernelGGL((conv_pipe_kernel<WM, WN, WK, MT, NT, CC, kLeanNPL, K, NL, FL>), dim3(grid), dim3(256 + 64 * NL), lds, s, d); \
-        break;
+        return launch_or_query((conv_pipe_kernel<WM, WN, WK, MT, NT, CC, kLeanNPL, K, NL, FL>), 256 + 64 * NL, d, grid, lds, s, occ);
         FC_LEAN_TILES_WIDE1(X)
 #undef X
         default: return -1;
     }
-    FC_HIP(hipGetLastError());
-    return FC_OK;
 }
 
 template <int KS, int FL>
-static int lean_launch(const ConvDev& d, int tile, int grid, size_t lds, hipStream_t s) {
+static int lean_launch(const ConvDev& d, int tile, int grid, size_t lds, hipStream_t s, int* occ) {
     switch (tile) {
 #define X(T, WM, WN, WK, MT, NT, CC, K, NL)                                                                                       \
     case T:                                                                                                                       \
         if (d.P * (CC / 4) > 64 * NL * kLeanNPL) return -1;    /* more window elements per staging thread than a lean kernel keeps */ \
-        hipLaunchKernelGGL((conv_pipe_kernel<WM, WN, WK, MT, NT, CC, kLeanNPL, K, NL, FL>), dim3(grid), dim3(256 + 64 * NL), lds, s, d); \
-        break;
+        return launch_or_query((conv_pipe_kernel<WM, WN, WK, MT, NT, CC, kLeanNPL, K, NL, FL>), 256 + 64 * NL, d, grid, lds, s, occ);
         FC_LEAN_TILES(X, KS)
 #undef X
         default: return -1;      // no lean flavour of this tile
     }
-    FC_HIP(hipGetLastError());
-    return FC_OK;
 }
 
 int conv_pipe_init() {
@@ -579,19 +589,17 @@ int conv_pipe_init() {
 bool conv_pipe_supports_ks(int ks) { return ks == 1 || ks == 2 || ks == 3 || ks == 5; }
 
 template <int KS>
-static int pipe_launch_ks(const ConvDev& d, int tile, int grid, size_t lds, hipStream_t s) {
+static int pipe_launch_ks(const ConvDev& d, int tile, int grid, size_t lds, hipStream_t s, int* occ) {
     switch (tile) {
 #define X(T, WM, WN, WK, MT, NT, CC, K, NL) \
-    case T: hipLaunchKernelGGL((conv_pipe_kernel<WM, WN, WK, MT, NT, CC, 8, K, NL>), dim3(grid), dim3(256 + 64 * NL), lds, s, d); break;
+    case T: return launch_or_query((conv_pipe_kernel<WM, WN, WK, MT, NT, CC, 8, K, NL>), 256 + 64 * NL, d, grid, lds, s, occ);
         FC_PIPE_TILES(X, KS)
 #undef X
         default: return fail(FC_E_ARG, "conv: bad tile id");
     }
-    FC_HIP(hipGetLastError());
-    return FC_OK;
 }
 
-int conv_pipe_launch(const ConvDev& d, int tile, int grid, size_t lds, hipStream_t s) {
+static int conv_pipe_dispatch(const ConvDev& d, int tile, int grid, size_t lds, hipStream_t s, int* occ) {
     static const bool lean = [] { const char* e = std::getenv("FLOCODER_AMD_LEAN_KERNELS"); return !(e && std::string(e) == "0"); }();
     if (lean) {                  // the smallest flavour that covers this launch
         const bool small_tile = tile == TILE_M32N32K4;
@@ -602,25 +610,46 @@ int conv_pipe_launch(const ConvDev& d, int tile, int grid, size_t lds, hipStream
                          ((d.a.fin.gamma && !d.fin_local) ? FL_MEET : 0);
         int r = -1;
         if (d.a.KS == 3) {
-#define X(F) if (r == -1 && need == (F)) r = lean_launch<3, (F)>(d, tile, grid, lds, s);
+#define X(F) if (r == -1 && need == (F)) r = lean_launch<3, (F)>(d, tile, grid, lds, s, occ);
             FC_LEAN_FLAVOURS_3(X)
 #undef X
         } else if (d.a.KS == 1) {
-#define X(F) if (r == -1 && need == (F)) { r = lean_launch<1, (F)>(d, tile, grid, lds, s); if (r == -1) r = lean_launch_wide1<(F)>(d, tile, grid, lds, s); }
+#define X(F) if (r == -1 && need == (F)) { r = lean_launch<1, (F)>(d, tile, grid, lds, s, occ); if (r == -1) r = lean_launch_wide1<(F)>(d, tile, grid, lds, s, occ); }
             FC_LEAN_FLAVOURS_1(X)
 #undef X
         } else if (d.a.KS == 2 && need == 0) {
-            r = lean_launch<2, 0>(d, tile, grid, lds, s);
+            r = lean_launch<2, 0>(d, tile, grid, lds, s, occ);
         }
         if (r != -1) return r;
     }
     switch (d.a.KS) {
-        case 1: return pipe_launch_ks<1>(d, tile, grid, lds, s);
-        case 2: return pipe_launch_ks<2>(d, tile, grid, lds, s);
-        case 3: return pipe_launch_ks<3>(d, tile, grid, lds, s);
-        case 5: return pipe_launch_ks<5>(d, tile, grid, lds, s);
+        case 1: return pipe_launch_ks<1>(d, tile, grid, lds, s, occ);
+        case 2: return pipe_launch_ks<2>(d, tile, grid, lds, s, occ);
+        case 3: return pipe_launch_ks<3>(d, tile, grid, lds, s, occ);
+        case 5: return pipe_launch_ks<5>(d, tile, grid, lds, s, occ);
     }
     return fail(FC_E_SHAPE, "conv: kernel size not instantiated in the pipelined kernel");
+}
+
+int conv_pipe_launch(const ConvDev& d, int tile, int grid, size_t lds, hipStream_t s) { return conv_pipe_dispatch(d, tile, grid, lds, s, nullptr); }
+
+// Workgroups of the instantiation this launch would go to that ONE CU holds at once (registers, waves and LDS as the runtime counts
+// them), cached per (tile, kernel size, flavour mask, LDS bytes).  0 = the query failed.
+int conv_pipe_blocks_per_cu(const ConvDev& d, int tile, size_t lds) {
+    static std::map<std::tuple<int, int, int, size_t>, int> cache;
+    static std::mutex mu;
+    const int mask = (d.a.fin.gamma ? FL_FIN : 0) | (d.a.res_out ? FL_RES : 0) | (d.a.stats_post ? FL_POST : 0) | (d.any_xf ? FL_XF : 0) |
+                     (d.a.s1.C ? FL_CAT : 0) | (d.stamps ? FL_STAMP : 0) | (d.a.stats_out ? FL_STATS : 0) | (d.a.fin.gn1_out ? FL_GN1 : 0) |
+                     ((d.a.out_act || d.a.add) ? FL_POSTOP : 0) | ((d.o_out < 0 || d.a.fin.raw) ? FL_NARROW : 0) | (d.TB > 1 ? FL_MULTI : 0) |
+                     ((d.a.fin.gamma && !d.fin_local) ? FL_MEET : 0);
+    const auto key = std::make_tuple(tile, d.a.KS, mask, lds);
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    int occ = 0;
+    if (conv_pipe_dispatch(d, tile, 1, lds, nullptr, &occ) != FC_OK) occ = 0;
+    cache[key] = occ;
+    return occ;
 }
 
 }  // namespace fc

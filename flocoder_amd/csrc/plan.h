@@ -55,6 +55,7 @@ struct Plan {                 // one launch plan + activation arena for up to ma
     int side_ops = 0, join_at = 0;   // ops [0, side_ops) depend on nothing the ops [side_ops, join_at) produce or read: they may run beside them
     std::vector<std::string> op_kernel, op_what;  // parallel to ops: kernel family, reference module it serves
     std::vector<double> op_flops;                  // algorithmic FLOPs per sample of that launch
+    std::vector<double> op_bytes_ps, op_bytes_fixed;   // algorithmic HBM bytes of that launch: per sample (activations in + out, each once) and per launch (weights); 0 = not stated
     std::vector<void*> allocs;
     double flops = 0.0;
     float *t_emb = nullptr, *ss = nullptr;
@@ -63,7 +64,8 @@ struct Plan {                 // one launch plan + activation arena for up to ma
     FuseRec fuse;
     std::vector<TapeItem> tape;
     Act x0, head;                                   // init_conv output, final_res_block output
-    std::vector<int*> fin_err;                      // device flags of the fused Block tails (a timed-out wait sets one)
+    int n_meet = 0;                                 // launches whose workgroups wait for each other (fused Block tails across workgroups)
+    std::vector<unsigned*> fin_sync;                // their arrival counters (fc_debug_unet_break_meeting)
     void release() {
         for (void* p : allocs) (void)hipFree(p);
         *this = Plan();
@@ -178,10 +180,11 @@ struct PlanBuilder {
     int B = 0;  // max batch
     int err = FC_OK;
     std::string scope;  // reference module the ops being emitted belong to
+    int* fin_err_word = nullptr;   // device word a timed-out fused tail sets (owned by the handle the plan belongs to)
 
     // guard: 0 always | 1 only when the call has a mask | 2 only when it runs mask_fusion_conv | 3 only when it has NO mask | 4 mask but no fusion
     int guard = 0;
-    void push(Op op, const std::string& kernel, double flops = 0.0) {
+    void push(Op op, const std::string& kernel, double flops = 0.0, double bytes_ps = 0.0, double bytes_fixed = 0.0) {
         if (guard) {
             const int g = guard;
             Op inner = std::move(op);
@@ -194,6 +197,8 @@ struct PlanBuilder {
         pl->op_kernel.push_back(kernel);
         pl->op_what.push_back(scope);
         pl->op_flops.push_back(flops);
+        pl->op_bytes_ps.push_back(bytes_ps);
+        pl->op_bytes_fixed.push_back(bytes_fixed);
         pl->flops += flops;
     }
     float* dmalloc(size_t floats) {
@@ -223,6 +228,23 @@ struct PlanBuilder {
         return x;
     }
 
+    // Algorithmic HBM bytes of one convolution launch: every input / output / residual element once per sample, the
+    // weights once per launch -- what a kernel with perfect on-chip reuse would move.
+    static double conv_bytes_ps(const ConvArgs& a) {
+        double e = (double)a.Hs * a.Ws * a.Cin + (double)a.H * a.W * a.Cout;
+        if (a.res_out) e += (double)a.H * a.W * a.Cout;
+        if (a.add) e += (double)a.H * a.W * a.Cout;
+        if (a.fin.res) e += (double)a.H * a.W * a.Cout;
+        if (a.fin.raw) e += (double)a.H * a.W * a.Cout;
+        if (a.w_batch_stride) e += (double)a.KS * a.KS * a.Cin * a.Cout;
+        return 4.0 * e;
+    }
+    static double conv_bytes_fixed(const ConvArgs& a) {
+        double e = a.w_batch_stride ? 0.0 : (double)a.KS * a.KS * a.Cin * a.Cout;
+        if (a.res_w) e += (double)a.Cin * a.Cout;
+        return 4.0 * e;
+    }
+
     // Emits one implicit-GEMM launch (plus a standalone statistics pass when the output has < 16 pixels per sample).
     // `want_G` > 0 asks for GroupNorm partials of the output; returns them in *st.
     void conv(ConvArgs a, const Act& out, int want_G, Stat* st) {
@@ -237,7 +259,8 @@ struct PlanBuilder {
         const int tile = g.tile;
         double fl = 2.0 * out.H * out.W * a.KS * a.KS * (double)a.Cin * a.Cout;
         if (a.res_out) fl += 2.0 * out.H * out.W * (double)a.Cin * a.Cout;
-        push([a, tile](const FwdCtx& c, hipStream_t s) { ConvArgs b = a; b.B = c.B; return conv_launch(b, tile, s); }, kTileNames[tile], fl);
+        push([a, tile](const FwdCtx& c, hipStream_t s) { ConvArgs b = a; b.B = c.B; return conv_launch(b, tile, s); }, kTileNames[tile], fl,
+             conv_bytes_ps(a), conv_bytes_fixed(a));
         if (fused && st->T > 16) {   // many tiles per sample (large images): fold the partials once instead of in every consumer workgroup
             const Stat raw = *st;
             *st = stat(want_G, 1, raw.n_t * (float)raw.T);
@@ -263,6 +286,8 @@ struct PlanBuilder {
         if ((out.H * out.W) % 16) return false;
         a.Gout = G; a.stats_out = reinterpret_cast<float*>(16);
         a.fin.gamma = gamma; a.fin.beta = beta; a.fin.res = res;
+        if (want_gn1) a.fin.gn1_out = reinterpret_cast<float*>(16);   // placeholders: the geometry (and the occupancy query behind the
+        if (raw) a.fin.raw = reinterpret_cast<float*>(16);            // residency check) must see the flavour the launch will use
         ConvGeom g;
         if (conv_plan(a, TILE_AUTO, &g) != FC_OK || !g.pipe) return false;
         if (only_local && !g.fin_local) return false;    // the cross-workgroup meeting costs what the finalize launch costs; the local form is free
@@ -278,11 +303,12 @@ struct PlanBuilder {
         if (err) return false;
         if (hipMemset(a.fin.gran, 0, ngran * sizeof(unsigned long long)) != hipSuccess) { err = fail(FC_E_HIP, "hipMemset failed"); return false; }   // tag 0 = never a live epoch
         a.fin.sync = sync;
-        a.fin.err = reinterpret_cast<int*>(sync + g.groups);
-        pl->fin_err.push_back(a.fin.err);
+        a.fin.err = fin_err_word ? fin_err_word : reinterpret_cast<int*>(sync + g.groups);   // the handle's error word (one per object)
+        if (!g.fin_local) { ++pl->n_meet; pl->fin_sync.push_back(sync); }
         const int tile = g.tile;
         const double fl = 2.0 * out.H * out.W * a.KS * a.KS * (double)a.Cin * a.Cout;
-        push([a, tile](const FwdCtx& c, hipStream_t s) { ConvArgs b = a; b.B = c.B; return conv_launch(b, tile, s); }, std::string(kTileNames[tile]) + "+fin", fl);
+        push([a, tile](const FwdCtx& c, hipStream_t s) { ConvArgs b = a; b.B = c.B; return conv_launch(b, tile, s); }, std::string(kTileNames[tile]) + "+fin", fl,
+             conv_bytes_ps(a), conv_bytes_fixed(a));
         return true;
     }
 
@@ -340,6 +366,30 @@ struct PlanBuilder {
 inline int run_plan(const Plan& pl, const FwdCtx& c, hipStream_t s) {
     for (const Op& op : pl.ops) FC_TRY(op(c, s));
     return FC_OK;
+}
+
+// Measurement: every launch of `pl` timed alone -- `repeats` back-to-back launches between two HIP events on `s` (ops only read their
+// inputs, so repeating one is idempotent).  ms_out[i] = average milliseconds of op i.  Synchronises.
+inline int profile_plan(const Plan& pl, const FwdCtx& c, int repeats, float* ms_out, int n_out, hipStream_t s) {
+    const int n = (int)pl.ops.size();
+    if (n_out < n) return fail(FC_E_ARG, "profile_ops: output array too small");
+    FC_TRY(run_plan(pl, c, s));   // warm: every buffer holds finite data
+    std::vector<hipEvent_t> ev(2 * n);
+    for (auto& e : ev) FC_HIP(hipEventCreate(&e));
+    int rc = FC_OK;
+    for (int i = 0; i < n && rc == FC_OK; ++i) {
+        (void)hipEventRecord(ev[2 * i], s);
+        for (int r = 0; r < repeats && rc == FC_OK; ++r) rc = pl.ops[i](c, s);
+        (void)hipEventRecord(ev[2 * i + 1], s);
+    }
+    (void)hipStreamSynchronize(s);
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
+        ms_out[i] = ms / repeats;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return rc;
 }
 
 }  // namespace fc

@@ -10,6 +10,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <unordered_map>
@@ -130,7 +131,9 @@ static bool fused_tail_enabled() {
 // ------------------------------------------------------------------------------------------- plan builder
 struct Builder : PlanBuilder {
     fc_unet* u = nullptr;
-    Builder(fc_unet* u_, Plan* pl_, int B_) : u(u_) { pl = pl_; B = B_; }
+    Builder(fc_unet* u_, Plan* pl_, int B_) : u(u_) { pl = pl_; B = B_; fin_err_word = u_->dev_err; }
+    // launches that wait for other workgroups: only on a device this handle has to itself, and never with two chains on two streams
+    bool meeting_ok() const { return fused_tail_enabled() && !u->shared && u->nchains < 2; }
 
     // ResnetBlock (unet.py:76-96): conv1 [+res_conv] | conv2 with GN+FiLM+SiLU folded into its loader | finalize.
     Act resblock(const std::string& p, const Act& x, const Act* skip, int cout, bool want_gn1, Stat* gn1) {
@@ -167,9 +170,9 @@ struct Builder : PlanBuilder {
         // FLOCODER_AMD_TRAIN_FUSED_TAIL=1.  Off by default -- measured on one box (r02): stl_sd step 3.515 ms fused against 3.446 ms
         // with conv + finalize, flowers-sized step 7.91 against 7.92: at these small grids the meeting costs what the launch it saves does.
         static const bool train_fused = [] { const char* e = std::getenv("FLOCODER_AMD_TRAIN_FUSED_TAIL"); return e && std::string(e) == "1"; }();
-        const bool fused = (!u->keep_all || train_fused) && (fused_tail_enabled() || !no_local) &&
+        const bool fused = (!u->keep_all || train_fused) && (meeting_ok() || !no_local) &&
                            conv_fin(b, out, G, u->R(p + ".block2.norm.weight"), u->R(p + ".block2.norm.bias"), resp, want_gn1, gn1,
-                                    !fused_tail_enabled(), u->keep_all ? &h2 : nullptr, u->keep_all ? &st2 : nullptr);
+                                    !meeting_ok(), u->keep_all ? &h2 : nullptr, u->keep_all ? &st2 : nullptr);
         if (!fused) {
             conv(b, h2, G, &st2);
             FinalizeArgs f;
@@ -350,6 +353,10 @@ static void free_plan(fc_unet* u) {
     for (void* p : u->int_allocs) (void)hipFree(p);
     u->int_allocs.clear();
     u->maxB = 0;
+    // a rebuilt plan starts clean (callers of free_plan have synchronised the device)
+    if (u->dev_err) (void)hipMemset(u->dev_err, 0, sizeof(int));
+    if (u->host_err) *u->host_err = 0;
+    u->tail_failed = false;
 }
 
 static int build_plan(fc_unet* u, Plan* pl, int maxB, int H, int W) {
@@ -579,6 +586,50 @@ static FwdCtx slice_ctx(const FwdCtx& c, int r0, int n, size_t sample_floats) {
     return k;
 }
 
+// ---- process-wide guard of the meeting launches ------------------------------------------------------------------------------
+// A launch whose workgroups wait for each other is only safe while no OTHER such launch can hold part of the CUs: two of them, each
+// half resident, would wait for workgroups that cannot start (bounded by the spin limit, then NaN + error -- never a hang, never silent).
+// Inside one process that cannot happen: a plan with meeting launches is ordered behind the previous one of ANY handle when that ran
+// on another stream (one hipStreamWaitEvent, nothing when the event has completed).  Kernels without meetings beside it only delay it.
+// Other processes on the same GPU are beyond this guard: that is what fc_unet_set_shared is for.
+struct MeetGuard { std::mutex mu; hipEvent_t ev = nullptr; hipStream_t s = nullptr; const fc_unet* owner = nullptr; };
+static MeetGuard g_meet[16];
+static MeetGuard& meet_guard(int device) { return g_meet[device & 15]; }
+
+static int plan_meets(const fc_unet* u) { return u->plan[0].n_meet + u->plan[1].n_meet; }
+
+static int meet_enter(fc_unet* u, hipStream_t s) {
+    if (!plan_meets(u)) return FC_OK;
+    MeetGuard& g = meet_guard(u->device);
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (g.ev && g.s != s && hipEventQuery(g.ev) != hipSuccess) FC_HIP(hipStreamWaitEvent(s, g.ev, 0));
+    return FC_OK;
+}
+static int meet_leave(fc_unet* u, hipStream_t s) {
+    if (!plan_meets(u)) return FC_OK;
+    MeetGuard& g = meet_guard(u->device);
+    std::lock_guard<std::mutex> lk(g.mu);
+    FC_HIP(hipEventRecord(u->ev_meet, s));
+    g.ev = u->ev_meet; g.s = s; g.owner = u;
+    // the error word follows the work: the host sees it at its next synchronisation with `s` (fc_unet_check) or at the next call
+    FC_HIP(hipMemcpyAsync(const_cast<int*>(u->host_err), u->dev_err, sizeof(int), hipMemcpyDeviceToHost, s));
+    return FC_OK;
+}
+static void meet_forget(const fc_unet* u) {
+    MeetGuard& g = meet_guard(u->device);
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (g.owner == u) { g.ev = nullptr; g.s = nullptr; g.owner = nullptr; }
+}
+// refuse to go on after a timed-out meeting: the arena holds NaN-poisoned activations and whatever was returned since is invalid
+static int check_poison(fc_unet* u) {
+    if (u->host_err && *u->host_err) u->tail_failed = true;
+    if (u->tail_failed)
+        return fail(FC_E_STATE, "unet: a fused Block tail timed out waiting for its sample group (the GPU was shared with other work while "
+                                "the exclusive plan ran); the affected samples are NaN.  Rebuild the plan -- fc_unet_set_shared(handle, 1) "
+                                "selects the plan without cross-workgroup waits");
+    return FC_OK;
+}
+
 // one chain: the conditioning MLPs (time / class embedding -> every block's scale and shift) on the second stream, joined before
 // the first conv2; inside a captured step this becomes a parallel branch of the graph
 static int run_single(fc_unet* u, const Plan& pl, const FwdCtx& c, hipStream_t s) {
@@ -664,6 +715,10 @@ int fc_unet_create(const fc_unet_config* cfg, int device, fc_unet** out) {
     FC_HIP(hipStreamCreateWithFlags(&u->stream2, hipStreamNonBlocking));
     FC_HIP(hipEventCreateWithFlags(&u->ev_fork, hipEventDisableTiming));
     FC_HIP(hipEventCreateWithFlags(&u->ev_join, hipEventDisableTiming));
+    FC_HIP(hipEventCreateWithFlags(&u->ev_meet, hipEventDisableTiming));
+    FC_HIP(hipMalloc(reinterpret_cast<void**>(&u->dev_err), sizeof(int)));
+    FC_HIP(hipMemset(u->dev_err, 0, sizeof(int)));
+    { void* hp = nullptr; FC_HIP(hipHostMalloc(&hp, sizeof(int), hipHostMallocDefault)); u->host_err = static_cast<volatile int*>(hp); *u->host_err = 0; }
     *out = u.release();
     return FC_OK;
 }
@@ -684,6 +739,10 @@ void fc_unet_destroy(fc_unet* u) {
     if (u->stream2) (void)hipStreamDestroy(u->stream2);
     if (u->ev_fork) (void)hipEventDestroy(u->ev_fork);
     if (u->ev_join) (void)hipEventDestroy(u->ev_join);
+    meet_forget(u);
+    if (u->ev_meet) (void)hipEventDestroy(u->ev_meet);
+    if (u->dev_err) (void)hipFree(u->dev_err);
+    if (u->host_err) (void)hipHostFree(const_cast<int*>(u->host_err));
     delete u;
 }
 
@@ -747,8 +806,39 @@ int fc_unet_forward(fc_unet* u, const float* x, const float* time, const int64_t
     c.mask = u->cfg.mask_cond ? mask : nullptr;
     c.mask_fuse = (c.mask && !mask_is_ones) ? 1 : 0;
     c.out = out; c.B = B;
+    FC_TRY(check_poison(u));
     u->arena_touched(u->keep_all ? B : 0);
-    return run_forward(u, c, static_cast<hipStream_t>(stream));
+    FC_TRY(meet_enter(u, static_cast<hipStream_t>(stream)));
+    FC_TRY(run_forward(u, c, static_cast<hipStream_t>(stream)));
+    return meet_leave(u, static_cast<hipStream_t>(stream));
+}
+
+int fc_unet_set_shared(fc_unet* u, int shared) {
+    if (!u) return fail(FC_E_ARG, "fc_unet_set_shared: null handle");
+    if (u->device < 0) return fail(FC_E_STATE, "unet: created with device < 0 (description only)");
+    if (u->shared == (shared != 0)) return FC_OK;
+    u->shared = shared != 0;
+    if (u->maxB > 0) {   // the plan in place was built for the other mode: drop it, the next reserve rebuilds
+        FC_HIP(hipSetDevice(u->device));
+        FC_HIP(hipDeviceSynchronize());
+        const bool train = u->keep_all;
+        free_plan(u);
+        u->arena_touched(0);
+        u->keep_all = train;
+    }
+    return FC_OK;
+}
+
+int fc_unet_meeting_launches(const fc_unet* u) { return u ? plan_meets(u) : 0; }
+
+int fc_unet_check(fc_unet* u, void* stream, int synchronize) {
+    if (!u) return fail(FC_E_ARG, "fc_unet_check: null handle");
+    if (u->device < 0) return FC_OK;
+    if (synchronize) {
+        FC_HIP(hipSetDevice(u->device));
+        FC_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    }
+    return check_poison(u);
 }
 
 uint64_t fc_unet_arena_serial(const fc_unet* u) { return u ? u->arena_serial : 0; }
@@ -795,6 +885,13 @@ int fc_unet_op_info(const fc_unet* u, int i, const char** kernel, const char** m
     return FC_OK;
 }
 
+int fc_unet_op_bytes(const fc_unet* u, int i, double* bytes_per_sample, double* bytes_per_launch) {
+    if (!u || i < 0 || i >= (int)u->plan[0].ops.size()) return fail(FC_E_ARG, "fc_unet_op_bytes: index out of range");
+    if (bytes_per_sample) *bytes_per_sample = u->plan[0].op_bytes_ps[i];
+    if (bytes_per_launch) *bytes_per_launch = u->plan[0].op_bytes_fixed[i];
+    return FC_OK;
+}
+
 int fc_unet_chains(const fc_unet* u, int* rows_per_chain) {
     if (!u) return 0;
     if (rows_per_chain) *rows_per_chain = u->plan[0].maxB;
@@ -804,12 +901,10 @@ int fc_unet_chains(const fc_unet* u, int* rows_per_chain) {
 int fc_unet_fused_tail_errors(const fc_unet* u, int* count) {
     if (!u || !count) return fail(FC_E_ARG, "fc_unet_fused_tail_errors: null argument");
     *count = 0;
-    for (const Plan& pl : u->plan)
-        for (int* f : pl.fin_err) {
-            int v = 0;
-            FC_HIP(hipMemcpy(&v, f, sizeof(int), hipMemcpyDeviceToHost));
-            *count += v != 0;
-        }
+    if (u->device < 0 || !u->dev_err) return FC_OK;
+    int v = 0;
+    FC_HIP(hipMemcpy(&v, u->dev_err, sizeof(int), hipMemcpyDeviceToHost));   // synchronises with the null stream; callers sync their own
+    *count = (v != 0 || u->tail_failed) ? 1 : 0;
     return FC_OK;
 }
 
@@ -869,6 +964,7 @@ int fc_unet_integrate(fc_unet* u, int method, float* x_dev, int B, int H, int W,
     const bool cfg_on = has_ids && cfg_strength != 0.0f;   // sampling.py:69
     const int rows = cfg_on ? 2 * B : B;
     FC_TRY(check_ready(u, rows, H, W));
+    FC_TRY(check_poison(u));
     u->arena_touched(0);
     const int mask_mode = (mask && u->cfg.mask_cond) ? (mask_is_ones ? 2 : 1) : 0;
     const int n_steps = method == FC_METHOD_RK4 ? n_points - 1 : n_points;
@@ -933,27 +1029,44 @@ int fc_unet_integrate(fc_unet* u, int method, float* x_dev, int B, int H, int W,
     }
     if (euler_tail_ok(u, method, cfg_on))   // time of the first interval; every step publishes its successor's
         FC_TRY(ode_time_launch(u->step, u->ts_dev, t_scale, 0, u->sc, u->tvec, rows, s));
+    FC_TRY(meet_enter(u, s));
     static const bool no_graph = std::getenv("FLOCODER_AMD_NO_GRAPH") != nullptr;
     if (no_graph) {
         for (int i = 0; i < n_steps; ++i) FC_TRY(enqueue_step(u, method, B, cfg_on, cfg_strength, dt_euler, t_scale, has_ids, mask_mode, pre_on, s));
     } else {
-        const auto key = std::make_tuple(method, B, (int)cfg_on, mask_mode, fbits(cfg_strength), fbits(dt_euler), fbits(t_scale), (int)has_ids | ((int)pre_on << 1));
-        auto it = u->graphs.find(key);
-        if (it == u->graphs.end()) {
-            hipGraph_t graph = nullptr;
-            FC_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            const int r = enqueue_step(u, method, B, cfg_on, cfg_strength, dt_euler, t_scale, has_ids, mask_mode, pre_on, s);
-            const hipError_t e = hipStreamEndCapture(s, &graph);
-            if (r != FC_OK) { if (graph) (void)hipGraphDestroy(graph); return r; }
-            if (e != hipSuccess) return fail(FC_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-            hipGraphExec_t exec = nullptr;
-            FC_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-            FC_HIP(hipGraphDestroy(graph));
-            it = u->graphs.emplace(key, exec).first;
+        // One graph holds SEVERAL consecutive intervals (round 3): the step counter, the time grid and the conditioning slice index all
+        // live on the device, so a captured interval is position-independent and k of them in a row are one hipGraphLaunch instead
+        // of k (the per-interval form left ~4 % of the trajectory between replays: 64 launches of a 70-node graph).  Capped by node
+        // count; FLOCODER_AMD_GRAPH_STEPS=1 restores one interval per graph.
+        static const int steps_env = [] { const char* e = std::getenv("FLOCODER_AMD_GRAPH_STEPS"); return e ? std::atoi(e) : 0; }();
+        const int nodes_per_step = (int)u->plan[0].ops.size() * (method == FC_METHOD_RK4 ? 4 : 1) * (u->nchains == 2 ? 2 : 1) + 16;
+        int per = steps_env > 0 ? steps_env : (6144 / nodes_per_step > 0 ? 6144 / nodes_per_step : 1);
+        if (per > 255) per = 255;
+        for (int left = n_steps; left > 0;) {
+            const int k = left < per ? left : per;
+            const auto key = std::make_tuple(method, B, (int)cfg_on, mask_mode, fbits(cfg_strength), fbits(dt_euler), fbits(t_scale),
+                                             (int)has_ids | ((int)pre_on << 1) | (k << 2));
+            auto it = u->graphs.find(key);
+            if (it == u->graphs.end()) {
+                hipGraph_t graph = nullptr;
+                FC_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                int r = FC_OK;
+                for (int j = 0; j < k && r == FC_OK; ++j)
+                    r = enqueue_step(u, method, B, cfg_on, cfg_strength, dt_euler, t_scale, has_ids, mask_mode, pre_on, s);
+                const hipError_t e = hipStreamEndCapture(s, &graph);
+                if (r != FC_OK) { if (graph) (void)hipGraphDestroy(graph); return r; }
+                if (e != hipSuccess) return fail(FC_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+                hipGraphExec_t exec = nullptr;
+                FC_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                FC_HIP(hipGraphDestroy(graph));
+                it = u->graphs.emplace(key, exec).first;
+            }
+            FC_HIP(hipGraphLaunch(it->second, s));
+            left -= k;
         }
-        for (int i = 0; i < n_steps; ++i) FC_HIP(hipGraphLaunch(it->second, s));
     }
     FC_HIP(hipMemcpyAsync(x_dev, u->y, nbytes, hipMemcpyDeviceToDevice, s));
+    FC_TRY(meet_leave(u, s));
     FC_HIP(hipEventRecord(u->ev_out, s));
     FC_HIP(hipStreamWaitEvent(caller, u->ev_out, 0));
     return FC_OK;
@@ -968,6 +1081,18 @@ int fc_unet_debug_tensor(const fc_unet* u, const char* name, const float** ptr, 
         if (it == u->bwd.named.end()) return fail(FC_E_ARG, std::string("fc_unet_debug_tensor: no tap named ") + name);
     }
     *ptr = it->second.p; *C = it->second.C; *H = it->second.H; *W = it->second.W;
+    return FC_OK;
+}
+
+// Test hook: put the arrival counter of one meeting launch out of step, so that its workgroups draw different epochs and every wait of
+// that launch times out (bounded spins) -- the failure a shared device can cause, on demand.
+int fc_debug_unet_break_meeting(fc_unet* u) {
+    if (!u || u->plan[0].fin_sync.empty()) return fail(FC_E_STATE, "fc_debug_unet_break_meeting: the plan has no meeting launch");
+    FC_HIP(hipDeviceSynchronize());
+    unsigned v = 0;
+    FC_HIP(hipMemcpy(&v, u->plan[0].fin_sync[0], sizeof(unsigned), hipMemcpyDeviceToHost));
+    ++v;
+    FC_HIP(hipMemcpy(u->plan[0].fin_sync[0], &v, sizeof(unsigned), hipMemcpyHostToDevice));
     return FC_OK;
 }
 

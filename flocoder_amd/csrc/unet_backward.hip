@@ -100,6 +100,13 @@ struct BwdBuilder : PlanBuilder {
                 deferred = true;
             }
         }
+        // An activation recomputed only for this weight gradient (materialize(..., for_wgrad)) leaves the chain exactly when this entry
+        // did: decided HERE, once, for both (round 2 decided it twice from conditions that merely happened to coincide -- an entry the
+        // table refused would have read its input before the end-of-plan finalize launch had produced it).
+        if (pending_mat.flag && pending_mat.y == x.p) {
+            if (deferred) { *pending_mat.flag = true; fin_jobs.push_back(pending_mat.f); pinned.insert(pending_mat.y); }
+            pending_mat = PendingMat();
+        }
         push([a, wo, bo, own, own_floats, maxB, deferred](const FwdCtx& c, hipStream_t s) -> int {
             if (deferred && c.B == maxB) return FC_OK;      // runs in the table launch at the end of the plan
             WgradArgs b = a;
@@ -151,15 +158,18 @@ struct BwdBuilder : PlanBuilder {
     // y = act(gn(h)).  `for_wgrad`: the only reader is a deferred weight-gradient entry, so at the full batch the pass joins the
     // table launch in front of the weight gradients instead of sitting on the data-gradient chain
     std::vector<FinalizeArgs> fin_jobs;
+    struct PendingMat { FinalizeArgs f; std::shared_ptr<bool> flag; const float* y = nullptr; };
+    PendingMat pending_mat;                 // a for_wgrad activation whose reader (the next wgrad() of y) has not been emitted yet
     void materialize(const Act& h, const SrcXform& xf, const Act& y, bool for_wgrad = false) {
         if (err) return;
+        if (pending_mat.flag) { err = fail(FC_E_STATE, "backward: an activation materialised for a weight gradient was never read by one (" + scope + ")"); return; }
         FinalizeArgs f;
         f.h = h.p; f.xf = xf; f.y = y.p; f.HW = h.H * h.W; f.C = h.C;
-        const bool deferred = for_wgrad && batch_wgrad && guard == 0;
-        if (deferred) { f.B = B; fin_jobs.push_back(f); pinned.insert(y.p); }
+        auto deferred = std::make_shared<bool>(false);      // set by the wgrad() that reads y, if and only if that entry joins the table launch
+        if (for_wgrad) { pending_mat.f = f; pending_mat.f.B = B; pending_mat.flag = deferred; pending_mat.y = y.p; }
         const int maxB = B;
         push([f, deferred, maxB](const FwdCtx& c, hipStream_t s) -> int {
-            if (deferred && c.B == maxB) return FC_OK;
+            if (*deferred && c.B == maxB) return FC_OK;
             FinalizeArgs g = f; g.B = c.B; return finalize_launch(g, s);
         }, "finalize");
     }
@@ -705,6 +715,15 @@ int fc_adam_ema_step(float* params_dev, const float* grads_dev, float* exp_avg_d
         return fail(FC_E_ARG, "fc_adam_ema_step: bad argument");
     return adam_ema_launch(params_dev, grads_dev, exp_avg_dev, exp_avg_sq_dev, ema_dev, (size_t)numel, clip_coef_dev, lr, beta1, beta2, eps, step,
                            ema_decay, apply_adam, static_cast<hipStream_t>(stream));
+}
+
+int fc_adam_ema_step_guarded(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, float* ema_dev, int64_t numel,
+                             const float* clip_coef_dev, float lr, float beta1, float beta2, float eps, int step, float ema_decay, int apply_adam,
+                             const int* skip_flag_dev, void* stream) {
+    if (!params_dev || numel < 0 || (apply_adam && (!grads_dev || !exp_avg_dev || !exp_avg_sq_dev || step < 1)))
+        return fail(FC_E_ARG, "fc_adam_ema_step_guarded: bad argument");
+    return adam_ema_launch(params_dev, grads_dev, exp_avg_dev, exp_avg_sq_dev, ema_dev, (size_t)numel, clip_coef_dev, lr, beta1, beta2, eps, step,
+                           ema_decay, apply_adam, static_cast<hipStream_t>(stream), skip_flag_dev);
 }
 
 }  // extern "C"

@@ -37,6 +37,16 @@ struct fc_unet : fc::ParamStore {
     fc::TembArgs temb_proto;                 // weights of the conditioning chain as the plan's own launches use them
     std::map<std::tuple<int, int, int, int, uint32_t, uint32_t, uint32_t, int>, hipGraphExec_t> graphs;
 
+    // Fused Block tails whose workgroups wait for each other (conv_dev.h) need the device to themselves.  `shared` = the caller said the
+    // device is shared with other streams / processes (fc_unet_set_shared): plans are then built without such launches.  A wait that
+    // times out anyway poisons its sample group with NaN and sets `dev_err`; `host_err` (pinned) receives a copy behind every forward /
+    // integration, and every entry point refuses to go on once it is set (sticky until the plan is rebuilt).
+    bool shared = false;
+    int* dev_err = nullptr;
+    volatile int* host_err = nullptr;
+    bool tail_failed = false;
+    hipEvent_t ev_meet = nullptr;            // end of this handle's last plan with meeting launches (process-wide guard, unet.hip)
+
     bool keep_all = false;   // plans keep every intermediate (q/k/v, attention output) for the backward: set by fc_unet_train_reserve
 
     // training (unet_backward.hip): backward launch plan over the forward arena, data-gradient weight operands

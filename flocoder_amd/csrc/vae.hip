@@ -370,6 +370,15 @@ int fc_vae_op_info(const fc_vae* v, int decode, int i, const char** kernel, cons
     return FC_OK;
 }
 
+int fc_vae_op_bytes(const fc_vae* v, int decode, int i, double* bytes_per_sample, double* bytes_per_launch) {
+    if (!v) return fail(FC_E_ARG, "fc_vae_op_bytes: null handle");
+    const Plan& pl = decode ? v->dec : v->enc;
+    if (i < 0 || i >= (int)pl.ops.size()) return fail(FC_E_ARG, "fc_vae_op_bytes: index out of range");
+    if (bytes_per_sample) *bytes_per_sample = pl.op_bytes_ps[i];
+    if (bytes_per_launch) *bytes_per_launch = pl.op_bytes_fixed[i];
+    return FC_OK;
+}
+
 // Measurement hook: every launch of the encode / decode plan timed alone (`repeats` back-to-back launches between two events).
 // in_dev / out_dev: valid input and output tensors for `batch` samples at the plan's shape.  Synchronises.
 int fc_vae_profile_ops(fc_vae* v, int decode, const float* in_dev, float* out_dev, int batch, int repeats, float* ms_out, int n_out, void* stream) {

@@ -421,5 +421,29 @@ int fc_vqvae_decode(fc_vqvae* v, const float* z_dev, float* x_out_dev, int batch
     return run_vq(v, true, z_dev, x_out_dev, batch, lat_height, lat_width, stream);
 }
 double fc_vqvae_flops_per_sample(const fc_vqvae* v, int decode) { return v ? (decode ? v->dec.flops : v->enc.flops) : 0.0; }
+int fc_vqvae_plan_launches(const fc_vqvae* v, int decode) { return v ? (int)(decode ? v->dec.ops.size() : v->enc.ops.size()) : 0; }
+
+int fc_vqvae_op_info(const fc_vqvae* v, int decode, int i, const char** kernel, const char** module, double* flops_per_sample,
+                     double* bytes_per_sample, double* bytes_per_launch) {
+    if (!v) return fail(FC_E_ARG, "fc_vqvae_op_info: null handle");
+    const Plan& pl = decode ? v->dec : v->enc;
+    if (i < 0 || i >= (int)pl.ops.size()) return fail(FC_E_ARG, "fc_vqvae_op_info: index out of range");
+    if (kernel) *kernel = pl.op_kernel[i].c_str();
+    if (module) *module = pl.op_what[i].c_str();
+    if (flops_per_sample) *flops_per_sample = pl.op_flops[i];
+    if (bytes_per_sample) *bytes_per_sample = pl.op_bytes_ps[i];
+    if (bytes_per_launch) *bytes_per_launch = pl.op_bytes_fixed[i];
+    return FC_OK;
+}
+
+int fc_vqvae_profile_ops(fc_vqvae* v, int decode, const float* in_dev, float* out_dev, int batch, int repeats, float* ms_out, int n_out, void* stream) {
+    if (!v || !in_dev || !out_dev || !ms_out || repeats < 1) return fail(FC_E_ARG, "fc_vqvae_profile_ops: bad argument");
+    const Plan& pl = decode ? v->dec : v->enc;
+    if (pl.maxB < batch || pl.ops.empty()) return fail(FC_E_STATE, "vqvae: reserve the plan first");
+    if (!v->loaded) return fail(FC_E_STATE, "vqvae: weights not loaded (fc_vqvae_load_params)");
+    FwdCtx c;
+    c.x = in_dev; c.x_mod = batch; c.out = out_dev; c.B = batch;
+    return profile_plan(pl, c, repeats, ms_out, n_out, static_cast<hipStream_t>(stream));
+}
 
 }  // extern "C"

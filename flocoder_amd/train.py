@@ -130,7 +130,8 @@ class FlowTrainer:
         self._lo, self._hi = self._groups["class"]
         self.step_main, self.steps = 0, {k: 0 for k in self._groups}
         self._scal = torch.zeros(4, dtype=torch.float32, device=device)      # loss | grad norm | clip coefficient
-        self._id_flag = torch.zeros(1, dtype=torch.int32, device=device)     # set by the step prologue when a class id is out of range
+        self._id_flag = torch.zeros(1, dtype=torch.int32, device=device)     # sticky: bit 0 = a class id, bit 1 = a pairing entry out of range (step prologue)
+        self._id_flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()   # its mirror, refreshed asynchronously behind every prologue
         self._ws = torch.zeros(256, dtype=torch.float32, device=device)
         self.pg = process_group
         dist = torch.distributed
@@ -155,17 +156,31 @@ class FlowTrainer:
         t, time = torch.empty(bsz, device=dev), torch.empty(bsz, device=dev)
         x, v = torch.empty_like(source), torch.empty_like(source)
         ncls = self.model._cfg.n_classes if cls is not None else 0
+        check = cls is not None or pairing is not None
         B.check(B.lib().fc_flow_prepare(B.ptr(source), B.ptr(target), B.ptr(pairing), B.ptr(u), self.t_eps, 0.5, self.t_scale, B.ptr(cls), ncls,
-                                        B.ptr(t), B.ptr(time), B.ptr(x), B.ptr(v), self._id_flag.data_ptr() if cls is not None else None, bsz,
+                                        B.ptr(t), B.ptr(time), B.ptr(x), B.ptr(v), self._id_flag.data_ptr() if check else None, bsz,
                                         target[0].numel(), B.current_stream(dev)))
+        if check:
+            self._id_flag_host.copy_(self._id_flag, non_blocking=True)     # the host looks at it when it next passes by: no sync
         return t, time, x, v
 
     def check_class_ids(self) -> None:
-        """Raise IndexError if any step so far was given a class id outside [0, n_classes) (nn.Embedding raises for those, unet.py:205;
-        the kernels treat such a row as unconditional).  One host sync: ``step`` calls it every 64 steps, the state-dict methods always."""
-        if int(self._id_flag.item()):
+        """Raise IndexError if any step so far was given a class id outside [0, n_classes) (nn.Embedding raises for those, unet.py:205)
+        or a pairing entry outside [0, batch) (``target[ot_indices]`` raises, train_flow.py:350).  The optimiser launches are guarded
+        by the same device flag (``fc_adam_ema_step_guarded``): from the offending step on NO update is applied -- parameters, Adam
+        moments and EMA are those of the last valid step -- until this raises.  One host sync: ``step`` calls it as soon as the pinned
+        mirror of the flag shows it (usually the next step), every 64 steps in any case, and the state-dict methods always."""
+        flag = int(self._id_flag.item())
+        if flag:
             self._id_flag.zero_()
-            raise IndexError(f"class_cond ids must lie in [0, {self.model._cfg.n_classes}) (a training step since the last check was given others)")
+            self._id_flag_host.zero_()
+            what = []
+            if flag & 1:
+                what.append(f"class_cond ids must lie in [0, {self.model._cfg.n_classes})")
+            if flag & 2:
+                what.append("pairing indices must lie in [0, batch)")
+            raise IndexError("; ".join(what) + " (a training step since the last check was given others; no optimiser update has been "
+                                               "applied from that step on)")
 
     def loss_and_grads(self, x, t, cls, v_target, mask=None, time=None):
         """forward -> loss -> backward; leaves the gradients in ``self.grads`` and returns (loss 0-d tensor, v_model)."""
@@ -204,8 +219,8 @@ class FlowTrainer:
 
         def run(a, b, step, adam):
             if b > a:
-                B.check(lib.fc_adam_ema_step(P + 4 * a, G + 4 * a, M + 4 * a, V + 4 * a, E + 4 * a, b - a, coef, self.lr, b1, b2, self.eps,
-                                             max(step, 1), self.ema_decay, int(adam), st))
+                B.check(lib.fc_adam_ema_step_guarded(P + 4 * a, G + 4 * a, M + 4 * a, V + 4 * a, E + 4 * a, b - a, coef, self.lr, b1, b2, self.eps,
+                                                     max(step, 1), self.ema_decay, int(adam), self._id_flag.data_ptr(), st))
         cuts = sorted((lo, hi, k) for k, (lo, hi) in self._groups.items() if hi > lo)
         pos = 0
         for lo, hi, k in cuts:
@@ -230,9 +245,16 @@ class FlowTrainer:
             lo, hi = self._groups[k]
             if hi > lo and not present[k]:
                 self.grads[lo:hi].zero_()
-        flags = torch.tensor([float(present[k]) for k in keys], device=self.device)
+        # the input-validity flag (class ids / pairing, set by the step prologue on the device) rides in the same collective: every rank
+        # learns that SOME rank was given bad inputs and all raise together, before any of them enters the gradient all-reduce
+        flags = torch.cat([torch.tensor([float(present[k]) for k in keys], device=self.device), self._id_flag.to(torch.float32)])
         torch.distributed.all_reduce(flags, op=torch.distributed.ReduceOp.MAX, group=self.pg)
-        return {k: bool(v) for k, v in zip(keys, flags.tolist())}
+        vals = flags.tolist()
+        if vals[-1]:
+            if not int(self._id_flag.item()):
+                self._id_flag.fill_(int(vals[-1]))           # another rank's batch: raise the same error here
+            self.check_class_ids()
+        return {k: bool(v) for k, v in zip(keys, vals)}
 
     # ---- the step -------------------------------------------------------------------------------------------------
     def step(self, source, target, cond=None, u: Optional[torch.Tensor] = None, pairing: Optional[torch.Tensor] = None):
@@ -260,10 +282,14 @@ class FlowTrainer:
                 raise ValueError("class_cond must have shape [batch]")
         if pairing is not None:
             pairing = pairing.to(dev, torch.int64).contiguous()
+            if pairing.shape != (bsz,):
+                raise ValueError(f"pairing must have shape [batch] = ({bsz},), got {tuple(pairing.shape)}")
+        if int(self._id_flag_host[0]):
+            self.check_class_ids()                                   # an earlier step's inputs were out of range: raise now
         t, time, x, v_target = self.prepare(source, target, u, cls, pairing)
         loss, _ = self.loss_and_grads(x, t, cls, v_target, mask, time=time)
         loss = loss.clone()
-        if cls is not None and (self.step_main & 63) == 0:
+        if (cls is not None or pairing is not None) and (self.step_main & 63) == 0:
             self.check_class_ids()                                   # every 64th step (and from the state-dict methods): one host sync
         fused = mask is not None and not bool(torch.allclose(mask, torch.ones_like(mask)))    # unet.py:301 (host sync, as upstream)
         present = self._agree({"class": cls is not None, "inject": mask is not None, "fusion": fused})
@@ -307,6 +333,7 @@ class FlowTrainer:
             u = torch.rand(bsz, device=dev)
         t = warp_time(f(u) * (1 - self.t_eps) + self.t_eps).contiguous()
         cls = class_cond.to(dev, torch.int64).contiguous() if (class_cond is not None and self.model.class_condition) else None
+        self.model.check_class_ids(cls)                       # this step does not go through fc_flow_prepare: check on the host (it synchronises anyway)
         with torch.no_grad():
             time = (t * self.t_scale).contiguous()
             if drop_cond:                                     # the 10 % classifier-free-guidance drop (train_flow.py:343-345): no cond, pure noise source

@@ -119,6 +119,7 @@ class Unet(nn.Module):
         self._handle: Optional[C.c_void_p] = None
         self._handle_device: Optional[torch.device] = None
         self._synced_version = None
+        self._shared = None          # None: decide per call (see _device_is_shared); True / False: set_shared_device
 
     # ------------------------------------------------------------------ parameters
     def _register(self, name: str, shape: Tuple[int, ...]) -> None:
@@ -175,6 +176,7 @@ class Unet(nn.Module):
             half = self.dim // 2    # frequency table exactly as torch computes it (unet.py:26-27)
             fr = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1))).contiguous()
             B.check(lib.fc_unet_set_time_freqs(h, fr.numpy().ctypes.data_as(C.POINTER(C.c_float)), half))
+        B.check(lib.fc_unet_set_shared(self._handle, int(self._device_is_shared(device))))
         ver = self._version()
         if ver != self._synced_version:
             flat = self._flat_params(device)
@@ -213,6 +215,38 @@ class Unet(nn.Module):
         rows = C.c_int(0)
         n = B.lib().fc_unet_chains(self._handle, C.byref(rows)) if self._handle else 0
         return n, rows.value
+
+    # ------------------------------------------------------------------ device sharing (fc_unet_set_shared)
+    def set_shared_device(self, shared: Optional[bool]) -> None:
+        """Tell the library whether this model's GPU work runs beside other work it is not ordered against (a second replica meant to
+        overlap, the collectives of a training job, another process on the same GPU).  ``True`` selects the plan without
+        cross-workgroup waits (same results bit for bit, one more launch per Block); ``False`` insists on the exclusive plan;
+        ``None`` (default) decides per call: shared when a process group with more than one rank is live or the caller works on a
+        non-default stream, exclusive otherwise."""
+        self._shared = shared
+
+    def _device_is_shared(self, device) -> bool:
+        if self._shared is not None:
+            return bool(self._shared)
+        import os
+        if os.environ.get("FLOCODER_AMD_SHARED_DEVICE") in ("0", "1"):
+            return os.environ["FLOCODER_AMD_SHARED_DEVICE"] == "1"
+        d = torch.distributed
+        if d.is_available() and d.is_initialized() and d.get_world_size() > 1 and self.training:
+            return True          # gradient collectives (RCCL kernels) run beside this model's launches
+        return torch.cuda.current_stream(device) != torch.cuda.default_stream(device)
+
+    @property
+    def meeting_launches(self) -> int:
+        """Launches of the current plan whose workgroups wait for each other (0 on a shared device)."""
+        return int(B.lib().fc_unet_meeting_launches(self._handle)) if self._handle else 0
+
+    def check_errors(self, synchronize: bool = True) -> None:
+        """Raise RuntimeError if a cross-workgroup wait of a fused Block tail ever timed out on this model (its samples are NaN and
+        every later call fails too, until the plan is rebuilt).  With ``synchronize`` the current stream is waited for first, so
+        the answer covers everything queued so far."""
+        if self._handle:
+            B.check(B.lib().fc_unet_check(self._handle, B.current_stream(self._handle_device), int(synchronize)))
 
     def fused_tail_errors(self) -> int:
         """Timed-out waits of the fused Block tails since the plan was built (must be 0; synchronises)."""
@@ -336,8 +370,11 @@ class Unet(nn.Module):
     # ------------------------------------------------------------------ integrators (used by flocoder_amd.sampling)
     def integrate(self, method: str, x: torch.Tensor, ts: torch.Tensor, *, dt_euler: float = 0.0, t_scale: float = 999.0,
                   class_ids: Optional[torch.Tensor] = None, cfg_strength: float = 0.0, mask: Optional[torch.Tensor] = None,
-                  mask_is_ones: bool = False) -> torch.Tensor:
-        """Integrate ``x`` in place along the fp32 grid ``ts`` with the hipGraph-captured step; returns ``x``."""
+                  mask_is_ones: bool = False, check: bool = True) -> torch.Tensor:
+        """Integrate ``x`` in place along the fp32 grid ``ts`` with the hipGraph-captured step; returns ``x``.  With ``check`` (default)
+        the call waits for the trajectory when the plan contains cross-workgroup waits and raises if one timed out -- a caller never
+        receives samples from a plan whose residency assumption broke.  ``check=False`` keeps the call asynchronous; the error then
+        surfaces at the next call on the model or at ``check_errors()``."""
         if not x.is_cuda:
             raise RuntimeError("flocoder_amd integrators run on MI355X (gfx950) only")
         dev = x.device
@@ -365,6 +402,8 @@ class Unet(nn.Module):
         B.check(B.lib().fc_unet_integrate(hnd, code, B.ptr(x), bsz, h, w, ts_host.numpy().ctypes.data_as(C.POINTER(C.c_float)),
                                           ts_host.numel(), float(dt_euler), float(t_scale), B.ptr(class_ids),
                                           float(cfg_strength or 0.0), B.ptr(mask), int(mask_is_ones), B.current_stream(dev)))
+        if check and B.lib().fc_unet_meeting_launches(hnd) > 0:
+            B.check(B.lib().fc_unet_check(hnd, B.current_stream(dev), 1))
         return x
 
     def profile_ops(self, batch: int, repeats: int = 20):
@@ -382,7 +421,10 @@ class Unet(nn.Module):
         for i in range(n):
             k, m, f = C.c_char_p(), C.c_char_p(), C.c_double()
             B.check(lib.fc_unet_op_info(h, i, C.byref(k), C.byref(m), C.byref(f)))
-            out.append(dict(kernel=k.value.decode(), module=m.value.decode(), flops_per_sample=f.value, ms=float(ms[i]), rows=batch))
+            bp, bf = C.c_double(), C.c_double()
+            B.check(lib.fc_unet_op_bytes(h, i, C.byref(bp), C.byref(bf)))
+            out.append(dict(kernel=k.value.decode(), module=m.value.decode(), flops_per_sample=f.value, ms=float(ms[i]), rows=batch,
+                            bytes=bp.value * batch + bf.value))
         return out
 
     def debug_tensor(self, name: str) -> torch.Tensor:

@@ -94,8 +94,10 @@ int fc_unet_forward(fc_unet* u, const float* x_dev, const float* time_dev, const
  *   t_scale multiplies every time value before it reaches the U-Net (999, sampling.py:57).
  *   class_ids_dev/mask_dev as in fc_unet_forward.  cfg_strength != 0 with class ids present runs the
  *   classifier-free-guidance pair as one 2B-row pass (sampling.py:69-74).
- * One integration step is captured in a hipGraph the first time a (method, B, H, W, cfg, mask) variant
- * is seen and replayed from then on; the time grid lives in device memory, so replays take any grid. */
+ * A run of consecutive integration steps (as many as fit ~6000 graph nodes: all 64 of the Euler sampler) is captured in a hipGraph
+ * the first time a (method, B, H, W, cfg, mask, run length) variant is seen and replayed from then on; step counter, time grid and
+ * conditioning table live in device memory, so replays take any grid.  On return the trajectory is queued on `stream`, not finished:
+ * fc_unet_check(u, stream, 1) waits for it and reports a timed-out cross-workgroup wait (see fc_unet_set_shared). */
 int fc_unet_integrate(fc_unet* u, int method, float* x_dev, int batch, int height, int width,
                       const float* ts_host, int n_points, float dt_euler, float t_scale,
                       const int64_t* class_ids_dev, float cfg_strength, const float* mask_dev, int mask_is_ones,
@@ -111,11 +113,30 @@ int fc_unet_plan_launches(const fc_unet* u);
  * timed out since the plan was built -- must be 0; anything else means the residency assumption broke and results are invalid.
  * Synchronises. */
 int fc_unet_fused_tail_errors(const fc_unet* u, int* count);
-/* Experiment switch (default off): plans built after the call close each Block inside its second convolution. */
+/* Device sharing.  The default ("exclusive") plan closes most Blocks inside their second convolution by letting the workgroups of a
+ * sample exchange GroupNorm partials inside the launch; such a launch is only correct while its whole grid is resident, i.e. while
+ * nothing else competes for the CUs.  Within one process the library orders these plans against each other across streams by itself.
+ * A caller that runs the handle beside other GPU work it does not order against (a second replica meant to overlap, collectives of a
+ * training job, another process on the same GPU) declares that with shared = 1: plans are then built without cross-workgroup waits
+ * (same results bit for bit, one more launch per Block).  Changing the mode drops the current plan; the next reserve rebuilds it.
+ * No counterpart in the reference (PyTorch kernels never wait for each other). */
+int fc_unet_set_shared(fc_unet* u, int shared);
+/* Launches of the current plan whose workgroups wait for each other (0 for a shared-mode or training plan). */
+int fc_unet_meeting_launches(const fc_unet* u);
+/* Has a wait of such a launch ever timed out?  A timed-out wait turns its samples into NaN (never finite garbage) and makes every later
+ * call on the handle -- this one included -- return FC_E_STATE until the plan is rebuilt.  With `synchronize` != 0 the call first waits
+ * for `stream` (the stream the last forward / integration was given), so that its answer covers that work. */
+int fc_unet_check(fc_unet* u, void* stream, int synchronize);
+/* Test hook: makes the next run of the plan's first meeting launch time out. */
+int fc_debug_unet_break_meeting(fc_unet* u);
+/* Experiment switch: plans built after the call use (1) / do not use (0) the cross-workgroup Block tails (default on). */
 int fc_debug_set_fused_tail(int on);
 double fc_unet_flops_per_sample(const fc_unet* u);
 /* Launch i of the plan: kernel family, the reference module it implements, its algorithmic FLOPs per sample. */
 int fc_unet_op_info(const fc_unet* u, int i, const char** kernel, const char** module, double* flops_per_sample);
+/* Algorithmic HBM bytes of launch i (convolution launches; 0 for the others): per sample = every input / output / residual element
+ * once, per launch = the weights once -- the figure bench.py's roofline.traffic is read against. */
+int fc_unet_op_bytes(const fc_unet* u, int i, double* bytes_per_sample, double* bytes_per_launch);
 /* Measurement hook for bench.py: average device milliseconds of every launch of the plan at `batch` rows, each
  * timed alone with HIP events on `stream` over `repeats` back-to-back launches (`batch` is clamped to the rows of one
  * chain, see fc_unet_chains).  Synchronises. */
@@ -173,8 +194,9 @@ int fc_flow_interp(const float* source_dev, const float* target_dev, const float
 /* The per-step prologue of train_flow.py:346-357 in one launch: t = warp_time(u (1 - t_eps) + t_eps, s = warp_s) (sampling.py:23-33,
  * the same rounded operations torch runs), time = t * t_scale (the U-Net's time input), x / v* as fc_flow_interp with
  * target row pairing[b] when pairing_dev != NULL (the OT pairing's gather, train_flow.py:350), and the range check of the class ids:
- * *id_flag_dev is set to 1 (never cleared) when an id lies outside [0, n_classes) -- nn.Embedding's IndexError, reported when the
- * host next reads the flag.  pairing_dev, class_ids_dev and id_flag_dev may be NULL. */
+ * bit 0 of *id_flag_dev is set (never cleared) when an id lies outside [0, n_classes) -- nn.Embedding's IndexError, reported when the
+ * host next reads the flag; bit 1 when a pairing entry lies outside [0, batch) (torch's target[ot_indices] raises IndexError; the row
+ * then reads its own target instead of memory out of bounds).  pairing_dev, class_ids_dev and id_flag_dev may be NULL. */
 int fc_flow_prepare(const float* source_dev, const float* target_dev, const int64_t* pairing_dev, const float* u_dev, float t_eps, float warp_s,
                     float t_scale, const int64_t* class_ids_dev, int n_classes, float* t_out_dev, float* time_out_dev, float* x_out_dev,
                     float* v_out_dev, int* id_flag_dev, int batch, int64_t per_sample, void* stream);
@@ -189,6 +211,11 @@ int fc_grad_clip_coef(const float* grads_dev, int64_t numel, const float* grads2
 int fc_adam_ema_step(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, float* ema_dev, int64_t numel,
                      const float* clip_coef_dev, float lr, float beta1, float beta2, float eps, int step, float ema_decay, int apply_adam,
                      void* stream);
+/* The same, skipped entirely (no Adam, no EMA) when *skip_flag_dev != 0 (NULL: never): FlowTrainer passes fc_flow_prepare's flag, so a
+ * step whose class ids / pairing were out of range changes nothing before the host has seen the flag and raised. */
+int fc_adam_ema_step_guarded(float* params_dev, const float* grads_dev, float* exp_avg_dev, float* exp_avg_sq_dev, float* ema_dev, int64_t numel,
+                             const float* clip_coef_dev, float lr, float beta1, float beta2, float eps, int step, float ema_decay, int apply_adam,
+                             const int* skip_flag_dev, void* stream);
 /* test hook: weight / bias gradient of one convolution (NHWC operands, dw in [O][I][KH][KW]) */
 int fc_debug_conv_wgrad(const float* src0, int c0, const float* src1, int c1, const float* dy, int cout, int batch, int hs, int ws, int ksize,
                         int pad, int stride, int upsample, float* dw_out, float* db_out, void* stream);
@@ -218,6 +245,7 @@ int fc_vae_plan_launches(const fc_vae* v, int decode);
 int fc_vae_op_info(const fc_vae* v, int decode, int i, const char** kernel, const char** module, double* flops_per_sample);
 int fc_vae_profile_ops(fc_vae* v, int decode, const float* in_dev, float* out_dev, int batch, int repeats, float* ms_out, int n_out,
                        void* stream);
+int fc_vae_op_bytes(const fc_vae* v, int decode, int i, double* bytes_per_sample, double* bytes_per_launch);   /* as fc_unet_op_bytes */
 
 /* ------------------------------------------------------------------------------------------------
  * VQVAE codec, encode / decode  (replaces flocoder/codecs.py:386-525 VQVAE.encode / VQVAE.decode with
@@ -254,6 +282,13 @@ int fc_vqvae_encode(fc_vqvae* v, const float* x_dev, float* z_out_dev, int batch
 /* x = vqvae.decode(z_q)  (codecs.py:523-525, noise_strength 0): z_dev [B,vq_embedding_dim,h,w] -> x_out_dev [B,in_channels,H,W]. */
 int fc_vqvae_decode(fc_vqvae* v, const float* z_dev, float* x_out_dev, int batch, int lat_height, int lat_width, void* stream);
 double fc_vqvae_flops_per_sample(const fc_vqvae* v, int decode);
+/* Measurement only (bench.py's config-5 leg): launches of the encode / decode plan, launch i's kernel family, module, algorithmic FLOPs
+ * per sample and HBM bytes (per sample / per launch; 0 where not stated), and every launch timed alone as in fc_unet_profile_ops. */
+int fc_vqvae_plan_launches(const fc_vqvae* v, int decode);
+int fc_vqvae_op_info(const fc_vqvae* v, int decode, int i, const char** kernel, const char** module, double* flops_per_sample,
+                     double* bytes_per_sample, double* bytes_per_launch);
+int fc_vqvae_profile_ops(fc_vqvae* v, int decode, const float* in_dev, float* out_dev, int batch, int repeats, float* ms_out, int n_out,
+                         void* stream);
 /* z_q, indices = ResidualVQ(z) in inference form (replaces VQVAE.quantize, codecs.py:504-521 -> vector_quantize_pytorch.ResidualVQ,
  * third party, parity unpinned): per level the nearest codeword of the running residual, z_q = their sum.
  * z_dev / zq_out_dev [B,dim,hw] (NCHW with hw = h*w); codebooks_dev [levels][codebook_size][dim]; indices_out_dev [B*hw][levels]

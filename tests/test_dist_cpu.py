@@ -105,11 +105,23 @@ def _agree_worker(rank, world, port, q):
     # the trainer's agreement step on a stand-in that carries exactly the state it touches (the real object needs a GPU)
     t = types.SimpleNamespace(distributed=True, pg=None, device=torch.device("cpu"),
                               _groups={"class": (10, 20), "fusion": (30, 40), "inject": (0, 0)},
-                              grads=torch.full((50,), float(rank + 1)))
+                              grads=torch.full((50,), float(rank + 1)),
+                              _id_flag=torch.zeros(1, dtype=torch.int32), _id_flag_host=torch.zeros(1, dtype=torch.int32),
+                              model=types.SimpleNamespace(_cfg=types.SimpleNamespace(n_classes=10)))
+    t.check_class_ids = lambda: FlowTrainer.check_class_ids(t)
     # rank 0 trained WITH class conditioning, rank 1 dropped it (cond=None); nobody had a mask
     present = FlowTrainer._agree(t, {"class": rank == 0, "fusion": False, "inject": False})
     fdist.average_gradients(t.grads)
-    q.put((rank, present, t.grads.tolist()))
+    # second round: rank 1's batch carried a class id outside the table (its step prologue set the device flag): BOTH ranks must raise,
+    # inside the agreement, before either enters the gradient all-reduce (one alone would leave the other hanging there)
+    if rank == 1:
+        t._id_flag.fill_(1)
+    raised = False
+    try:
+        FlowTrainer._agree(t, {"class": True, "fusion": False, "inject": False})
+    except IndexError:
+        raised = True
+    q.put((rank, present, t.grads.tolist(), raised))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -126,7 +138,8 @@ def test_replicas_agree_on_adam_groups_world2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, p0, g0), (_, p1, g1) = res
+    (_, p0, g0, e0), (_, p1, g1, e1) = res
+    assert e0 and e1, "a bad class id on one rank must raise IndexError on every rank, in the same step"
     assert p0 == p1 == {"class": True, "fusion": False, "inject": False}
     assert g0 == g1                                              # identical averaged gradients -> identical Adam updates
     assert g0[0] == g0[45] == 1.5 and g0[15] == 0.5              # class range: (1 + 0) / 2 -- rank 1's stale 2.0 was zeroed first

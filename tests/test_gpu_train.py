@@ -472,3 +472,40 @@ def test_train_batch_inpainting_dict_batches():
     assert all(np.isfinite(losses)) and not torch.equal(before[0], tr.me_params) and not torch.equal(before[1], tr.params)
     assert tr.me_step == 12 and tr.steps["inject"] < 12                     # some steps dropped the condition
     assert "mask_encoder.layers.0.conv1.weight" in dict(model.named_parameters())
+
+
+_SPLIT_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from flocoder_amd.unet import Unet
+torch.manual_seed(3)
+m = Unet(dim=16, dim_mults=(1, 2, 4, 8), channels=4, n_classes=10).to("cuda:0").train()
+g = torch.Generator().manual_seed(4)
+x = torch.randn(6, 4, 16, 16, generator=g).to("cuda:0"); t = (torch.rand(6, generator=g) * 999).to("cuda:0")
+ids = torch.randint(10, (6,), generator=g).to("cuda:0"); dv = torch.randn(6, 4, 16, 16, generator=g).to("cuda:0")
+m._forward_native(x, t, ids, None, train=True)
+flat, _, _ = m.backward_native(x, t, ids, dv)
+torch.save(flat.cpu(), sys.argv[1])
+"""
+
+
+@pytest.mark.timeout(900)
+def test_weight_gradients_do_not_depend_on_which_entries_join_the_table_launch(tmp_path):
+    """ADVICE r2 (unet_backward.hip): an activation recomputed only for a weight gradient leaves the data-gradient chain exactly when
+    that weight gradient joined the end-of-plan table launch -- one decision for both.  Different table splits (and no table at all)
+    move entries in and out of the table; the gradients must not care."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, env in (("default", {}), ("split64", {"FLOCODER_AMD_WGRAD_TABLE_SPLIT": "64"}), ("split4096", {"FLOCODER_AMD_WGRAD_TABLE_SPLIT": "4096"}),
+                     ("each", {"FLOCODER_AMD_WGRAD_EACH": "1"})):
+        f = str(tmp_path / (tag + ".pt"))
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", _SPLIT_SCRIPT % root, f], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = torch.load(f)
+    for tag, v in outs.items():
+        assert torch.isfinite(v).all()
+        assert rel_l2(v, outs["default"]) < 2e-6, tag

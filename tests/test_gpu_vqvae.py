@@ -104,3 +104,48 @@ def test_protocol_errors():
         m.encode(torch.zeros(1, 1, 64, 64))
     with pytest.raises(ValueError, match="latent pixels"):                          # latent side < 4: no plan
         m.encode(torch.zeros(1, 1, 32, 32, device=DEV))
+
+
+@pytest.mark.timeout(1500)
+def test_full_midi_inpainting_shape_vs_oracle_and_batch_independence():
+    """The codec of BASELINE config 5 at its FULL midi_inpainting.yaml shape (codecs.py:395-574 with in_channels=1, 4 downsamples,
+    hidden 256, internal 128 -> 4x8x8 latents; 563 M parameters): B=1 against the CPU oracle, then B=64 at 128x128 (the size SURVEY
+    8(d) config (5) names) through batch independence -- every sample of the big batch equals its own B=1 pass.  Weights: seeded
+    synthetic tensors over the library's own parameter table (names / shapes as the reference's state_dict, pinned for two other
+    configurations by fixture g9)."""
+    from flocoder_amd.codecs import VQVAE
+    cfg = dict(in_channels=1, hidden_channels=256, num_downsamples=4, internal_dim=128, vq_embedding_dim=4)
+    m = VQVAE(codebook_levels=2, vq_num_embeddings=32, **cfg).eval()
+    shapes = {name: list(shape) for name, shape, _ in m._table}
+    nparam = sum(int(torch.tensor(s).prod()) for s in shapes.values())
+    assert nparam > 5.0e8, nparam
+    sd = synth_state_dict(shapes, 21)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k == "codebook_usage" or k.startswith("vq.") for k in missing)
+    m = m.to(DEV)
+    gen = torch.Generator().manual_seed(8)
+    x1 = torch.rand(1, 1, 128, 128, generator=gen)
+    z1 = m.encode(x1.to(DEV))
+    assert z1.shape == (1, 4, 8, 8)
+    e_enc = rel_l2(z1.cpu(), vq.encode(sd, x1))
+    zq1 = torch.randn(1, 4, 8, 8, generator=gen)
+    y1 = m.decode(zq1.to(DEV))
+    e_dec = rel_l2(y1.cpu(), vq.decode(sd, zq1))
+    print("full midi_inpainting VQVAE (%.0f M params): encode %.2e decode %.2e" % (nparam / 1e6, e_enc, e_dec))
+    assert e_enc < 5e-5 and e_dec < 5e-5
+    # B = 64 at 128 x 128
+    x = torch.rand(64, 1, 128, 128, generator=gen)
+    x[17] = x1[0]
+    z = m.encode(x.to(DEV))
+    assert z.shape == (64, 4, 8, 8) and torch.isfinite(z).all()
+    assert rel_l2(z[17:18].cpu(), z1.cpu()) < 1e-5
+    for k in (0, 40, 63):
+        assert rel_l2(z[k:k + 1].cpu(), m.encode(x[k:k + 1].to(DEV)).cpu()) < 1e-5
+    zq = torch.randn(64, 4, 8, 8, generator=gen)
+    zq[5] = zq1[0]
+    y = m.decode(zq.to(DEV))
+    assert y.shape == (64, 1, 128, 128) and torch.isfinite(y).all()
+    assert rel_l2(y[5:6].cpu(), y1.cpu()) < 1e-5
+    for k in (0, 33, 63):
+        assert rel_l2(y[k:k + 1].cpu(), m.decode(zq[k:k + 1].to(DEV)).cpu()) < 1e-5
+    assert torch.equal(m.decode(zq.to(DEV)), y)                                    # bit-reproducible

@@ -2,6 +2,8 @@
 # One GPU-box session: run from the repo root as  bash tools/gpu_session.sh <tag> [steps...]
 # steps: tests bench rehearse2 counters prof pmc mfma train codec   (default: tests bench)
 set -o pipefail
+: ${GRAFT_REPO_ROOT:=$(pwd)}      # the rocprofv3 steps cd to /tmp and name the repo absolutely
+export GRAFT_REPO_ROOT
 TAG=${1:-r02_x}; shift
 STEPS=${@:-tests bench}
 OUT=gpurun_out/$TAG

@@ -40,11 +40,13 @@ def main():
         e.record()
         marks.append((name, e))
 
-    orig_interp, orig_lg, orig_opt = tr.interpolate, tr.loss_and_grads, tr.optimizer_step
+    orig_prep, orig_lg, orig_opt = tr.prepare, tr.loss_and_grads, tr.optimizer_step
 
-    def interp(*a):
-        mark("step prologue (torch)")
-        return orig_interp(*a)
+    def prep(*a, **k):                       # FlowTrainer.step's prologue is ONE library call since round 2 (fc_flow_prepare)
+        mark("host: tensor checks / casts")
+        r = orig_prep(*a, **k)
+        mark("step prologue (fc_flow_prepare)")
+        return r
 
     def lg(*a, **k):
         r = orig_lg(*a, **k)
@@ -57,7 +59,7 @@ def main():
         mark("clip + Adam + EMA + repack")
         return r
 
-    tr.interpolate, tr.loss_and_grads, tr.optimizer_step = interp, lg, opt
+    tr.prepare, tr.loss_and_grads, tr.optimizer_step = prep, lg, opt
     acc = {}
     wall = 0.0
     for it in range(args.warmup + args.steps):
