@@ -435,7 +435,8 @@ def config5(device):
                                       f"mask_cond, latents 4x8x8, B={BATCH}", "ms": round(t_inp * 1e3, 1), "samples_per_s": round(BATCH / t_inp, 1),
                           "us_per_evaluation": round(1e6 * t_inp / evals, 1), "gflop_per_sample_per_evaluation": round(unet.flops_per_sample / 1e9, 4),
                           "tflops": round(BATCH * evals * unet.flops_per_sample / t_inp / 1e12, 3), "plan_entries_per_forward": unet.launches_per_forward,
-                          "note": "0.06 GFLOP per evaluation over ~90 launches: launch-latency bound by construction, not an MFMA or HBM roofline case"}
+                          "note": f"{unet.flops_per_sample / 1e6:.1f} MFLOP per sample per evaluation over {unet.launches_per_forward} plan entries: "
+                                  "launch-latency bound by construction, not an MFMA or HBM roofline case"}
     return out
 
 

@@ -754,6 +754,19 @@ int gather_rows_launch(const float* table, const int64_t* ids, float* out, int B
     FC_HIP(hipGetLastError());
     return FC_OK;
 }
+// out[b][:] = d[b][:] where ids[b] is a valid class, 0 elsewhere: rows without a class embedding (id < 0, fc_unet_forward) take no part
+// in the class MLP's backward either
+__global__ void __launch_bounds__(256) mask_rows_kernel(const float* d, int ld, const int64_t* ids, float* out, int B, int D, int R) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= B * D) return;
+    const int64_t id = ids[t / D];
+    out[t] = (id >= 0 && id < R) ? d[(size_t)(t / D) * ld + t % D] : 0.f;
+}
+int mask_rows_launch(const float* d, int ld, const int64_t* ids, float* out, int B, int D, int R, hipStream_t s) {
+    hipLaunchKernelGGL(mask_rows_kernel, dim3(cdiv(B * D, 256)), dim3(256), 0, s, d, ld, ids, out, B, D, R);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
 // dtable[r][k] = sum over rows b with ids[b] == r of d[b][k], in batch order
 __global__ void __launch_bounds__(256) scatter_rows_kernel(const float* d, const int64_t* ids, float* dtable, int B, int D, int R) {
     const int t = blockIdx.x * 256 + threadIdx.x;

@@ -339,6 +339,7 @@ int dense_bwd_x_launch(const float* dy, int ldy, const float* w, int w_t, int ld
                        int B, int I, int O, hipStream_t s);
 int sin_emb_launch(const float* time, const float* freqs, float* e, int B, int dim, hipStream_t s);
 int gather_rows_launch(const float* table, const int64_t* ids, float* out, int B, int D, int R, hipStream_t s);
+int mask_rows_launch(const float* d, int ld, const int64_t* ids, float* out, int B, int D, int R, hipStream_t s);
 int scatter_rows_launch(const float* d, const int64_t* ids, float* dtable, int B, int D, int R, hipStream_t s);
 int add_into_launch(float* dst, const float* src, size_t n, hipStream_t s);
 int silu_fwd_launch(const float* z, const float* add, float* y, size_t n, hipStream_t s);

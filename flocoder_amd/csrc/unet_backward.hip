@@ -594,6 +594,7 @@ int build_backward(fc_unet* u) {
         if (ncls > 0) {
             b.scope = "class_cond_mlp";
             float *e = b.dmalloc((size_t)B * td), *cz1 = b.dmalloc((size_t)B * td), *dcz1 = b.dmalloc((size_t)B * td), *de = b.dmalloc((size_t)B * td);
+            float* dTm = b.dmalloc((size_t)B * td);   // d(t_emb) of the rows that HAVE a class (a row with id < 0 got no class term in the forward)
             const float *E = u->R("class_cond_mlp.0.weight"), *cw1 = u->R("class_cond_mlp.1.weight"), *cb1 = u->R("class_cond_mlp.1.bias"),
                         *cw3 = u->R("class_cond_mlp.3.weight");
             const int64_t oE = b.off("class_cond_mlp.0.weight"), c1w = b.off("class_cond_mlp.1.weight"), c1b = b.off("class_cond_mlp.1.bias"),
@@ -602,8 +603,9 @@ int build_backward(fc_unet* u) {
                 if (!cx.ids) return FC_OK;    // no conditioning this step: these parameters get no gradient (left zero, the optimiser skips them)
                 FC_TRY(gather_rows_launch(E, cx.ids, e, cx.B, td, ncls, s));
                 FC_TRY(dense_fwd_launch(e, 0, cw1, cb1, cz1, cx.B, td, td, s));
-                FC_TRY(dense_bwd_w_launch(dT, td, cz1, 1, cx.grads + c3w, cx.grads + c3b, cx.B, td, td, s));
-                FC_TRY(dense_bwd_x_launch(dT, td, cw3, 0, 0, cz1, 1, dcz1, 0, cx.B, td, td, s));
+                FC_TRY(mask_rows_launch(dT, td, cx.ids, dTm, cx.B, td, ncls, s));
+                FC_TRY(dense_bwd_w_launch(dTm, td, cz1, 1, cx.grads + c3w, cx.grads + c3b, cx.B, td, td, s));
+                FC_TRY(dense_bwd_x_launch(dTm, td, cw3, 0, 0, cz1, 1, dcz1, 0, cx.B, td, td, s));
                 FC_TRY(dense_bwd_w_launch(dcz1, td, e, 0, cx.grads + c1w, cx.grads + c1b, cx.B, td, td, s));
                 FC_TRY(dense_bwd_x_launch(dcz1, td, cw1, 0, 0, nullptr, 0, de, 0, cx.B, td, td, s));
                 return scatter_rows_launch(de, cx.ids, cx.grads + oE, cx.B, td, ncls, s);

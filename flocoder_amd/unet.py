@@ -220,7 +220,7 @@ class Unet(nn.Module):
     def set_shared_device(self, shared: Optional[bool]) -> None:
         """Tell the library whether this model's GPU work runs beside other work it is not ordered against (a second replica meant to
         overlap, the collectives of a training job, another process on the same GPU).  ``True`` selects the plan without
-        cross-workgroup waits (same results bit for bit, one more launch per Block); ``False`` insists on the exclusive plan;
+        cross-workgroup waits (same results to fp32 rounding, one more launch per Block); ``False`` insists on the exclusive plan;
         ``None`` (default) decides per call: shared when a process group with more than one rank is live or the caller works on a
         non-default stream, exclusive otherwise."""
         self._shared = shared

@@ -118,7 +118,7 @@ int fc_unet_fused_tail_errors(const fc_unet* u, int* count);
  * nothing else competes for the CUs.  Within one process the library orders these plans against each other across streams by itself.
  * A caller that runs the handle beside other GPU work it does not order against (a second replica meant to overlap, collectives of a
  * training job, another process on the same GPU) declares that with shared = 1: plans are then built without cross-workgroup waits
- * (same results bit for bit, one more launch per Block).  Changing the mode drops the current plan; the next reserve rebuilds it.
+ * (same results to fp32 rounding -- the GroupNorm partials are combined in another order --, one more launch per Block).  Changing the mode drops the current plan; the next reserve rebuilds it.
  * No counterpart in the reference (PyTorch kernels never wait for each other). */
 int fc_unet_set_shared(fc_unet* u, int shared);
 /* Launches of the current plan whose workgroups wait for each other (0 for a shared-mode or training plan). */

@@ -79,11 +79,11 @@ def test_two_replicas_on_two_streams_take_the_shared_plan(reference):
         assert torch.isfinite(o).all() and rel_l2(o.cpu(), want) < 1e-4
     assert all(torch.equal(o, outs[0]) for o in outs)
     a.check_errors(); b.check_errors()
-    # ... and the two plans agree bit for bit (the fused tail is the same arithmetic in the same order)
+    # ... and the two plans agree to fp32 rounding (the fused tail combines the same GroupNorm partials, in a different order)
     from flocoder_amd.sampling import euler_sampler
     c = _model()
     excl = euler_sampler(c, (B, 4, 32, 32), STEPS, cond=ids.to(DEV), source=x.to(DEV))[0]
-    assert c.meeting_launches > 0 and torch.equal(excl, outs[0])
+    assert c.meeting_launches > 0 and rel_l2(excl, outs[0]) < 1e-6
 
 
 def test_two_exclusive_replicas_on_two_streams_are_ordered_by_the_library(reference):
@@ -140,7 +140,7 @@ def test_a_timed_out_meeting_is_loud_not_garbage(reference):
     m.set_shared_device(True)
     with torch.no_grad():
         again = m(x.to(DEV), t, {"class_cond": ids.to(DEV)})
-    assert m.meeting_launches == 0 and torch.equal(again, good)
+    assert m.meeting_launches == 0 and rel_l2(again, good) < 1e-6
     m.check_errors()
 
 

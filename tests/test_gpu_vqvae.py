@@ -121,7 +121,7 @@ def test_full_midi_inpainting_shape_vs_oracle_and_batch_independence():
     assert nparam > 5.0e8, nparam
     sd = synth_state_dict(shapes, 21)
     missing, unexpected = m.load_state_dict(sd, strict=False)
-    assert not unexpected and all(k == "codebook_usage" or k.startswith("vq.") for k in missing)
+    assert not unexpected and not (set(missing) & set(shapes))     # (what stays missing: the quantiser and the NoiseInjection holders, neither on this path)
     m = m.to(DEV)
     gen = torch.Generator().manual_seed(8)
     x1 = torch.rand(1, 1, 128, 128, generator=gen)
