@@ -28,10 +28,15 @@ import subprocess
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+# The HIP runtime reads its switches once, when it is first loaded: the package's process-level defaults (AMD_DIRECT_DISPATCH=0, see
+# flocoder_amd.runtime_defaults) go into the environment before torch is imported.  FLOCODER_AMD_KEEP_ENV=1 leaves the environment alone.
+if not os.environ.get("FLOCODER_AMD_KEEP_ENV"):
+    os.environ.setdefault("AMD_DIRECT_DISPATCH", "0")
+
+import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 N_EULER, BATCH, LATENT, DIM, NCLS = 64, 64, (4, 32, 32), 32, 102
@@ -538,7 +543,8 @@ def main():
                    "plan_entries_per_forward": model.launches_per_forward,
                    "kernel_launches_per_forward": model.launches_per_forward + 9,
                    "kernel_launches_per_euler_step": model.launches_per_forward + 9 - 2,
-                   "plan": "exclusive device (cross-workgroup Block tails)" if model.meeting_launches else "shared device (no cross-workgroup waits)"},
+                   "plan": "exclusive device (cross-workgroup Block tails)" if model.meeting_launches else "shared device (no cross-workgroup waits)",
+                   "runtime_env": {k: os.environ.get(k) for k in ("AMD_DIRECT_DISPATCH", "FLOCODER_AMD_KEEP_ENV") if os.environ.get(k) is not None}},
     }
     line["ode_tflops"] = round(line["value"] * model.flops_per_sample * N_EULER / 1e12, 3)
     line["frac_of_fp32_mfma_peak_end_to_end"] = round(line["ode_tflops"] / (PEAK_FP32_MFMA_TFLOPS * world), 4)

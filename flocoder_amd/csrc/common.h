@@ -96,6 +96,10 @@ struct ConvArgs {
     int Cin = 0, Cout = 0;
     int KS = 1, pad = 0, stride = 1, ups = 0;
     int w_batch_stride = 0;    // != 0: per-sample weights (w + b*stride), tiles then hold one sample
+    // the same weights in the k-step-quad layout [tap][Cin/8][half][Cout][4] (pack kind 6), or null: the 32-row tile at 3x3 loads its MFMA B
+    // operands straight from it, 16 bytes per lane (conv_pipe.hip)
+    const float* w4 = nullptr;
+    const float* res_w4 = nullptr;
     ConvFin fin;
 };
 
@@ -262,6 +266,8 @@ struct PackTable {                            // device-resident job list + (job
     void release();
 };
 int pack_conv_launch(const float* oihw, float* dst /*[KK][I][O]*/, int O, int I, int KH, int KW, hipStream_t s);
+// k-step-quad layout [KK][I/8][half][O][4] (I % 8 == 0): ConvArgs::w4
+int pack_conv_k8_launch(const float* oihw, float* dst, int O, int I, int KK, hipStream_t s);
 // same with zero padding of either channel count: dst [KK][Ipad][Opad]
 int pack_conv_pad_launch(const float* oihw, float* dst, int O, int I, int KK, int Opad, int Ipad, hipStream_t s);
 // operand of the data-gradient pass (forward kernel on dY): [taps flipped][O][nci] for input channels ci0..ci0+nci

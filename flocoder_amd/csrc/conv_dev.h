@@ -87,6 +87,7 @@ __device__ __forceinline__ void conv_params_from_lanes(ConvDev& p) {
     a.s0.xf.beta = as_global(a.s0.xf.beta); a.s0.xf.ss = as_global(a.s0.xf.ss);
     a.s1.p = as_global(a.s1.p); a.s1.xf.stats = as_global(a.s1.xf.stats); a.s1.xf.gamma = as_global(a.s1.xf.gamma);
     a.s1.xf.beta = as_global(a.s1.xf.beta); a.s1.xf.ss = as_global(a.s1.xf.ss);
+    a.w4 = as_global(a.w4); a.res_w4 = as_global(a.res_w4);
     a.w = as_global(a.w); a.bias = as_global(a.bias); a.out = as_global(a.out); a.add = as_global(a.add);
     a.stats_out = as_global(a.stats_out); a.res_w = as_global(a.res_w); a.res_b = as_global(a.res_b); a.res_out = as_global(a.res_out);
     a.fin.gamma = as_global(a.fin.gamma); a.fin.beta = as_global(a.fin.beta); a.fin.res = as_global(a.fin.res);
@@ -100,7 +101,8 @@ __device__ __forceinline__ void conv_params_from_lanes(ConvDev& p) {
 // taken still costs -- the taken path then jumps over it, every jump lands on a cold instruction-cache line (the cache is invalidated
 // at every launch), and a launch is short.  Measured: with the tail code merely compiled OUT the un-fused sampler ran 2.9 % faster.
 constexpr int FL_FIN = 1, FL_RES = 2, FL_POST = 4, FL_XF = 8, FL_CAT = 16, FL_STAMP = 32, FL_STATS = 64, FL_GN1 = 128, FL_POSTOP = 256,
-              FL_NARROW = 512, FL_MULTI = 1024, FL_MEET = 2048, FL_ALL = 4095;
+              FL_NARROW = 512, FL_MULTI = 1024, FL_MEET = 2048, FL_ALL = 4095, FL_W4 = 4096;
+// (4096, outside FL_ALL: the 32-row tile at 3x3 reads its weights from the k-step-quad copy -- ConvArgs::w4 -- 16 bytes per lane)
 // (8: the input may carry a GroupNorm / FiLM / SiLU transform, 16: a second, concatenated source, 32: diagnostic phase stamps, 64: GroupNorm
 // partials of the output, 128: GroupNorm(1) partials of the tail's result, 256: activation / addend on the output, 512: per-lane dword
 // stores when the LDS image for the wide stores does not fit, 1024: several samples per tile -- always on for the 32-row tile,
@@ -305,6 +307,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
     };
     constexpr bool CAN_MULTI = (FL & FL_MULTI) || (WM * MT == 1);     // the 32-row tile is the small-image tile: samples share it
     const bool fast_stats = !CAN_MULTI || p.TB == 1;
+    // The 32-row tile over two 16-pixel samples (every 4x4 layer of the U-Net): accumulator registers 0-7 of a lane are sample 0, 8-15
+    // sample 1 (row = (r & 3) + 8 (r >> 2) + 4 half), so the partials are register sums + shuffles inside the one wave that owns the
+    // tile -- no LDS tables, no barrier.  The general multi-sample form below costs 2.6 k cycles per pass here (stamps, round 3), and a
+    // convolution that closes its Block runs it twice.
+    constexpr bool PAIR_TILE = (WM * MT == 1 && WN * NT == 1);
+    const bool pair_stats = PAIR_TILE && p.TB == 2 && p.rps == 16;
+    auto stats_pair = [&](float* dst, int G, int cpg, int cpgt, int NPG, bool coherent, bool ltab) {
+        if (owner) {
+            float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { const float v = acc[0][0][r], w = acc[0][0][r + 8]; s0 += v; q0 += v * v; s1 += w; q1 += w * w; }
+            s0 += __shfl_xor(s0, 32); q0 += __shfl_xor(q0, 32); s1 += __shfl_xor(s1, 32); q1 += __shfl_xor(q1, 32);
+            for (int o = cpgt >> 1; o > 0; o >>= 1) {
+                s0 += __shfl_xor(s0, o); q0 += __shfl_xor(q0, o); s1 += __shfl_xor(s1, o); q1 += __shfl_xor(q1, o);
+            }
+            const int ncols = min(BN, Cout - n0);
+            if (half == 0 && (l31 & (cpgt - 1)) == 0 && l31 < ncols) {
+                if (b0 < a.B) publish(dst, G, cpg, cpgt, NPG, coherent, ltab, 0, l31 / cpgt, s0, q0);
+                if (b0 + 1 < a.B) publish(dst, G, cpg, cpgt, NPG, coherent, ltab, 1, l31 / cpgt, s1, q1);
+            }
+        }
+    };
 
     // Statistics first, stores last: a workgroup barrier waits for every outstanding global store (s_waitcnt vmcnt(0)), so a
     // barrier AFTER the output stores would park the whole workgroup for the store round trip.
@@ -336,11 +360,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                 }
             }
     }
-    if (do_stats && !fast_stats) block_sums();
+    if (do_stats && !fast_stats && !pair_stats) block_sums();
 
     if (FL & FL_STAMP) conv_stamp(p, 7);
     if (do_stats) {
-        if (fast_stats) stats_fast(a.stats_out, a.Gout, p.cpg, p.cpgt, p.NPG, meeting, fin && !meeting);
+        if (pair_stats) stats_pair(a.stats_out, a.Gout, p.cpg, p.cpgt, p.NPG, meeting, fin && !meeting);
+        else if (fast_stats) stats_fast(a.stats_out, a.Gout, p.cpg, p.cpgt, p.NPG, meeting, fin && !meeting);
         else {
             __syncthreads();
             emit(a.stats_out, a.Gout, p.cpg, p.cpgt, p.NPG, meeting, fin && !meeting);
@@ -448,7 +473,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
         if (LEAN ? bool(FL & FL_GN1) : a.fin.gn1_out != nullptr) {   // GroupNorm(1) partials of the final value for the PreNorm that follows (unet.py:156-160)
             lds_only_barrier();                    // every reader of part* / tab is done
             const int cpg1 = Cout, cpgt1 = Cout < BN ? Cout : BN, NPG1 = Cout >= BN ? Cout / BN : 1;
-            if (fast_stats) stats_fast(a.fin.gn1_out, 1, cpg1, cpgt1, NPG1, false, false);
+            if (pair_stats) stats_pair(a.fin.gn1_out, 1, cpg1, cpgt1, NPG1, false, false);
+            else if (fast_stats) stats_fast(a.fin.gn1_out, 1, cpg1, cpgt1, NPG1, false, false);
             else {
                 block_sums();
                 lds_only_barrier();

@@ -316,10 +316,10 @@ static int conv_geometry(const ConvArgs& a, int tile, bool pipe, ConvDev* d, Con
         p.o_gstat = o; o += align4(2 * TB * (G0 + G1));
         p.o_aff = o; o += p.any_xf ? align4(2 * TB * a.Cin) : 0;
         p.o_patch = o;
-        p.patch_stride = align4(p.P * (t.CC + 1));
-        p.o_wl = o + 2 * p.patch_stride;
         // M32N32K4 at 3x3 loads its weights global -> registers (conv_pipe.hip "DB"): no slab stages in LDS
         const bool direct_b = (t.WMWN == 1 && t.MTNT == 1 && a.KS == 3);
+        p.patch_stride = align4(p.P * (t.CC + (direct_b ? 4 : 1)));    // (its k-step-quad form strides pixels by CC + 4 floats)
+        p.o_wl = o + 2 * p.patch_stride;
         p.wl_stride = direct_b ? 0 : a.KS * a.KS * t.CC * t.BN + (a.res_out ? t.CC * t.BN : 0);
         p.o_wres = 0;
         p.nchunks = cdiv(a.Cin, t.CC);

@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
     ConvDev p;
     conv_params_from_lanes(p);       // p_kernarg itself is never touched: see conv_dev.h
     constexpr int NTHR = 256 + 64 * NL, LT = 64 * NL;
-    constexpr int BN = 32 * NT * WN, CS = CC + 1, KSTEPS = CC / 2, KPW = KSTEPS / WK, Q = CC / 4, PIXSTEP = LT / Q, KK = KS * KS;
+    constexpr int BN = 32 * NT * WN, KSTEPS = CC / 2, KPW = KSTEPS / WK, Q = CC / 4, PIXSTEP = LT / Q, KK = KS * KS;
     static_assert(WM * WN * WK == 4, "4 consumer waves per workgroup");
     // DB ("direct B"): with one 32 x 32 output tile per workgroup every weight element feeds exactly one wave, so staging the slab in
     // LDS buys no reuse -- it only makes the loaders the pacemaker (stamps at 256->256 @4x4: loaders busy 37 k of the 43 k main-loop
@@ -95,6 +95,22 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
     // straight into the MFMA B register layout (two 128-byte row segments per wave load), one chunk ahead, and the loaders keep
     // only the input window.
     constexpr bool DB = (WM * WN == 1 && MT == 1 && NT == 1 && KS == 3);
+    // DB4 (round 3): the same with the weights in the k-step-quad layout (pack kind 6): a lane's B operands of the four k-steps its wave
+    // owns in a chunk are ONE 16-byte load per tap (nine loads per chunk instead of 36, uniform base + 32-bit lane offset), and the two
+    // register sets swap roles from chunk to chunk instead of being copied.  The copy was the round-2 kernel's hidden stall: the compiler
+    // moved `wcur = wnxt` up to the last use of each wcur register, and every such move waits for a load issued moments earlier --
+    // s_waitcnt vmcnt(35) in front of the chunk's FIRST MFMA, vmcnt(8) in front of its fourth: the "prefetch" was waited for at once
+    // (ISA of <1,1,4,1,1,32,4,3,8,64>; 115 cycles per MFMA instead of 64).
+    constexpr bool DB4 = DB && (FL & FL_W4) != 0;
+#ifndef FC_DB4_CHAINS
+#define FC_DB4_CHAINS 2
+#endif
+    constexpr int DB4_CHAINS = FC_DB4_CHAINS;
+    // Pixel stride of the staged window in LDS.  CC + 1 keeps the dword operand reads of the MFMA lanes (one pixel per lane) off each other's
+    // banks.  DB4 reads a lane's four k-steps of a tap as ONE 16-byte LDS read instead: inside every 8-channel block the window is stored
+    // as [parity][4] (channel c at 8 (c / 8) + 4 (c & 1) + ((c >> 1) & 3)), so the channels 8 wk + 2 kk + half, kk = 0..3, are contiguous, and
+    // the stride is a multiple of four floats (CC + 4) for the alignment the wide read needs.
+    constexpr int CS = DB4 ? CC + 4 : CC + 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const ConvArgs& a = p.a;
     float* gstat = smem + p.o_gstat;
@@ -261,7 +277,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
                     const int tb = fastdiv(pix, p.magic_phw), r = pix - tb * PHW, py = fastdiv(r, p.magic_pw), px = r - py * PW;
                     const int iy = y0 * a.stride - a.pad + py, ix = x0 * a.stride - a.pad + px, b = b0 + tb;
                     if (b < a.B && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) e_po[k] = (b * a.Hs + (iy >> a.ups)) * a.Ws + (ix >> a.ups);
-                    e_lds[k] = pix * CS + q4;
+                    e_lds[k] = pix * CS + (DB4 ? 8 * ((ltid % Q) >> 1) + 2 * ((ltid % Q) & 1) : q4);
                     e_tb[k] = tb;
                 }
             }
@@ -325,7 +341,8 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
                     if (act) { x.x = silu_f(x.x); x.y = silu_f(x.y); x.z = silu_f(x.z); x.w = silu_f(x.w); }
                 }
                 float* d = pb + e_lds[k];
-                d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+                if (DB4) { d[0] = x.x; d[1] = x.z; d[4] = x.y; d[5] = x.w; }      // [parity][4] inside the 8-channel block
+                else { d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w; }
             }
         };
         unsigned long long dbg_mem = 0, dbg_store = 0, dbg_bar = 0, dbg_issue = 0, dbg_dma = 0;   // diagnostics: cycles per loader phase
@@ -382,8 +399,9 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
         }
         const int bbase = half * BN + wn * NT * 32 + l31;
         const int kk0 = wk * KPW;
+        const int abase4 = abase[0] - half + 8 * wk + 4 * half;     // DB4: this lane's [parity][4] quad of its wave's 8-channel block
         unsigned long long dbg_cbar = 0;
-        constexpr int NB = DB ? KK * KPW : 1, NR = DB ? KPW : 1;
+        constexpr int NB = (DB && !DB4) ? KK * KPW : 1, NR = (DB && !DB4) ? KPW : 1;
         float wcur[NB], wnxt[NB], rcur[NR], rnxt[NR];
         const int ncol = n0 + l31;
         const bool colok = ncol < Cout;                 // a column beyond Cout reads the zero block with zero strides
@@ -401,7 +419,21 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
                 if (has_res) r[kk] = rq[(size_t)c * wcs];
             }
         };
-        if (DB) fetch_w(0, wcur, rcur);
+        // DB4: registers A / B, each the nine taps' float4 (component j = k-step kk0 + j) of one chunk, plus the res_conv quad
+        constexpr int NQ = DB4 ? KK : 1;
+        f32x4 wA[NQ], wB[NQ], rA, rB;
+        const unsigned lane_off4 = DB4 ? (unsigned)(half * Cout + ncol) * 4u : 0u;       // floats; DB4 launches have Cout % 32 == 0: every column exists
+        const int wk_u = __builtin_amdgcn_readfirstlane(wk);
+        auto fetch4 = [&](int i, f32x4 (&w)[NQ], f32x4& r) {
+            // uniform base: chunk i, this wave's K-quarter = row block c8 = i * (CC / 8) + wk of [tap][Cin/8][half][Cout][4]
+            const size_t blk = (size_t)((i * (CC / 8) + wk_u) * 2) * (size_t)Cout * 4;
+            const float* ub = a.w4 + blk;
+#pragma unroll
+            for (int tap = 0; tap < NQ; ++tap) w[tap] = *reinterpret_cast<const f32x4*>(ub + (size_t)tap * ((size_t)Cin * Cout) + lane_off4);
+            if (has_res) r = *reinterpret_cast<const f32x4*>(a.res_w4 + blk + lane_off4);
+        };
+        if (DB4) fetch4(0, wA, rA);
+        else if (DB) fetch_w(0, wcur, rcur);
         if (FL & FL_STAMP) conv_stamp(p, 1);
         gn_tables(false, 0, 1);
         if (meet && tid == 0) {
@@ -410,6 +442,76 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
         }
         __syncthreads();        // stage 0 ready
         if (FL & FL_STAMP) conv_stamp(p, 4);
+        f32x16 acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+        if constexpr (DB4) {
+            // one chunk on register set `wc`, the next chunk's weights requested into `wn` first: they are not read before the NEXT chunk
+            // (a whole chunk of MFMAs of lookahead), and nothing is copied.  The A operands of tap t + 1 are read from LDS before the
+            // MFMAs of tap t are issued.
+            auto chunk = [&](int i, f32x4 (&wc)[NQ], f32x4& rc, f32x4 (&wn)[NQ], f32x4& rn) {
+                const float* patch = patch0 + (i & 1) * p.patch_stride;
+                // UNCONDITIONAL (the last chunk re-requests itself): s_waitcnt takes an immediate, so with a conditional request the
+                // compiler must count for the path that skipped it -- vmcnt(8) instead of vmcnt(17) in front of the first MFMA, i.e. a wait
+                // for the request issued two lines above
+                fetch4(i + 1 < nchunks ? i + 1 : i, wn, rn);
+                __builtin_amdgcn_sched_barrier(0);       // the requests stay HERE: left alone, the scheduler sinks them behind the chunk's MFMAs
+                static_assert(!DB4 || KPW == 4, "one 16-byte operand read = the four k-steps of a wave");
+                (void)patch;
+                // Pinned schedule: the operand quad of tap t + 1 is requested (asm: the compiler neither counts nor moves it), then the four
+                // MFMAs of tap t run -- 256 cycles of cover for the LDS round trip --, then the wait.  Left to the scheduler the reads
+                // ended up directly in front of their first use (s_waitcnt lgkmcnt right behind ds_read, every eighth MFMA).
+                const unsigned pl = smem_lds + 4u * (unsigned)(p.o_patch + (i & 1) * p.patch_stride + abase4);
+                const unsigned prow = 4u * (unsigned)(PW * CS);
+                auto lds_quad = [&](f32x4& dst, int tapn) {
+                    const unsigned ad = pl + (unsigned)(tapn / KS) * prow;
+                    switch (tapn % KS) {         // column offset as an immediate
+                        case 0: asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(ad) : "memory"); break;
+                        case 1: asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(ad), "n"(4 * CS) : "memory"); break;
+                        default: asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(ad), "n"(8 * CS) : "memory"); break;
+                    }
+                };
+                f32x4 av, an;
+                lds_quad(av, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av) :: "memory");
+                an = av;
+#pragma unroll
+                for (int tap = 0; tap < KK; ++tap) {
+                    // (after the last tap: the centre tap again, for the fused res_conv)
+                    if (tap + 1 < KK || has_res) lds_quad(an, tap + 1 < KK ? tap + 1 : KK / 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (DB4_CHAINS == 2) {
+                        // two independent accumulator chains: an MFMA that waits for its predecessor's result seems to hold the SIMD's issue
+                        // port while it waits, and the staging waves that share the SIMD starve (stamps, round 3)
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], wc[tap][0], acc[0][0], 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], wc[tap][1], acc2, 0, 0, 0);
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], wc[tap][2], acc[0][0], 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], wc[tap][3], acc2, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int kk = 0; kk < KPW; ++kk) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], wc[tap][kk], acc[0][0], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (tap + 1 < KK || has_res) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(an) :: "memory");
+                    av = an;
+                }
+                if (has_res) {
+#pragma unroll
+                    for (int kk = 0; kk < KPW; ++kk) accr[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], rc[kk], accr[0][0], 0, 0, 0);
+                }
+                unsigned long long t0 = ((FL & FL_STAMP) && p.stamps) ? __builtin_amdgcn_s_memtime() : 0ull;
+                loader_handover();                       // not __syncthreads(): its vmcnt(0) would wait for the weights requested above
+                if ((FL & FL_STAMP) && p.stamps) dbg_cbar += __builtin_amdgcn_s_memtime() - t0;
+            };
+            for (int i = 0; i < nchunks; i += 2) {
+                chunk(i, wA, rA, wB, rB);
+                if (i + 1 < nchunks) chunk(i + 1, wB, rB, wA, rA);
+            }
+            if (DB4_CHAINS == 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][0][r] += acc2[r];
+            }
+        } else {
         for (int i = 0; i < nchunks; ++i) {
             const float* patch = patch0 + (i & 1) * p.patch_stride;
             const float* wl = wl0 + (i % p.nwb) * p.wl_stride + bbase;
@@ -460,6 +562,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
                 __syncthreads();    // stage i consumed; stage i+1 (if any) ready
             }
             if ((FL & FL_STAMP) && p.stamps) dbg_cbar += __builtin_amdgcn_s_memtime() - t0;
+        }
         }
         if ((FL & FL_STAMP) && p.stamps && lane == 0) p.stamps[((size_t)blockIdx.x * 8 + wave8) * 16 + 11] = dbg_cbar;
         if (FL & FL_STAMP) conv_stamp(p, 5);
@@ -518,6 +621,14 @@ static int lean_attr() {
     return FC_OK;
 }
 
+// the k-step-quad (FL_W4) flavours exist for the one tile that feeds its weights from registers: M32N32K4 at 3x3
+template <int FL>
+static int lean_attr_db4() {
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pipe_kernel<1, 1, 4, 1, 1, 32, kLeanNPL, 3, 8, FL | FL_W4>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return FC_OK;
+}
+
 template <int FL>
 static int lean_attr_wide1() {
 #define X(T, WM, WN, WK, MT, NT, CC, K, NL)                                                                               \
@@ -553,6 +664,12 @@ static int lean_launch_wide1(const ConvDev& d, int tile, int grid, size_t lds, h
     }
 }
 
+template <int FL>
+static int lean_launch_db4(const ConvDev& d, int tile, int grid, size_t lds, hipStream_t s, int* occ) {
+    if (tile != TILE_M32N32K4 || d.P * (32 / 4) > 64 * 8 * kLeanNPL) return -1;
+    return launch_or_query((conv_pipe_kernel<1, 1, 4, 1, 1, 32, kLeanNPL, 3, 8, FL | FL_W4>), 256 + 64 * 8, d, grid, lds, s, occ);
+}
+
 template <int KS, int FL>
 static int lean_launch(const ConvDev& d, int tile, int grid, size_t lds, hipStream_t s, int* occ) {
     switch (tile) {
@@ -575,7 +692,7 @@ int conv_pipe_init() {
     FC_TRY(pipe_attr_ks<2>());
     FC_TRY(pipe_attr_ks<3>());
     FC_TRY(pipe_attr_ks<5>());
-#define X(F) FC_TRY((lean_attr<3, (F)>()));
+#define X(F) FC_TRY((lean_attr<3, (F)>())); FC_TRY((lean_attr_db4<(F)>()));
     FC_LEAN_FLAVOURS_3(X)
 #undef X
 #define X(F) FC_TRY((lean_attr<1, (F)>())); FC_TRY((lean_attr_wide1<(F)>()));
@@ -610,6 +727,15 @@ static int conv_pipe_dispatch(const ConvDev& d, int tile, int grid, size_t lds, 
                          ((d.a.fin.gamma && !d.fin_local) ? FL_MEET : 0);
         int r = -1;
         if (d.a.KS == 3) {
+            // register-fed weights in the k-step-quad layout: whole 32-channel chunks, whole 32-column tiles, the centre tap at (1, 1)
+            static const bool no_w4 = std::getenv("FLOCODER_AMD_NO_W4") != nullptr;
+            const bool w4 = !no_w4 && small_tile && d.a.w4 && d.a.Cin % 32 == 0 && d.a.Cout % 32 == 0 && d.a.pad == 1 && !d.a.w_batch_stride &&
+                            (!d.a.res_out || d.a.res_w4);
+            if (w4) {
+#define X(F) if (r == -1 && need == (F)) r = lean_launch_db4<(F)>(d, tile, grid, lds, s, occ);
+                FC_LEAN_FLAVOURS_3(X)
+#undef X
+            }
 #define X(F) if (r == -1 && need == (F)) r = lean_launch<3, (F)>(d, tile, grid, lds, s, occ);
             FC_LEAN_FLAVOURS_3(X)
 #undef X

@@ -80,6 +80,7 @@ __global__ void __launch_bounds__(256) transpose_batched_kernel(const float* src
 // ---- a whole table of re-layout jobs in ONE launch (a training step re-packs ~190 weight tensors: launch latency, not bytes) ----
 // kinds: 0 conv OIHW -> [KK][I][O] (a=O b=I c=KK) | 1 s2d (a=O b=C) | 2 transpose (a=R b=Cc c=ld d=col0) | 3 copy (a=n)
 //        4 conv with channel padding (a=O b=I c=KK d=Opad e=Ipad) | 5 data-gradient operand (a=O b=I c=KS d=ci0 e=nci)
+//        6 conv in k-step-quad layout (a=O b=I c=KK)
 __global__ void __launch_bounds__(256) pack_table_kernel(const PackJob* jobs, const int2* blocks) {
     const int2 bj = blocks[blockIdx.x];          // (job, block index inside the job)
     const PackJob j = jobs[bj.x];
@@ -97,6 +98,11 @@ __global__ void __launch_bounds__(256) pack_table_kernel(const PackJob* jobs, co
             case 3: dst[t] = src[t]; break;
             case 4: { const int o = (int)(t % j.d); const size_t r = t / j.d; const int ci = (int)(r % j.e), tap = (int)(r / j.e);
                       dst[t] = (o < j.a && ci < j.b) ? src[((size_t)o * j.b + ci) * j.c + tap] : 0.f; break; }
+            case 6: {   // conv OIHW -> [tap][I/8][half][O][4]: element (tap, ci = 8 c8 + 2 jj + half, o) -- the MFMA B operand of four consecutive
+                        // k-steps of one lane as ONE 16-byte load (conv_pipe.hip, register-fed weights); a=O b=I c=KK
+                const int jj = (int)(t & 3); size_t r = t >> 2; const int o = (int)(r % j.a); r /= j.a; const int half = (int)(r & 1); r >>= 1;
+                const int c8 = (int)(r % (j.b / 8)), tap = (int)(r / (j.b / 8));
+                dst[t] = src[((size_t)o * j.b + 8 * c8 + 2 * jj + half) * j.c + tap]; break; }
             default: { const int KK = j.c * j.c; const int i = (int)(t % j.e); const size_t r = t / j.e; const int o = (int)(r % j.a), tap = (int)(r / j.a);
                        const int ky = j.c - 1 - tap / j.c, kx = j.c - 1 - tap % j.c;
                        dst[t] = src[((size_t)o * j.b + j.d + i) * KK + ky * j.c + kx]; break; }
@@ -111,6 +117,7 @@ size_t pack_job_total(const PackJob& j) {
         case 2: return (size_t)j.a * j.b;
         case 3: return (size_t)j.a;
         case 4: return (size_t)j.d * j.e * j.c;
+        case 6: return (size_t)j.a * j.b * j.c;
         default: return (size_t)j.a * j.e * j.c * j.c;
     }
 }
@@ -149,6 +156,20 @@ static int pgrid(size_t total) { size_t g = (total + 255) / 256; return (int)(g 
 
 int pack_conv_launch(const float* oihw, float* dst, int O, int I, int KH, int KW, hipStream_t s) {
     hipLaunchKernelGGL(pack_conv_kernel, dim3(pgrid((size_t)O * I * KH * KW)), dim3(256), 0, s, oihw, dst, O, I, KH * KW);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+// OIHW -> [tap][I/8][half][O][4] (the table launch's kind 6, alone: test / debug entry points)
+__global__ void __launch_bounds__(256) pack_conv_k8_kernel(const float* src, float* dst, int O, int I, int KK) {
+    const size_t total = (size_t)O * I * KK;
+    for (size_t t = blockIdx.x * 256ull + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        const int jj = (int)(t & 3); size_t r = t >> 2; const int o = (int)(r % O); r /= O; const int half = (int)(r & 1); r >>= 1;
+        const int c8 = (int)(r % (I / 8)), tap = (int)(r / (I / 8));
+        dst[t] = src[((size_t)o * I + 8 * c8 + 2 * jj + half) * KK + tap];
+    }
+}
+int pack_conv_k8_launch(const float* oihw, float* dst, int O, int I, int KK, hipStream_t s) {
+    hipLaunchKernelGGL(pack_conv_k8_kernel, dim3(pgrid((size_t)O * I * KK)), dim3(256), 0, s, oihw, dst, O, I, KK);
     FC_HIP(hipGetLastError());
     return FC_OK;
 }

@@ -90,6 +90,9 @@ struct ParamStore {
     PackTable pack_table;                          // all of `packops` as one launch
     bool loaded = false;
 
+    bool want_k8 = false;   // also keep 3x3 / 1x1 conv weights in the k-step-quad layout (pack kind 6) where the shapes allow: the U-Net's low-resolution layers
+    // the k-step-quad copy of a convolution weight, or null when there is none
+    const float* P8(const std::string& n) const { auto it = pk.find(n + "#k8"); return it == pk.end() ? nullptr : packed + it->second; }
     const float* R(const std::string& n) const { return raw + params[pidx.at(n)].offset; }
     const float* P(const std::string& n) const { return packed + pk.at(n); }
     bool has(const std::string& n) const { return pidx.count(n) != 0; }
@@ -116,6 +119,10 @@ struct ParamStore {
         if (bias) declare(n + ".bias", {O});
         const int64_t dst = pk_alloc(n + ".weight", (int64_t)O * I * K * K);
         packops.push_back({0, params[pidx[n + ".weight"]].offset, dst, O, I, K, K});
+        if (want_k8 && (K == 3 || K == 1) && I % 32 == 0 && O % 32 == 0) {
+            const int64_t d8 = pk_alloc(n + ".weight#k8", (int64_t)O * I * K * K);
+            packops.push_back({6, params[pidx[n + ".weight"]].offset, d8, O, I, K * K, 0});
+        }
     }
     void decl_linear_t(const std::string& n, int O, int I) {  // stored transposed [I][O]
         declare(n + ".weight", {O, I});
@@ -152,6 +159,7 @@ struct ParamStore {
                 case 2: FC_TRY(pack_transpose_launch(src, dst, o.a, o.b, o.c, o.d, s)); break;
                 case 3: FC_HIP(hipMemcpyAsync(dst, src, (size_t)o.a * sizeof(float), hipMemcpyDeviceToDevice, s)); break;
                 case 4: FC_TRY(pack_conv_pad_launch(src, dst, o.a, o.b, o.c, o.d, o.e, s)); break;
+                case 6: return fail(FC_E_STATE, "pack: the k-step-quad layout exists in the table launch only");
             }
         }
         return FC_OK;

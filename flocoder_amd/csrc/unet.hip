@@ -146,9 +146,12 @@ struct Builder : PlanBuilder {
         if (skip) { a.s1.p = skip->p; a.s1.C = skip->C; }
         a.Hs = x.H; a.Ws = x.W; a.KS = 3; a.pad = 1;
         a.w = u->P(p + ".block1.proj.weight"); a.bias = u->R(p + ".block1.proj.bias");
+        a.w4 = u->P8(p + ".block1.proj.weight");
         if (cin != cout) {
             rb = act(cout, x.H, x.W);
             a.res_w = u->P(p + ".res_conv.weight"); a.res_b = u->R(p + ".res_conv.bias"); a.res_out = rb.p;
+            a.res_w4 = u->P8(p + ".res_conv.weight");
+            if (!a.res_w4) a.w4 = nullptr;      // both operands or neither
         }
         conv(a, h1, G, &st1);
         if (pl->join_at == 0) pl->join_at = (int)pl->ops.size();   // first reader of the scale / shift table
@@ -157,6 +160,7 @@ struct Builder : PlanBuilder {
         b.s0.xf = xf_of(st1, 2, u->R(p + ".block1.norm.weight"), u->R(p + ".block1.norm.bias"), pl->ss + u->ss_off.at(p), u->S);
         b.Hs = x.H; b.Ws = x.W; b.KS = 3; b.pad = 1;
         b.w = u->P(p + ".block2.proj.weight"); b.bias = u->R(p + ".block2.proj.bias");
+        b.w4 = u->P8(p + ".block2.proj.weight");
         // inference plans close the Block inside conv2 (ConvFin) when the launch keeps its whole grid resident; training plans keep
         // the raw h2 and its statistics for the backward
         // Measured on one box, B=64 (profiles/README.md r01_g): 494 samples/s with the fused tails against 503 without -- the
@@ -472,7 +476,7 @@ static int build_plan(fc_unet* u, Plan* pl, int maxB, int H, int W) {
         ConvArgs a;
         a.s0.p = x.p; a.s0.C = x.C; a.Hs = x.H; a.Ws = x.W;
         if (i == L - 1) {
-            a.KS = 3; a.pad = 1; a.w = u->P(p + ".3.weight"); a.bias = u->R(p + ".3.bias");
+            a.KS = 3; a.pad = 1; a.w = u->P(p + ".3.weight"); a.bias = u->R(p + ".3.bias"); a.w4 = u->P8(p + ".3.weight");
             Act o = b.act(cs[i + 1], x.H, x.W);
             b.conv(a, o, 0, nullptr);
             pl->tape.push_back({3, (int)pl->convs.size()});
@@ -511,14 +515,14 @@ static int build_plan(fc_unet* u, Plan* pl, int maxB, int H, int W) {
         ConvArgs a;
         a.s0.p = x.p; a.s0.C = x.C; a.Hs = x.H; a.Ws = x.W; a.KS = 3; a.pad = 1;
         if (i == L - 1) {
-            a.w = u->P(p + ".3.weight"); a.bias = u->R(p + ".3.bias");
+            a.w = u->P(p + ".3.weight"); a.bias = u->R(p + ".3.bias"); a.w4 = u->P8(p + ".3.weight");
             Act o = b.act(din, x.H, x.W);
             b.conv(a, o, 0, nullptr);
             pl->tape.push_back({3, (int)pl->convs.size()});
             pl->convs.push_back({p + ".3", x, o, 3, 1, 1, 0});
             x = o;
         } else {  // nn.Upsample(nearest x2) folded into the conv's loader (unet.py:42-46)
-            a.ups = 1; a.w = u->P(p + ".3.1.weight"); a.bias = u->R(p + ".3.1.bias");
+            a.ups = 1; a.w = u->P(p + ".3.1.weight"); a.bias = u->R(p + ".3.1.bias"); a.w4 = u->P8(p + ".3.1.weight");
             Act o = b.act(din, x.H * 2, x.W * 2);
             b.conv(a, o, 0, nullptr);
             pl->tape.push_back({3, (int)pl->convs.size()});
@@ -691,6 +695,7 @@ int fc_unet_create(const fc_unet_config* cfg, int device, fc_unet** out) {
     std::unique_ptr<fc_unet> u(new fc_unet);
     u->cfg = *cfg;
     u->device = device;
+    u->want_k8 = std::getenv("FLOCODER_AMD_NO_K8") == nullptr;
     FC_TRY(declare_all(u.get()));
     if (device < 0) {  // description only: parameter table without touching a GPU
         *out = u.release();
@@ -1096,8 +1101,8 @@ int fc_debug_unet_break_meeting(fc_unet* u) {
     return FC_OK;
 }
 
-int fc_debug_set_fused_tail(int on) {   // plans built from now on use (1) / do not use (0) the fused Block tails
-    fc::g_fused_tail = on ? 1 : 0;
+int fc_debug_set_fused_tail(int on) {   // plans built from now on use (1) / do not use (0) the fused Block tails; < 0: back to the default (environment)
+    fc::g_fused_tail = on < 0 ? -1 : (on ? 1 : 0);
     return FC_OK;
 }
 
@@ -1128,6 +1133,12 @@ int fc_debug_conv(const float* src0, int c0, const float* src1, int c1, const fl
     FC_HIP(hipMalloc(reinterpret_cast<void**>(&wp), (size_t)cout * a.Cin * ksize * ksize * sizeof(float)));
     int r = pack_conv_launch(w_oihw, wp, cout, a.Cin, ksize, ksize, s);
     a.w = wp;
+    float* wp8 = nullptr;       // the k-step-quad copy where the shapes allow it, as a U-Net plan would carry it (conv_pipe.hip FL_W4)
+    if (r == FC_OK && ksize == 3 && a.Cin % 32 == 0 && cout % 32 == 0 && std::getenv("FLOCODER_AMD_NO_K8") == nullptr) {
+        FC_HIP(hipMalloc(reinterpret_cast<void**>(&wp8), (size_t)cout * a.Cin * 9 * sizeof(float)));
+        r = pack_conv_k8_launch(w_oihw, wp8, cout, a.Cin, 9, s);
+        a.w4 = wp8;
+    }
     ConvGeom g;
     if (r == FC_OK) r = conv_plan(a, tile_cfg, &g);
     if (r == FC_OK) { if (stats_T) *stats_T = g.T; if (stats_nt) *stats_nt = g.n_t; r = conv_launch(a, g.tile, s); }
@@ -1145,6 +1156,7 @@ int fc_debug_conv(const float* src0, int c0, const float* src1, int c1, const fl
     }
     (void)hipStreamSynchronize(s);
     (void)hipFree(wp);
+    if (wp8) (void)hipFree(wp8);
     return r;
 }
 

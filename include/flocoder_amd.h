@@ -129,7 +129,8 @@ int fc_unet_meeting_launches(const fc_unet* u);
 int fc_unet_check(fc_unet* u, void* stream, int synchronize);
 /* Test hook: makes the next run of the plan's first meeting launch time out. */
 int fc_debug_unet_break_meeting(fc_unet* u);
-/* Experiment switch: plans built after the call use (1) / do not use (0) the cross-workgroup Block tails (default on). */
+/* Experiment switch: plans built after the call use (1) / do not use (0) the cross-workgroup Block tails; < 0 restores the default
+ * (on, unless FLOCODER_AMD_FUSED_TAIL says otherwise). */
 int fc_debug_set_fused_tail(int on);
 double fc_unet_flops_per_sample(const fc_unet* u);
 /* Launch i of the plan: kernel family, the reference module it implements, its algorithmic FLOPs per sample. */

@@ -44,6 +44,7 @@ def gn_ref(y, groups):
     (2, 64, 64, 16, 16, 3, 1),
     (5, 128, 128, 4, 4, 3, 1),
     (2, 256, 256, 8, 8, 3, 1),
+    (3, 96, 64, 4, 4, 3, 1),          # three 32-channel chunks: the register-fed 32-row tile's odd tail (conv_pipe.hip DB4)
     (2, 32, 96, 16, 16, 1, 0),
     (3, 12, 16, 8, 8, 5, 2),
     (2, 8, 8, 2, 2, 3, 1),

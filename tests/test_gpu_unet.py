@@ -187,7 +187,7 @@ def test_bench_batch_forward_with_fused_tails():
     try:
         _fused_tail_body(Unet)
     finally:
-        B.check(B.lib().fc_debug_set_fused_tail(0))
+        B.check(B.lib().fc_debug_set_fused_tail(-1))      # back to the default: later tests in this process build default plans
 
 
 def _fused_tail_body(Unet):
