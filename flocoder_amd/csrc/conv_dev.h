@@ -394,6 +394,23 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
         // a release/acquire fence pair would cost every workgroup (measured: 120 us per launch instead of 25).
         float* tab = smem + p.o_fin;
         const int ngt = p.cpg >= BN ? 1 : BN / p.cpg;
+        // The residual is requested BEFORE the wait for the other workgroups' partials: it depends on nothing computed here, it is a cold
+        // miss (another kernel wrote it), and behind the meeting it was a second memory round trip on the tail's critical path (round 3).
+        float rs[MT][NT][16];
+        if (owner) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int n = n0 + (wn * NT + nt) * 32 + l31;
+                    const bool nok = n < Cout;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int px = pix_of(mt, r);
+                        rs[mt][nt][r] = (a.fin.res && nok && px >= 0) ? a.fin.res[(size_t)px * Cout + n] : 0.f;
+                    }
+                }
+        }
         if (meeting) {
             // One round trip when the others have already published: every thread polls ONE granule (sc1 loads that bypass this CU's
             // L1) until its tag is this launch's epoch, parks the value in LDS; then the Chan combination runs from LDS.  Bounded:
@@ -453,19 +470,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                     const bool nok = n < Cout;
                     const int gl = p.cpg >= BN ? 0 : ncol / p.cpg;
                     const float gam = pre ? pre[2 * NT + nt] : (nok ? a.fin.gamma[n] : 0.f), bet = pre ? pre[3 * NT + nt] : (nok ? a.fin.beta[n] : 0.f);
-                    float rs[16];   // residual: all sixteen rows requested before the first is used
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int px = pix_of(mt, r);
-                        rs[r] = (a.fin.res && nok && px >= 0) ? a.fin.res[(size_t)px * Cout + n] : 0.f;
-                    }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                         const int tb = m >> (p.TWl + p.THl);
                         const float mean = tab[2 * (tb * ngt + gl)], rstd = tab[2 * (tb * ngt + gl) + 1];
                         const float A = rstd * gam;
-                        const float v = silu_f(A * acc[mt][nt][r] + (bet - mean * A)) + rs[r];
+                        const float v = silu_f(A * acc[mt][nt][r] + (bet - mean * A)) + rs[mt][nt][r];
                         acc[mt][nt][r] = (nok && b0 + tb < a.B) ? v : 0.f;
                     }
                 }

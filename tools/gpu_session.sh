@@ -25,6 +25,11 @@ for s in $STEPS; do
     pmc)       (cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_fetch -- python3 $GRAFT_REPO_ROOT/tools/pmc_forward.py 3 > $GRAFT_REPO_ROOT/$OUT/pmc_fetch.log 2>&1) &&
                (cd /tmp && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_write -- python3 $GRAFT_REPO_ROOT/tools/pmc_forward.py 3 > $GRAFT_REPO_ROOT/$OUT/pmc_write.log 2>&1) || exit 1
                python tools/pmc_summary.py $(find $OUT/pmc_fetch -name '*counter_collection.csv') $(find $OUT/pmc_write -name '*counter_collection.csv') 3 > $OUT/pmc_traffic.json; head -5 $OUT/pmc_traffic.json ;;
+    pmccodec)  for what in sdvae_decode vqvae_encode vqvae_decode; do
+                 (cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_${what}_fetch -- python3 $GRAFT_REPO_ROOT/tools/pmc_codec.py $what 2 > $GRAFT_REPO_ROOT/$OUT/pmc_${what}_fetch.log 2>&1) &&
+                 (cd /tmp && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_${what}_write -- python3 $GRAFT_REPO_ROOT/tools/pmc_codec.py $what 2 > $GRAFT_REPO_ROOT/$OUT/pmc_${what}_write.log 2>&1) || { tail -5 $OUT/pmc_${what}_fetch.log $OUT/pmc_${what}_write.log; exit 1; }
+                 python tools/pmc_summary.py $(find $OUT/pmc_${what}_fetch -name '*counter_collection.csv') $(find $OUT/pmc_${what}_write -name '*counter_collection.csv') 2 "tools/pmc_codec.py $what" > $OUT/pmc_traffic_${what}.json; head -4 $OUT/pmc_traffic_${what}.json
+               done ;;
     mfma)      (cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_mfma -- python3 $GRAFT_REPO_ROOT/tools/pmc_forward.py 3 > $GRAFT_REPO_ROOT/$OUT/pmc_mfma.log 2>&1) || { tail -20 $OUT/pmc_mfma.log; exit 1; }
                python tools/pmc_mfma_summary.py $(find $OUT/pmc_mfma -name '*counter_collection.csv') > $OUT/pmc_mfma.json; head -30 $OUT/pmc_mfma.json ;;
     trainprof) (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/trainprof -- python3 $GRAFT_REPO_ROOT/tools/bench_train.py --steps 25 --warmup 5 > $GRAFT_REPO_ROOT/$OUT/trainprof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/trainprof.err) || { tail -20 $OUT/trainprof.err; exit 1; }
