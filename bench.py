@@ -333,8 +333,20 @@ def train_step_secondary(device, dim, hw, batch, classes, steps=40, warmup=5):
     assert torch.isfinite(loss)
     out = {"workload": f"train_flow step: batch {batch}, latents 4x{hw}x{hw}, U-Net dim={dim} dim_mults [1,2,4,8] n_classes={classes}, greedy OT pairing, "
                        f"Adam lr 1e-4, EMA 0.999; {steps} steps timed on one GPU",
-           "ms_per_step": round(1e3 * t, 3), "samples_per_s": round(batch / t, 1), "step_tflops_3x_fwd": round(3 * net.flops_per_sample * batch / t / 1e12, 2)}
+           "ms_per_step": round(1e3 * t, 3), "samples_per_s": round(batch / t, 1), "step_tflops_3x_fwd": round(3 * net.flops_per_sample * batch / t / 1e12, 2),
+           "runtime_env": "this (sampler) process: AMD_DIRECT_DISPATCH=" + os.environ.get("AMD_DIRECT_DISPATCH", "unset")}
     del tr, net
+    # the training step is host-paced plain launches and wants the runtime's DEFAULT dispatch mode (flocoder_amd.runtime_defaults("training")):
+    # the same step in a process of its own without the sampler's setting (tools/bench_train.py) is the figure a training job sees
+    try:
+        env = {k: v for k, v in os.environ.items() if k != "AMD_DIRECT_DISPATCH"}
+        env["FLOCODER_AMD_KEEP_ENV"] = "1"
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_train.py"), "--dim", str(dim), "--hw", str(hw), "--batch", str(batch),
+                            "--classes", str(classes), "--steps", str(steps), "--warmup", str(warmup)], env=env, capture_output=True, text=True, timeout=300)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        out["default_dispatch_process"] = {"ms_per_step": d["ms_per_step"], "samples_per_s": d["value"], "step_tflops_3x_fwd": d.get("step_tflops_3x_fwd")}
+    except Exception as e:       # the leg is informative: never fail the bench line over it
+        out["default_dispatch_process"] = {"error": repr(e)[:200]}
     return out
 
 

@@ -60,6 +60,9 @@ SIGNATURES = {
     "fc_unet_train_reserve": (_i, [_vp, _i, _i, _i]),
     "fc_unet_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "fc_unet_backward_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _vp]),
+    "fc_unet_backward_parts": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "fc_unet_grad_buckets": (_i, [_vp, C.POINTER(_i64)]),
+    "fc_unet_set_grad_buckets": (_i, [_vp, _i]),
     "fc_unet_arena_serial": (C.c_uint64, [_vp]),
     "fc_unet_class_param_range": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "fc_flow_interp": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _vp]),

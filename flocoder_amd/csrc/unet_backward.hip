@@ -155,6 +155,7 @@ struct BwdBuilder : PlanBuilder {
         norm_jobs.push_back({s12l, xf.gamma, xf.beta, xf.ss, off(norm + ".weight"), off(norm + ".bias"), ss_col, h.C});
     }
     std::vector<NormJob> norm_jobs;
+    std::vector<std::string> film_blocks;   // ResnetBlocks whose backward has been emitted since the deferred tables last ran (their dss columns)
     // y = act(gn(h)).  `for_wgrad`: the only reader is a deferred weight-gradient entry, so at the full batch the pass joins the
     // table launch in front of the weight gradients instead of sitting on the data-gradient chain
     std::vector<FinalizeArgs> fin_jobs;
@@ -176,6 +177,7 @@ struct BwdBuilder : PlanBuilder {
 
     void resblock(const ResRec& r) {
         scope = r.p;
+        film_blocks.push_back(r.p);
         const std::string& p = r.p;
         const int cout = r.cout, cin = r.x.C + r.skip.C, H = r.x.H, W = r.x.W;
         const Act g_out = grad_of(r.out);
@@ -425,66 +427,12 @@ int build_backward(fc_unet* u) {
     }
     b.wgrad("final_conv.weight", "final_conv.bias", fw.head, nullptr, dv, 1, 0, 1, 0);
     b.dgrad("final_conv.weight", ch, dim, 1, 0, dv, 0, fw.head);
-    // -- the tape in reverse --
-    for (int i = (int)fw.tape.size() - 1; i >= 0 && !b.err; --i) {
-        const TapeItem& t = fw.tape[i];
-        if (t.kind == 0) b.resblock(fw.res[t.idx]);
-        else if (t.kind == 1) b.linattn(fw.lin[t.idx]);
-        else if (t.kind == 2) b.midattn(fw.mid[t.idx]);
-        else if (t.kind == 3) b.resample(fw.convs[t.idx]);
-        else b.inject(fw.inj[t.idx]);
-    }
-    if (b.err) return b.err;
-    // -- mask_fusion_conv (unet.py:298-305), then init_conv (unet.py:295); d(x) and d(mask) leave through the boundary when asked for --
-    if (c.mask_cond) b.fusion(fw.fuse);
-    if (b.err) return b.err;
-    {
-        b.scope = "init_conv";
-        Act xin = b.act(ch, H, W);
-        float* xp = xin.p;
-        b.push([=](const FwdCtx& cx, hipStream_t s) { return nchw_to_nhwc_launch(cx.x, xp, cx.B, ch, HW, ch, cx.B, s); }, "nchw_to_nhwc");
-        const Act g0 = b.grad_of(fw.x0);
-        if (b.err) return b.err;
-        const float* gx0 = g0.p;
-        const float* gxi = c.mask_cond ? b.slot(fw.fuse.xi).g.p : g0.p;
-        // the gradient of init_conv's output lives in d(xi) when the fusion ran, in d(x0) otherwise: two guarded variants
-        WgradArgs a;
-        a.x0 = xin.p; a.C0 = ch; a.H = H; a.W = W; a.Hs = H; a.Ws = W; a.Cin = ch; a.Cout = dim; a.KS = 1; a.B = B;
-        a.ws = b.ws; a.ws_floats = b.ws_floats;
-        const int64_t wo = b.off("init_conv.weight"), bo = b.off("init_conv.bias");
-        b.push([=](const FwdCtx& cx, hipStream_t s) {
-            WgradArgs q = a;
-            q.B = cx.B; q.dy = cx.mask_fuse ? gxi : gx0; q.dw = cx.grads + wo; q.db = cx.grads + bo;
-            return conv_wgrad_launch(q, s);
-        }, "conv_wgrad", 2.0 * HW * (double)ch * dim);
-        // d(x) = init_conv^T d(.) as an NHWC tensor, converted to the NCHW boundary layout on request (fc_unet_backward_ex)
-        Act dxn = b.act(ch, H, W);
-        float* wp = b.dmalloc((size_t)dim * ch);
-        u->dgrad_packs.push_back({b.off("init_conv.weight"), wp, dim, ch, 1, 0, ch});
-        ConvArgs q;
-        q.s0.C = dim; q.Hs = H; q.Ws = W; q.KS = 1; q.w = wp;
-        q.B = B; q.H = H; q.W = W; q.Cout = ch; q.out = dxn.p; q.Cin = dim;
-        q.s0.p = gx0;
-        ConvGeom g;
-        if ((b.err = conv_plan(q, TILE_AUTO, &g)) != FC_OK) return b.err;
-        const int tile = g.tile;
-        const float* dxp = dxn.p;
-        b.push([=](const FwdCtx& cx, hipStream_t s) -> int {
-            if (!cx.dx_out) return FC_OK;
-            ConvArgs k = q;
-            k.B = cx.B; k.s0.p = cx.mask_fuse ? gxi : gx0;
-            FC_TRY(conv_launch(k, tile, s));
-            return nhwc_to_nchw_launch(dxp, cx.dx_out, cx.B, ch, HW, ch, s);
-        }, "dgrad(init_conv)");
-        if (c.mask_cond) {
-            const float* gm = b.gmask.p;
-            b.push([=](const FwdCtx& cx, hipStream_t s) -> int {
-                if (!cx.dmask_out) return FC_OK;
-                return nhwc_to_nchw_launch(gm, cx.dmask_out, cx.B, ch, HW, ch, s);
-            }, "nhwc_to_nchw");
-        }
-    }
-    if (b.err) return b.err;
+    // ---- the deferred launches: activations only weight gradients read, every weight gradient recorded so far (one launch per kernel size),
+    // their split reduction, the norm / FiLM parameter gradients and the FiLM projections' weight gradients.  Emitted TWICE (round 3): once
+    // behind mid_block1 -- final_*, ups.* and mid_* are complete in the flat gradient vector from then on, [grad_split, end), and a data-
+    // parallel trainer can put that bucket on the wire while the rest of the chain runs (fc_unet_backward_parts) -- and once at the end.
+    const float* te_film = fw.t_emb;
+    auto emit_deferred = [&]() -> int {
     // -- the activations only the deferred weight gradients read, recomputed in one launch --
     if (!b.fin_jobs.empty()) {
         b.scope = "wgrad";
@@ -542,7 +490,7 @@ int build_backward(fc_unet* u) {
         b.push([=](const FwdCtx& cx, hipStream_t s) { return cx.B == B ? wgrad_reduce_table_launch(jd, bd, nblk, cx.grads, s) : (int)FC_OK; }, "wgrad_reduce");
     }
     // -- parameter gradients of every norm layer and the FiLM gradients, one launch --
-    {
+    if (!b.norm_jobs.empty()) {
         b.scope = "norms";
         NormJob* jd = reinterpret_cast<NormJob*>(b.dmalloc((b.norm_jobs.size() * sizeof(NormJob) + 3) / 4 + 4));
         if (b.err) return b.err;
@@ -553,18 +501,16 @@ int build_backward(fc_unet* u) {
         float* dssp = b.dss;
         b.push([=](const FwdCtx& cx, hipStream_t s) { return norm_param_grads_table_launch(jd, nj, mc, cx.grads, dssp, S, cx.B, s); }, "norm_param_grads");
     }
-    // -- conditioning: every ResnetBlock.mlp (unet.py:79-82,90-92), then time_mlp / class_cond_mlp (unet.py:199-212,310-316) --
-    {
-        b.scope = "resblock.mlp";
-        const float* te = fw.t_emb;
-        float* dss = b.dss;
+        if (!b.film_blocks.empty()) {
+            b.scope = "resblock.mlp";
+            const float* te = te_film;
+            float* dss = b.dss;
         {   // every block's mlp.1 weight / bias gradient: one table-driven launch
             std::vector<DenseWJob> jobs;
             std::vector<int2> blocks;
-            for (auto& kv : u->ss_off) {
-                const std::string& p = kv.first;
+            for (const std::string& p : b.film_blocks) {
                 const int rows = (int)u->params[u->pidx.at(p + ".mlp.1.bias")].numel;
-                jobs.push_back({kv.second, rows, b.off(p + ".mlp.1.weight"), b.off(p + ".mlp.1.bias")});
+                jobs.push_back({u->ss_off.at(p), rows, b.off(p + ".mlp.1.weight"), b.off(p + ".mlp.1.bias")});
                 const int nb = cdiv(rows * td, 256);
                 for (int k = 0; k < nb; ++k) blocks.push_back(make_int2((int)jobs.size() - 1, k));
             }
@@ -576,6 +522,90 @@ int build_backward(fc_unet* u) {
             const int nblk = (int)blocks.size();
             b.push([=](const FwdCtx& cx, hipStream_t s) { return dense_bwd_w_table_launch(jd, bd, nblk, dss, S, te, 2, cx.grads, cx.B, td, s); }, "dense_bwd_w");
         }
+        }
+        b.fin_jobs.clear(); b.wclasses.clear(); b.wred_jobs.clear(); b.norm_jobs.clear(); b.film_blocks.clear();
+        b.pinned.clear();          // what the tables read may be recycled by later plan entries
+        return b.err;
+    };
+    // -- the tape in reverse --
+    u->bwd_split_op = -1; u->grad_split = 0;
+    // two buckets only for a trainer that asked for them (fc_unet_set_grad_buckets): a single process gains nothing from the second set of
+    // table launches (stl_sd step 2.73 ms with them, 2.65 without)
+    const bool no_buckets = !u->want_buckets || std::getenv("FLOCODER_AMD_NO_GRAD_BUCKETS") != nullptr;
+    for (int i = (int)fw.tape.size() - 1; i >= 0 && !b.err; --i) {
+        const TapeItem& t = fw.tape[i];
+        if (t.kind == 0) {
+            b.resblock(fw.res[t.idx]);
+            if (!no_buckets && fw.res[t.idx].p == "mid_block1" && u->has("ups.0.0.mlp.1.weight")) {
+                if (emit_deferred() != FC_OK) return b.err;
+                u->bwd_split_op = (int)u->bwd.ops.size();
+                u->grad_split = b.off("ups.0.0.mlp.1.weight");      // table order: ..., downs.*, ups.*, mid_*, final_*: the tail is one range
+            }
+            continue;
+        }
+        if (false) b.resblock(fw.res[t.idx]);
+        else if (t.kind == 1) b.linattn(fw.lin[t.idx]);
+        else if (t.kind == 2) b.midattn(fw.mid[t.idx]);
+        else if (t.kind == 3) b.resample(fw.convs[t.idx]);
+        else b.inject(fw.inj[t.idx]);
+    }
+    if (b.err) return b.err;
+    // -- mask_fusion_conv (unet.py:298-305), then init_conv (unet.py:295); d(x) and d(mask) leave through the boundary when asked for --
+    if (c.mask_cond) b.fusion(fw.fuse);
+    if (b.err) return b.err;
+    {
+        b.scope = "init_conv";
+        Act xin = b.act(ch, H, W);
+        float* xp = xin.p;
+        b.push([=](const FwdCtx& cx, hipStream_t s) { return nchw_to_nhwc_launch(cx.x, xp, cx.B, ch, HW, ch, cx.B, s); }, "nchw_to_nhwc");
+        const Act g0 = b.grad_of(fw.x0);
+        if (b.err) return b.err;
+        const float* gx0 = g0.p;
+        const float* gxi = c.mask_cond ? b.slot(fw.fuse.xi).g.p : g0.p;
+        // the gradient of init_conv's output lives in d(xi) when the fusion ran, in d(x0) otherwise: two guarded variants
+        WgradArgs a;
+        a.x0 = xin.p; a.C0 = ch; a.H = H; a.W = W; a.Hs = H; a.Ws = W; a.Cin = ch; a.Cout = dim; a.KS = 1; a.B = B;
+        a.ws = b.ws; a.ws_floats = b.ws_floats;
+        const int64_t wo = b.off("init_conv.weight"), bo = b.off("init_conv.bias");
+        b.push([=](const FwdCtx& cx, hipStream_t s) {
+            WgradArgs q = a;
+            q.B = cx.B; q.dy = cx.mask_fuse ? gxi : gx0; q.dw = cx.grads + wo; q.db = cx.grads + bo;
+            return conv_wgrad_launch(q, s);
+        }, "conv_wgrad", 2.0 * HW * (double)ch * dim);
+        // d(x) = init_conv^T d(.) as an NHWC tensor, converted to the NCHW boundary layout on request (fc_unet_backward_ex)
+        Act dxn = b.act(ch, H, W);
+        float* wp = b.dmalloc((size_t)dim * ch);
+        u->dgrad_packs.push_back({b.off("init_conv.weight"), wp, dim, ch, 1, 0, ch});
+        ConvArgs q;
+        q.s0.C = dim; q.Hs = H; q.Ws = W; q.KS = 1; q.w = wp;
+        q.B = B; q.H = H; q.W = W; q.Cout = ch; q.out = dxn.p; q.Cin = dim;
+        q.s0.p = gx0;
+        ConvGeom g;
+        if ((b.err = conv_plan(q, TILE_AUTO, &g)) != FC_OK) return b.err;
+        const int tile = g.tile;
+        const float* dxp = dxn.p;
+        b.push([=](const FwdCtx& cx, hipStream_t s) -> int {
+            if (!cx.dx_out) return FC_OK;
+            ConvArgs k = q;
+            k.B = cx.B; k.s0.p = cx.mask_fuse ? gxi : gx0;
+            FC_TRY(conv_launch(k, tile, s));
+            return nhwc_to_nchw_launch(dxp, cx.dx_out, cx.B, ch, HW, ch, s);
+        }, "dgrad(init_conv)");
+        if (c.mask_cond) {
+            const float* gm = b.gmask.p;
+            b.push([=](const FwdCtx& cx, hipStream_t s) -> int {
+                if (!cx.dmask_out) return FC_OK;
+                return nhwc_to_nchw_launch(gm, cx.dmask_out, cx.B, ch, HW, ch, s);
+            }, "nhwc_to_nchw");
+        }
+    }
+    if (b.err) return b.err;
+    if (emit_deferred() != FC_OK) return b.err;
+    // -- conditioning: every ResnetBlock.mlp (unet.py:79-82,90-92), then time_mlp / class_cond_mlp (unet.py:199-212,310-316) --
+    {
+        b.scope = "resblock.mlp";
+        const float* te = fw.t_emb;
+        float* dss = b.dss;
         float* dT = b.dmalloc((size_t)B * td);
         const float* wt = u->P("__ss_wt");
         b.push([=](const FwdCtx& cx, hipStream_t s) { return dense_bwd_x_launch(dss, S, wt, 1, S, te, 2, dT, 0, cx.B, td, S, s); }, "dense_bwd_x");
@@ -648,6 +678,32 @@ int fc_unet_train_reserve(fc_unet* u, int max_batch, int height, int width) {
 
 int fc_unet_backward_ex(fc_unet* u, const float* x, const float* time, const int64_t* ids, const float* mask, int mask_is_ones,
                         const float* d_out, float* grads, int64_t numel, float* dx_out, float* dmask_out, int B, int H, int W, void* stream) {
+    return fc_unet_backward_parts(u, x, time, ids, mask, mask_is_ones, d_out, grads, numel, dx_out, dmask_out, B, H, W, 0, 1, stream);
+}
+
+int fc_unet_set_grad_buckets(fc_unet* u, int on) {
+    if (!u) return fail(FC_E_ARG, "fc_unet_set_grad_buckets: null handle");
+    if (u->want_buckets == (on != 0)) return FC_OK;
+    u->want_buckets = on != 0;
+    if (u->device >= 0 && u->bwd.maxB > 0) {      // the backward plan in place has the other form: drop it, fc_unet_train_reserve rebuilds
+        FC_HIP(hipSetDevice(u->device));
+        FC_HIP(hipDeviceSynchronize());
+        u->bwd.release(); u->dgrad_packs.clear(); u->dgrad_table.release();
+        u->dgrad_version = ~0ull;
+        u->arena_touched(0);
+    }
+    return FC_OK;
+}
+
+int fc_unet_grad_buckets(const fc_unet* u, int64_t* split_offset) {
+    if (!u || !split_offset) return fail(FC_E_ARG, "fc_unet_grad_buckets: null argument");
+    *split_offset = u->bwd_split_op >= 0 ? u->grad_split : 0;
+    return u->bwd.maxB > 0 ? (u->bwd_split_op >= 0 ? 2 : 1) : 0;
+}
+
+int fc_unet_backward_parts(fc_unet* u, const float* x, const float* time, const int64_t* ids, const float* mask, int mask_is_ones,
+                           const float* d_out, float* grads, int64_t numel, float* dx_out, float* dmask_out, int B, int H, int W,
+                           int first_part, int last_part, void* stream) {
     if (!u || !x || !time || !d_out || !grads || B < 1) return fail(FC_E_ARG, "fc_unet_backward: null argument");
     if (u->bwd.maxB < B || u->bwd.H != H || u->bwd.W != W || u->plan[0].maxB < B) return fail(FC_E_STATE, "unet: no backward plan for this shape; call fc_unet_train_reserve");
     if (numel != u->raw_numel) return fail(FC_E_ARG, "fc_unet_backward: gradient vector must have " + std::to_string(u->raw_numel) + " floats (padded table layout)");
@@ -661,13 +717,17 @@ int fc_unet_backward_ex(fc_unet* u, const float* x, const float* time, const int
         FC_TRY(pack_table_launch(u->dgrad_table, s));
         u->dgrad_version = u->param_version;
     }
-    FC_HIP(hipMemsetAsync(grads, 0, (size_t)numel * sizeof(float), s));
+    if (first_part < 0 || last_part > 1 || first_part > last_part) return fail(FC_E_ARG, "fc_unet_backward_parts: parts are 0 (through mid_block1) and 1 (the rest)");
+    if (first_part == 0) FC_HIP(hipMemsetAsync(grads, 0, (size_t)numel * sizeof(float), s));
     FwdCtx c;
     c.x = x; c.x_mod = B; c.time = time; c.ids = u->cfg.n_classes > 0 ? ids : nullptr; c.ids_mod = B; c.B = B;
     c.mask = u->cfg.mask_cond ? mask : nullptr;
     c.mask_fuse = (c.mask && !mask_is_ones) ? 1 : 0;
     c.d_out = d_out; c.grads = grads; c.dx_out = dx_out; c.dmask_out = c.mask ? dmask_out : nullptr;
-    return run_plan(u->bwd, c, s);
+    const int nops = (int)u->bwd.ops.size(), split = (u->bwd_split_op >= 0 && u->bwd_split_op <= nops) ? u->bwd_split_op : nops;
+    const int lo = first_part == 0 ? 0 : split, hi = last_part == 0 ? split : nops;
+    for (int i = lo; i < hi; ++i) FC_TRY(u->bwd.ops[i](c, s));
+    return FC_OK;
 }
 
 int fc_unet_backward(fc_unet* u, const float* x, const float* time, const int64_t* ids, const float* d_out, float* grads, int64_t numel,

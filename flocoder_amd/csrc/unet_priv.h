@@ -56,6 +56,11 @@ struct fc_unet : fc::ParamStore {
     fc::PackTable dgrad_table;                // all of them as one launch
     uint64_t param_version = 0, dgrad_version = ~0ull;
     int64_t class_lo = 0, class_hi = 0;       // [lo, hi) of class_cond_mlp.* in the flat table
+    // gradient buckets (fc_unet_backward_parts): backward plan entries [0, bwd_split_op) leave [grad_split, end) of the flat gradient vector
+    // complete (final_*, mid_*, ups.*); the rest of the plan completes [0, grad_split).  bwd_split_op < 0: one bucket
+    int bwd_split_op = -1;
+    int64_t grad_split = 0;
+    bool want_buckets = false;                // fc_unet_set_grad_buckets: build the backward plan in its two-bucket form (data-parallel trainers)
 
     // What the activation arena currently holds.  fc_unet_backward_ex reads the activations the LAST forward left there, so every
     // entry point that writes the arena moves `arena_serial`; `arena_train_rows` > 0 only after a forward on the keep-everything

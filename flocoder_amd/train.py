@@ -15,6 +15,7 @@ There is no CPU path.
 """
 from __future__ import annotations
 
+import os
 import random
 from typing import Dict, Optional
 
@@ -138,6 +139,10 @@ class FlowTrainer:
         self.distributed = (dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1) if distributed is None else distributed
         # the 10 % conditioning drop (train_flow.py:343-345) is drawn from a generator every rank seeds alike, so replicas drop together
         self._drop_rng = random.Random(0x5EED) if self.distributed else random
+        # data-parallel steps start the all-reduce of the late layers' gradients in the middle of the backward (loss_and_grads / finish_gradients)
+        self.overlap_comm = os.environ.get("FLOCODER_AMD_NO_COMM_OVERLAP") is None
+        self._pending = None
+        model.set_grad_buckets(self.distributed and self.overlap_comm)
         model.train()
         model.sync_flat()
 
@@ -182,16 +187,39 @@ class FlowTrainer:
             raise IndexError("; ".join(what) + " (a training step since the last check was given others; no optimiser update has been "
                                                "applied from that step on)")
 
-    def loss_and_grads(self, x, t, cls, v_target, mask=None, time=None):
-        """forward -> loss -> backward; leaves the gradients in ``self.grads`` and returns (loss 0-d tensor, v_model)."""
+    def loss_and_grads(self, x, t, cls, v_target, mask=None, time=None, overlap: bool = False):
+        """forward -> loss -> backward; leaves the gradients in ``self.grads`` and returns (loss 0-d tensor, v_model).  With ``overlap``
+        (data-parallel steps) the backward runs in its two parts and the SUM all-reduce of the early bucket -- final_*, mid_*, ups.*:
+        parameters every step has gradients for, so it needs no agreement between the ranks first -- is started in between: RCCL moves
+        it over xGMI while the second half of the data-gradient chain runs.  The handle is left in ``self._pending``;
+        ``finish_gradients`` waits for it and reduces the rest."""
         m, lib, st = self.model, B.lib(), B.current_stream(self.device)
         if time is None:
             time = (t * self.t_scale).contiguous()
         v = m._forward_native(x, time, cls, mask, train=True)
         dv = torch.empty_like(v)
         B.check(lib.fc_mse_loss_grad(B.ptr(v), B.ptr(v_target), B.ptr(dv), self._scal.data_ptr(), self._ws.data_ptr(), v.numel(), st))
-        m.backward_native(x, time, cls, dv, self.grads, mask=mask)
+        self._pending = None
+        nb, split = m.grad_buckets() if overlap else (1, 0)
+        if overlap and nb == 2 and 0 < split < self.grads.numel() and all(hi <= split for _, hi in self._groups.values()):
+            m.backward_native(x, time, cls, dv, self.grads, mask=mask, parts=(0, 0))
+            self._pending = (torch.distributed.all_reduce(self.grads[split:], op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True), split)
+            m.backward_native(x, time, cls, dv, self.grads, mask=mask, parts=(1, 1))
+        else:
+            m.backward_native(x, time, cls, dv, self.grads, mask=mask)
         return self._scal[0], v
+
+    def finish_gradients(self) -> None:
+        """DDP's gradient averaging over the flat vector: what ``loss_and_grads(overlap=True)`` left in flight is waited for, the remaining
+        range is reduced now (the ranks have agreed on its parameter groups by then, ``_agree``), everything is divided by the world size."""
+        pend, self._pending = getattr(self, "_pending", None), None
+        if pend is None:
+            average_gradients(self.grads, self.pg)
+            return
+        work, split = pend
+        torch.distributed.all_reduce(self.grads[:split], op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        work.wait()
+        self.grads.div_(torch.distributed.get_world_size(self.pg))
 
     @property
     def step_class(self):
@@ -287,14 +315,14 @@ class FlowTrainer:
         if int(self._id_flag_host[0]):
             self.check_class_ids()                                   # an earlier step's inputs were out of range: raise now
         t, time, x, v_target = self.prepare(source, target, u, cls, pairing)
-        loss, _ = self.loss_and_grads(x, t, cls, v_target, mask, time=time)
+        loss, _ = self.loss_and_grads(x, t, cls, v_target, mask, time=time, overlap=self.distributed and self.overlap_comm)
         loss = loss.clone()
         if (cls is not None or pairing is not None) and (self.step_main & 63) == 0:
             self.check_class_ids()                                   # every 64th step (and from the state-dict methods): one host sync
         fused = mask is not None and not bool(torch.allclose(mask, torch.ones_like(mask)))    # unet.py:301 (host sync, as upstream)
         present = self._agree({"class": cls is not None, "inject": mask is not None, "fusion": fused})
         if self.distributed:                                     # DDP semantics: average the gradients over ranks
-            average_gradients(self.grads, self.pg)
+            self.finish_gradients()
         self.optimizer_step(has_class_grads=present["class"], has_mask_grads=present["inject"], has_fusion_grads=present["fusion"])
         return loss
 

@@ -177,6 +177,7 @@ class Unet(nn.Module):
             fr = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1))).contiguous()
             B.check(lib.fc_unet_set_time_freqs(h, fr.numpy().ctypes.data_as(C.POINTER(C.c_float)), half))
         B.check(lib.fc_unet_set_shared(self._handle, int(self._device_is_shared(device))))
+        B.check(lib.fc_unet_set_grad_buckets(self._handle, int(getattr(self, "_grad_buckets", False))))
         ver = self._version()
         if ver != self._synced_version:
             flat = self._flat_params(device)
@@ -324,19 +325,37 @@ class Unet(nn.Module):
                                         B.current_stream(dev)))
         return out
 
-    def backward_native(self, x, time, cls, d_out, grads: Optional[torch.Tensor] = None, mask=None, want_dx=False, want_dmask=False):
+    def set_grad_buckets(self, on: bool) -> None:
+        """Build the backward plan in its two-bucket form (``fc_unet_set_grad_buckets``): data-parallel trainers, so that the all-reduce of
+        the late layers' gradients can start in the middle of the backward."""
+        self._grad_buckets = bool(on)
+
+    def grad_buckets(self) -> Tuple[int, int]:
+        """(number of gradient buckets of the current backward plan, flat offset where the early bucket starts): after part 0 of
+        ``backward_native`` the range [offset, numel) -- final_*, mid_*, ups.* -- is final, part 1 completes [0, offset)."""
+        off = C.c_int64(0)
+        n = B.lib().fc_unet_grad_buckets(self._handle, C.byref(off)) if self._handle else 0
+        return int(n), int(off.value)
+
+    def backward_native(self, x, time, cls, d_out, grads: Optional[torch.Tensor] = None, mask=None, want_dx=False, want_dmask=False,
+                        parts: Tuple[int, int] = (0, 1), dx=None, dm=None):
         """Parameter gradients of the LAST training forward (same x / time / class ids / mask) for d(out) = ``d_out``: a flat fp32
         vector in the library's table layout (``grad_views`` splits it), plus d(x) / d(mask) on request.  Returns
-        ``(flat, dx | None, dmask | None)``.  train_flow.py:371 loss.backward()."""
+        ``(flat, dx | None, dmask | None)``.  train_flow.py:371 loss.backward().  ``parts`` = (first, last) of the two halves of the
+        backward plan (``fc_unet_backward_parts``): (0, 0) stops behind mid_block1 with the late-layer gradients final, (1, 1) runs the
+        rest -- a data-parallel trainer all-reduces the first bucket in between."""
         dev = x.device
         bsz, _, h, w = x.shape
         if grads is None:
             grads = torch.empty(self._flat_numel, dtype=torch.float32, device=dev)
         ones = int(torch.allclose(mask, torch.ones_like(mask))) if mask is not None else 0
-        dx = torch.empty_like(x) if want_dx else None
-        dm = torch.empty_like(x) if (want_dmask and mask is not None) else None
-        B.check(B.lib().fc_unet_backward_ex(self._native(dev), B.ptr(x), B.ptr(time), B.ptr(cls), B.ptr(mask), ones, B.ptr(d_out.contiguous()),
-                                            B.ptr(grads), grads.numel(), B.ptr(dx), B.ptr(dm), bsz, h, w, B.current_stream(dev)))
+        if dx is None:
+            dx = torch.empty_like(x) if want_dx else None
+        if dm is None:
+            dm = torch.empty_like(x) if (want_dmask and mask is not None) else None
+        B.check(B.lib().fc_unet_backward_parts(self._native(dev), B.ptr(x), B.ptr(time), B.ptr(cls), B.ptr(mask), ones, B.ptr(d_out.contiguous()),
+                                               B.ptr(grads), grads.numel(), B.ptr(dx), B.ptr(dm), bsz, h, w, int(parts[0]), int(parts[1]),
+                                               B.current_stream(dev)))
         return grads, dx, dm
 
     def grad_views(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:

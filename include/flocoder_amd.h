@@ -181,6 +181,18 @@ int fc_unet_backward(fc_unet* u, const float* x_dev, const float* time_dev, cons
 int fc_unet_backward_ex(fc_unet* u, const float* x_dev, const float* time_dev, const int64_t* class_ids_dev, const float* mask_dev,
                         int mask_is_ones, const float* d_out_dev, float* grads_flat_dev, int64_t numel, float* dx_out_dev,
                         float* dmask_out_dev, int batch, int height, int width, void* stream);
+/* The same in two parts, for data-parallel training that overlaps the gradient all-reduce with the backward (train_flow.py:371 under
+ * DDP): part 0 runs the data-gradient chain from the output through mid_block1 and every weight / norm / FiLM gradient of final_*,
+ * ups.* and mid_*, after which [split_offset, numel) of grads_flat_dev is final (fc_unet_grad_buckets); part 1 runs the rest and completes
+ * [0, split_offset).  first_part = 0, last_part = 1 is fc_unet_backward_ex.  Part 1 must follow part 0 of the same forward. */
+int fc_unet_backward_parts(fc_unet* u, const float* x_dev, const float* time_dev, const int64_t* class_ids_dev, const float* mask_dev,
+                           int mask_is_ones, const float* d_out_dev, float* grads_flat_dev, int64_t numel, float* dx_out_dev,
+                           float* dmask_out_dev, int batch, int height, int width, int first_part, int last_part, void* stream);
+/* Ask for (1) / do without (0, default) the two-bucket form of the backward plan; takes effect at the next fc_unet_train_reserve.  One
+ * process gains nothing from it (the deferred table launches run twice); a data-parallel trainer sets it once. */
+int fc_unet_set_grad_buckets(fc_unet* u, int on);
+/* Number of gradient buckets of the current backward plan (0 none, 1, 2) and the flat offset where the early bucket starts. */
+int fc_unet_grad_buckets(const fc_unet* u, int64_t* split_offset);
 /* The backward reads the activations the last training forward left in the handle's single arena.  Every call that writes the arena
  * (fc_unet_forward, fc_unet_integrate, fc_unet_profile_ops, a re-plan by fc_unet_reserve) moves this counter; a caller that keeps
  * several forwards in flight (autograd with two micro-batches, gradient accumulation) compares the value it saw after ITS forward

@@ -509,3 +509,32 @@ def test_weight_gradients_do_not_depend_on_which_entries_join_the_table_launch(t
     for tag, v in outs.items():
         assert torch.isfinite(v).all()
         assert rel_l2(v, outs["default"]) < 2e-6, tag
+
+
+def test_backward_in_two_parts_equals_the_whole_and_finishes_the_late_layers_first():
+    """fc_unet_backward_parts (round 3): part 0 runs the backward through mid_block1 and leaves [split, numel) of the flat gradient vector --
+    ups.*, mid_*, final_* -- final, so a data-parallel trainer can all-reduce that bucket while part 1 runs; the two parts together are the
+    one-call backward bit for bit (same launches, same order)."""
+    from flocoder_amd.unet import Unet
+    torch.manual_seed(11)
+    m = Unet(dim=16, dim_mults=(1, 2, 4, 8), channels=4, n_classes=10).to(dev()).train()
+    m.set_grad_buckets(True)                   # what a data-parallel FlowTrainer asks for; a single process keeps the one-bucket plan
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(6, 4, 16, 16, generator=g).to(dev()); t = (torch.rand(6, generator=g) * 999).to(dev())
+    ids = torch.randint(10, (6,), generator=g).to(dev()); dv = torch.randn(6, 4, 16, 16, generator=g).to(dev())
+    m._forward_native(x, t, ids, None, train=True)
+    whole, _, _ = m.backward_native(x, t, ids, dv)
+    whole = whole.clone()
+    nb, split = m.grad_buckets()
+    assert nb == 2 and 0 < split < whole.numel()
+    names = {n: off for n, _, off in m._table}
+    assert split == names["ups.0.0.mlp.1.weight"] and all(off >= split for n, off in names.items() if n.startswith(("ups.", "mid_", "final_")))
+    assert all(off < split for n, off in names.items() if n.startswith(("downs.", "init_conv", "time_mlp", "class_cond_mlp")))
+    m._forward_native(x, t, ids, None, train=True)
+    flat = torch.full_like(whole, float("nan"))
+    m.backward_native(x, t, ids, dv, flat, parts=(0, 0))
+    torch.cuda.synchronize()
+    assert torch.equal(flat[split:], whole[split:]), "the late layers' gradients are final after part 0"
+    assert not torch.equal(flat[:split], whole[:split])
+    m.backward_native(x, t, ids, dv, flat, parts=(1, 1))
+    assert torch.equal(flat, whole)
