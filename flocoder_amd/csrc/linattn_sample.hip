@@ -33,21 +33,33 @@ __device__ __forceinline__ void wfetch(const float* __restrict__ wp, int ldw, in
 
 // acc[mt] += A[mt*32 .. +32][0..K) . W[0..K)[32 columns]; A in LDS (row stride lda), W in global; K % (2*PF) == 0; `cur` already
 // holds rows [0, 2*PF).  The next PF loads are in flight while the current PF feed the matrix pipe.
+// Round 3: two register sets that swap roles (the loop is unrolled by two) and an UNCONDITIONAL request (the last round re-requests
+// itself).  The round-2 form -- `if (more) wfetch(nxt)` ... `cur = nxt` -- was the pattern found in the convolution kernel's register-fed
+// tile (conv_pipe.hip DB4): the compiler hoists the copy to the last use of each `cur` register, a copy of a load's destination waits for
+// the load, and with a conditional request s_waitcnt (an immediate) must count for the path that skipped it -- every round then waited
+// for the round trip it had just started, 4-8 dependent cold round trips per launch of a kernel that lives ~15 us.
 template <int MT>
 __device__ __forceinline__ void gemm_stream(const float* __restrict__ A, int lda, const float* __restrict__ wp, int ldw, int K, int l31, int half,
                                             float (&cur)[PF], f32x16 (&acc)[MT]) {
     float nxt[PF];
-    for (int k0 = 0; k0 < K; k0 += 2 * PF) {
-        const bool more = k0 + 2 * PF < K;
-        if (more) wfetch(wp, ldw, k0 + 2 * PF, nxt);
+    auto round = [&](int k0, float (&wc)[PF], float (&wn)[PF]) {
+        wfetch(wp, ldw, k0 + 2 * PF < K ? k0 + 2 * PF : k0, wn);
+        __builtin_amdgcn_sched_barrier(0);      // the requests stay in front of this round's MFMAs
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = FC_MFMA(A[(mt * 32 + l31) * lda + k0 + 2 * u + half], cur[u], acc[mt]);
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = FC_MFMA(A[(mt * 32 + l31) * lda + k0 + 2 * u + half], wc[u], acc[mt]);
         }
-        if (more) {
-#pragma unroll
-            for (int u = 0; u < PF; ++u) cur[u] = nxt[u];
+    };
+    if ((K & (4 * PF - 1)) == 0) {        // an even number of rounds (every U-Net width from 64 channels up): no branch between the two halves,
+        for (int k0 = 0; k0 < K; k0 += 4 * PF) {      // so no path join for the wait counts to be pessimistic about
+            round(k0, cur, nxt);
+            round(k0 + 2 * PF, nxt, cur);
+        }
+    } else {
+        for (int k0 = 0; k0 < K; k0 += 4 * PF) {
+            round(k0, cur, nxt);
+            if (k0 + 2 * PF < K) round(k0 + 2 * PF, nxt, cur);
         }
     }
 }
