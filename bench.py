@@ -261,46 +261,25 @@ def rk4_share(model, rank, world, device):
 
 
 def two_in_flight(model, noise, ids, device, steps=6):
-    """Throughput mode for callers that generate many batches (e.g. 50 k samples for FID): two independent 64-sample trajectories
-    in flight on two streams, each on its own model replica (own activation arena and captured graphs).  One batch of 64 keeps
-    only ~2 workgroups per CU in lockstep phases; a second batch fills the matrix pipe while the first loads or stores.  NOT the
-    headline (that is one batch at a time): reported beside it."""
-    from flocoder_amd.sampling import euler_sampler
-    twin = build_model(device)
-    twin.load_state_dict(model.state_dict())
-    # two replicas meant to overlap share the device: both take the plan without cross-workgroup waits (fc_unet_set_shared; the caller's
-    # non-default streams would select it anyway).  Left on the exclusive plan the library would order the two trajectories one behind
-    # the other (the meeting guard), which is safe but not what this mode measures.
-    model.set_shared_device(True); twin.set_shared_device(True)
+    """Throughput mode for callers that generate many batches (e.g. 50 k samples for FID): ``flocoder_amd.sampling.sample_many`` -- two
+    independent 64-sample trajectories in flight on two streams, each on its own model replica (own activation arena and captured graphs),
+    on the plan without cross-workgroup waits.  One batch of 64 is a chain of dependent launches that leaves the chip waiting on
+    launch-to-launch latency; a second chain fills the gaps.  NOT the headline (that is one batch at a time): reported beside it."""
+    from flocoder_amd.sampling import sample_many
     shape = (BATCH,) + LATENT
-    streams = [torch.cuda.Stream(device), torch.cuda.Stream(device)]
-    models = [model, twin]
-    cur = torch.cuda.current_stream(device)
-
-    def run(k):
-        outs = []
-        for st in streams:
-            st.wait_stream(cur)
-        for i in range(k):
-            with torch.cuda.stream(streams[i & 1]):
-                outs.append(euler_sampler(models[i & 1], shape, N_EULER, cond=ids, source=noise)[0])
-        for st in streams:
-            cur.wait_stream(st)
-        return outs
-
-    run(2)
+    batches = [({"class_cond": ids}, noise)] * steps
+    sample_many(model, shape, batches[:2], method="euler", n_steps=N_EULER, in_flight=2)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    outs = run(steps)
+    outs = sample_many(model, shape, batches, method="euler", n_steps=N_EULER, in_flight=2)
     torch.cuda.synchronize(device)
     t = time.perf_counter() - t0
-    assert all(torch.isfinite(o).all() for o in outs) and torch.equal(outs[0], outs[1])     # both replicas integrate the same samples
-    assert model.meeting_launches == 0 and twin.meeting_launches == 0
-    model.check_errors(); twin.check_errors()
-    assert model.fused_tail_errors() == 0 and twin.fused_tail_errors() == 0
-    model.set_shared_device(None)            # back to the per-call decision (exclusive on the default stream)
-    del twin
-    return {"workload": f"64-step Euler, B={BATCH} per call, TWO calls in flight (two streams, two model replicas), {steps} calls timed",
+    assert all(torch.isfinite(o).all() for o in outs) and all(torch.equal(o, outs[0]) for o in outs)     # every call integrates the same samples
+    model.check_errors()
+    for m in getattr(model, "_replicas", []):
+        m.check_errors()
+    model._replicas = []
+    return {"workload": f"64-step Euler, B={BATCH} per call, TWO calls in flight (sample_many: two streams, two model replicas), {steps} calls timed",
             "samples_per_s": round(BATCH * steps / t, 1), "ms_per_call_amortised": round(1e3 * t / steps, 2),
             "tflops": round(BATCH * steps * N_EULER * model.flops_per_sample / t / 1e12, 2)}
 

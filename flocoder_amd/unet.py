@@ -217,6 +217,16 @@ class Unet(nn.Module):
         n = B.lib().fc_unet_chains(self._handle, C.byref(rows)) if self._handle else 0
         return n, rows.value
 
+    def replica(self) -> "Unet":
+        """A second model object with the same architecture and (copied) weights on the same device: its own native handle, activation
+        arena and captured graphs, so that it can run beside this one on another stream (``sampling.sample_many``)."""
+        c = self._cfg
+        twin = Unet(self.dim, self.dim_mults, channels=self.channels, resnet_block_groups=int(c.groups), n_classes=int(c.n_classes),
+                    mask_cond=bool(c.mask_cond), use_checkpoint=self.use_checkpoint)
+        twin.load_state_dict(self.state_dict())
+        twin.train(self.training)
+        return twin.to(next(self.parameters()).device)
+
     # ------------------------------------------------------------------ device sharing (fc_unet_set_shared)
     def set_shared_device(self, shared: Optional[bool]) -> None:
         """Tell the library whether this model's GPU work runs beside other work it is not ordered against (a second replica meant to

@@ -154,3 +154,21 @@ def test_the_sampler_raises_inside_the_call_that_waited(reference):
     Bn.check(Bn.lib().fc_debug_unet_break_meeting(m._handle))
     with pytest.raises(RuntimeError, match="timed out"):
         euler_sampler(m, (B, 4, 32, 32), 1, cond=ids.to(DEV), source=x.to(DEV))
+
+
+def test_sample_many_equals_one_at_a_time(reference):
+    """sampling.sample_many: batches in flight on replicas / streams give what the one-at-a-time calls give (trajectories are independent)."""
+    from flocoder_amd.sampling import euler_sampler, sample_many
+    sd, x, ids, want = reference
+    m = _model()
+    g = torch.Generator().manual_seed(5)
+    srcs = [torch.randn(B, 4, 32, 32, generator=g).to(DEV) for _ in range(5)]
+    cls = [torch.randint(102, (B,), generator=g).to(DEV) for _ in range(5)]
+    outs = sample_many(m, (B, 4, 32, 32), [({"class_cond": c}, s) for c, s in zip(cls, srcs)], method="euler", n_steps=STEPS, in_flight=2)
+    torch.cuda.synchronize()
+    assert len(outs) == 5 and len(m._replicas) == 1
+    for c, s, o in zip(cls, srcs, outs):
+        one = euler_sampler(m, (B, 4, 32, 32), STEPS, cond=c, source=s)[0]       # back on the default stream: the exclusive plan
+        assert torch.isfinite(o).all() and rel_l2(o, one) < 1e-6
+    assert m.meeting_launches > 0
+    assert rel_l2(sample_many(m, (B, 4, 32, 32), [({"class_cond": ids.to(DEV)}, x.to(DEV))], n_steps=STEPS, in_flight=1)[0].cpu(), want) < 1e-4
