@@ -365,6 +365,18 @@ def secondary(model, noise, ids, device):
     out["sdvae_encode"] = {"workload": f"SD-VAE encode 3x256x256 -> 4x32x32, B={BATCH} in chunks of {DECODE_CHUNK}", "ms": round(t_enc * 1e3, 1),
                            "images_per_s": round(BATCH / t_enc, 1), "gflop_per_image": round(gf_enc, 1),
                            "tflops": round(BATCH * gf_enc / t_enc / 1e3, 1)}
+    # opt-in split-bf16 arithmetic of the codec (fc_vae_set_precision): reported BESIDE the fp32 numbers with its measured error, never instead
+    vae.set_precision("bf16x3")
+    t_dec3, img3 = _gpu_time(lambda: decode_latents(vae, z, chunk_size=DECODE_CHUNK), device, 2)
+    t_enc3, _ = _gpu_time(lambda: torch.cat([vae.encode(img[i:i + DECODE_CHUNK]) for i in range(0, BATCH, DECODE_CHUNK)]), device, 2)
+    err3 = float((img3.double() - img.double()).norm() / img.double().norm())
+    vae.set_precision("fp32")
+    out["sdvae_decode_split_bf16"] = {
+        "workload": out["sdvae_decode"]["workload"] + "; OPT-IN arithmetic: operands as bf16 hi + lo, hi*hi + hi*lo + lo*hi on the bf16 matrix pipe, fp32 accumulation",
+        "ms": round(t_dec3 * 1e3, 1), "images_per_s": round(BATCH / t_dec3, 1), "speedup_vs_fp32": round(t_dec / t_dec3, 2),
+        "rel_l2_vs_fp32_decode": float(f"{err3:.3e}"), "gate": 1e-3, "encode_images_per_s": round(BATCH / t_enc3, 1),
+        "euler64_plus_decode_images_per_s": round(BATCH / (t_ode + t_dec3), 1)}
+    assert err3 < 1e-3
     out["euler64_plus_decode"] = {"workload": "64-step Euler + SD-VAE decode (decoded images/s, SURVEY 8d secondary metric)",
                                   "images_per_s": round(BATCH / (t_ode + t_dec), 1), "ode_ms": round(t_ode * 1e3, 1), "decode_ms": round(t_dec * 1e3, 1)}
     del vae

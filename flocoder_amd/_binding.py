@@ -98,6 +98,9 @@ SIGNATURES = {
     "fc_vqvae_decode": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "fc_vqvae_flops_per_sample": (C.c_double, [_vp, _i]),
     "fc_vae_op_info": (_i, [_vp, _i, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_double)]),
+    "fc_vae_set_precision": (_i, [_vp, _i]),
+    "fc_vqvae_set_precision": (_i, [_vp, _i]),
+    "fc_debug_set_conv_precision": (_i, [_i]),
     "fc_vae_op_bytes": (_i, [_vp, _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "fc_unet_op_bytes": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "fc_vqvae_plan_launches": (_i, [_vp, _i]),

@@ -14,7 +14,7 @@ def _nhwc(t: Optional[torch.Tensor]):
 
 
 def conv_debug(x0: torch.Tensor, w: torch.Tensor, bias=None, x1=None, add=None, *, pad=0, stride=1, upsample=False,
-               out_act=False, groups_out=0, tile="auto", repeats=0):
+               out_act=False, groups_out=0, tile="auto", repeats=0, precision="fp32"):
     """One implicit-GEMM launch.  NCHW in / NCHW out (converted with torch, test plumbing only).
     Returns (out, stats) with stats = (mean, var) per (b, group) reconstructed from the kernel's partials, or None;
     with repeats > 0 returns the average milliseconds of that many back-to-back launches instead."""
@@ -32,9 +32,13 @@ def conv_debug(x0: torch.Tensor, w: torch.Tensor, bias=None, x1=None, add=None, 
     tile_id = B.TILE_AUTO if tile == "auto" else B.TILES[tile]
     wc = w.float().contiguous()
     bc = None if bias is None else bias.float().contiguous()
-    B.check(B.lib().fc_debug_conv(B.ptr(x0n), c0, B.ptr(x1n), c1, B.ptr(wc), B.ptr(bc), B.ptr(addn), B.ptr(out), B.ptr(stats),
-                                  groups_out, C.byref(T), C.byref(nt), bsz, hs, ws, cout, ks, pad, stride, int(upsample),
-                                  int(out_act), tile_id, int(repeats), C.byref(ms), B.current_stream(dev)))
+    B.check(B.lib().fc_debug_set_conv_precision(1 if precision == "bf16x3" else 0))
+    try:
+        B.check(B.lib().fc_debug_conv(B.ptr(x0n), c0, B.ptr(x1n), c1, B.ptr(wc), B.ptr(bc), B.ptr(addn), B.ptr(out), B.ptr(stats),
+                                      groups_out, C.byref(T), C.byref(nt), bsz, hs, ws, cout, ks, pad, stride, int(upsample),
+                                      int(out_act), tile_id, int(repeats), C.byref(ms), B.current_stream(dev)))
+    finally:
+        B.check(B.lib().fc_debug_set_conv_precision(0))
     if repeats:
         return ms.value
     res = out.permute(0, 3, 1, 2).contiguous()

@@ -81,6 +81,9 @@ class _Node(nn.Module):
     pass
 
 
+_PRECISIONS = {"fp32": 0, "bf16x3": 1}
+
+
 class SD_VAE_Wrapper(nn.Module):
     """codecs.py:631-663 over the native AutoencoderKL.  Parameters live under ``self.vae.*`` with the upstream key names, so a
     ``state_dict`` saved from the reference's wrapper loads here unchanged.
@@ -156,6 +159,7 @@ class SD_VAE_Wrapper(nn.Module):
             h = C.c_void_p()
             B.check(lib.fc_vae_create(device.index or 0, C.byref(h)))
             self._handle, self._handle_device, self._synced = h, device, None
+        B.check(lib.fc_vae_set_precision(self._handle, _PRECISIONS[getattr(self, "_precision", "fp32")]))
         ver = tuple((p.data_ptr(), p._version) for p in self.vae.parameters())
         if ver != self._synced:
             flat = torch.zeros(self._flat_numel, dtype=torch.float32, device=device)
@@ -177,6 +181,14 @@ class SD_VAE_Wrapper(nn.Module):
             self._release()
         except Exception:
             pass
+
+    def set_precision(self, mode: str = "fp32") -> None:
+        """Arithmetic of the codec's convolutions: "fp32" (default, exact fp32 on the matrix pipe -- what parity tests and the headline use)
+        or "bf16x3" (every operand as bf16 hi + lo, three bf16 MFMAs per product, fp32 accumulation: ~1e-5 relative per layer; an opt-in for
+        callers that decode many images, ``fc_vae_set_precision``)."""
+        if mode not in _PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
+        self._precision = mode
 
     @staticmethod
     def _need_gpu(t):
@@ -402,6 +414,12 @@ class VQVAE(nn.Module):
         """Re-upload the weights on the next use (for writes that bypass the (data_ptr, _version) key, e.g. ``p.data.copy_``)."""
         self._synced = None
 
+    def set_precision(self, mode: str = "fp32") -> None:
+        """"fp32" (default) or "bf16x3" -- see ``SD_VAE_Wrapper.set_precision`` (``fc_vqvae_set_precision``)."""
+        if mode not in _PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
+        self._precision = mode
+
     def _native(self, device):
         lib = B.lib()
         if self._handle is None or self._handle_device != device:
@@ -409,6 +427,7 @@ class VQVAE(nn.Module):
             h = C.c_void_p()
             B.check(lib.fc_vqvae_create_ex(*self._cfg, device.index or 0, C.byref(h)))
             self._handle, self._handle_device, self._synced = h, device, None
+        B.check(lib.fc_vqvae_set_precision(self._handle, _PRECISIONS[getattr(self, "_precision", "fp32")]))
         sd = dict(self.named_parameters())
         ver = tuple((sd[n].data_ptr(), sd[n]._version) for n, _, _ in self._table)
         if ver != self._synced:

@@ -100,6 +100,7 @@ struct ConvArgs {
     // operands straight from it, 16 bytes per lane (conv_pipe.hip)
     const float* w4 = nullptr;
     const float* res_w4 = nullptr;
+    int prec = 0;              // 1: split-bf16 arithmetic where the tile has that form (codec decoders on request; 0 = exact fp32, always for the U-Net)
     ConvFin fin;
 };
 

@@ -29,6 +29,7 @@ struct ConvDev {
     int nchunks, nwb;            // Cin chunks; weight stages resident in LDS (2 or 3)
     unsigned magic_phw, magic_pw;  // ceil(2^32 / PH*PW), ceil(2^32 / PW): x / d == umulhi(x, magic) for the small x used here
     unsigned long long* stamps;  // diagnostic builds only: [block][8 waves][16] s_memtime samples, or null
+    int bf3;                     // the launch runs on the split-bf16 instantiation (ConvArgs::prec == 1 and the tile / kernel size have one)
 };
 
 // Phase stamp (diagnostics; null pointer = one scalar branch).  Lane 0 of every wave records the shader clock.

@@ -289,7 +289,7 @@ static int conv_geometry(const ConvArgs& a, int tile, bool pipe, ConvDev* d, Con
     p.nblocks = cdiv(a.B, TB) * p.tiles_x * p.tiles_y * p.ntiles;
     p.txl = ilog2(p.tiles_x); p.tyl = ilog2(p.tiles_y);
     p.magic_nt = (p.ntiles > 1 && p.nblocks < 65536) ? (unsigned)((1ull << 32) / (unsigned)p.ntiles) + 1u : 0u;   // exact for x < 2^16
-    p.loader_prio = 0; p.o_epoch = p.o_gran = 0; p.o_out = -1;
+    p.loader_prio = 0; p.o_epoch = p.o_gran = 0; p.o_out = -1; p.bf3 = 0;
     p.act0 = a.s0.xf.mode == 2; p.act1 = a.s1.xf.mode == 2;
     p.any_xf = (a.s0.xf.mode != 0) || (a.s1.xf.mode != 0);
     p.rps = TB > 1 ? a.H * a.W : t.BM;
@@ -318,7 +318,10 @@ static int conv_geometry(const ConvArgs& a, int tile, bool pipe, ConvDev* d, Con
         p.o_patch = o;
         // M32N32K4 at 3x3 loads its weights global -> registers (conv_pipe.hip "DB"): no slab stages in LDS
         const bool direct_b = (t.WMWN == 1 && t.MTNT == 1 && a.KS == 3);
-        p.patch_stride = align4(p.P * (t.CC + (direct_b ? 4 : 1)));    // (its k-step-quad form strides pixels by CC + 4 floats)
+        // split-bf16 form (ConvArgs::prec): the three codec tiles at 1x1 / 3x3, plain launches only (no fused res_conv / tail, shared weights)
+        p.bf3 = (a.prec == 1 && (tile == TILE_M128N32 || tile == TILE_M128N64 || tile == TILE_M256N64) && (a.KS == 1 || a.KS == 3) && !a.res_out &&
+                 !a.fin.gamma && !a.w_batch_stride) ? 1 : 0;
+        p.patch_stride = align4(p.P * (t.CC + ((direct_b || p.bf3) ? 4 : 1)));    // (its k-step-quad form strides pixels by CC + 4 floats, and so does split-bf16)
         p.o_wl = o + 2 * p.patch_stride;
         p.wl_stride = direct_b ? 0 : a.KS * a.KS * t.CC * t.BN + (a.res_out ? t.CC * t.BN : 0);
         p.o_wres = 0;

@@ -82,7 +82,42 @@ __device__ __forceinline__ void loader_handover() {   // LDS stores of this wave
 // NL = loader waves (4 or 8).  The small-M tiles stream a whole weight slab per 32 or 64 output rows: with four loader waves the
 // slab's LDS-DMA issue (~190 cycles per 1 KB piece per wave) took 1.65x the consumers' MFMA time per chunk and the consumers sat
 // at the chunk barrier half of the time (profiles/r01_c_stamps.txt); eight loader waves halve the issue time per wave.
-template <int WM, int WN, int WK, int MT, int NT, int CC, int NPL, int KS, int NL, int FL = FL_ALL>
+// PREC = 1: split-bf16 arithmetic (round 3, codec decoders on request -- never the U-Net, never a default): every fp32 operand x is taken as
+// hi + lo with hi = bf16(x), lo = bf16(x - hi), and a product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulation; the
+// dropped lo*lo term is 2^-16 relative).  Three MFMAs of 32 cycles cover sixteen channels where the exact-fp32 pipe needs eight of 64: 5.3x
+// the matrix rate.  Staging, LDS layouts and the epilogue are the fp32 kernel's; the accumulator waves split their operands on the way from
+// LDS to the matrix pipe.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_bf16x8(const float (&x)[8], bf16x8_t& hi, bf16x8_t& lo) {
+    union { bf16x8_t v; bf16x2_t p[4]; unsigned u[4]; } H, L;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x2_t pr; pr[0] = x[2 * j]; pr[1] = x[2 * j + 1];
+        H.p[j] = __builtin_convertvector(pr, bf16x2_t);                       // v_cvt_pk_bf16_f32 (round to nearest even)
+        const float h0 = __uint_as_float(H.u[j] << 16), h1 = __uint_as_float(H.u[j] & 0xffff0000u);
+        f32x2_t rr; rr[0] = x[2 * j] - h0; rr[1] = x[2 * j + 1] - h1;
+        L.p[j] = __builtin_convertvector(rr, bf16x2_t);
+    }
+    hi = H.v; lo = L.v;
+}
+
+// four fp32 values -> their bf16 hi parts and lo parts, packed two per dword (channel order kept)
+__device__ __forceinline__ void split_bf16x4(const f32x4& x, uint2& hi, uint2& lo) {
+    union { bf16x2_t p; unsigned u; } H0, H1, L0, L1;
+    f32x2_t a; a[0] = x.x; a[1] = x.y;
+    f32x2_t b; b[0] = x.z; b[1] = x.w;
+    H0.p = __builtin_convertvector(a, bf16x2_t);
+    H1.p = __builtin_convertvector(b, bf16x2_t);
+    f32x2_t ra; ra[0] = x.x - __uint_as_float(H0.u << 16); ra[1] = x.y - __uint_as_float(H0.u & 0xffff0000u);
+    f32x2_t rb; rb[0] = x.z - __uint_as_float(H1.u << 16); rb[1] = x.w - __uint_as_float(H1.u & 0xffff0000u);
+    L0.p = __builtin_convertvector(ra, bf16x2_t);
+    L1.p = __builtin_convertvector(rb, bf16x2_t);
+    hi = make_uint2(H0.u, H1.u); lo = make_uint2(L0.u, L1.u);
+}
+
+template <int WM, int WN, int WK, int MT, int NT, int CC, int NPL, int KS, int NL, int FL = FL_ALL, int PREC = 0>
 __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev p_kernarg) {
     ConvDev p;
     conv_params_from_lanes(p);       // p_kernarg itself is never touched: see conv_dev.h
@@ -110,7 +145,12 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
     // banks.  DB4 reads a lane's four k-steps of a tap as ONE 16-byte LDS read instead: inside every 8-channel block the window is stored
     // as [parity][4] (channel c at 8 (c / 8) + 4 (c & 1) + ((c >> 1) & 3)), so the channels 8 wk + 2 kk + half, kk = 0..3, are contiguous, and
     // the stride is a multiple of four floats (CC + 4) for the alignment the wide read needs.
-    constexpr int CS = DB4 ? CC + 4 : CC + 1;
+    constexpr bool BF3 = PREC == 1;
+    static_assert(!BF3 || (!DB && CC == 16 && FL == FL_ALL), "split-bf16: LDS-fed tiles, one 16-channel k-step per chunk, the all-in-one flavour");
+    // BF3: the staging waves split the window on its way into LDS (a pixel is read by up to nine taps: splitting it at every read was half of
+    // the accumulator waves' vector work): a pixel's 16 channels are stored as 16 bf16 hi parts | 16 bf16 lo parts (64 bytes) at the fp32
+    // form's pitch of CC + 4 floats, so a lane's eight channels of either part are one 16-byte read.
+    constexpr int CS = (DB4 || BF3) ? CC + 4 : CC + 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const ConvArgs& a = p.a;
     float* gstat = smem + p.o_gstat;
@@ -341,7 +381,14 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
                     if (act) { x.x = silu_f(x.x); x.y = silu_f(x.y); x.z = silu_f(x.z); x.w = silu_f(x.w); }
                 }
                 float* d = pb + e_lds[k];
-                if (DB4) { d[0] = x.x; d[1] = x.z; d[4] = x.y; d[5] = x.w; }      // [parity][4] inside the 8-channel block
+                if (BF3) {                                                        // hi parts at byte 2 c, lo parts at byte 2 CC + 2 c of the pixel
+                    uint2 h2, l2;
+                    split_bf16x4(x, h2, l2);
+                    char* pc = reinterpret_cast<char*>(pb + (e_lds[k] - q4)) + 2 * q4;
+                    *reinterpret_cast<uint2*>(pc) = h2;
+                    *reinterpret_cast<uint2*>(pc + 2 * CC) = l2;
+                }
+                else if (DB4) { d[0] = x.x; d[1] = x.z; d[4] = x.y; d[5] = x.w; }      // [parity][4] inside the 8-channel block
                 else { d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w; }
             }
         };
@@ -510,6 +557,48 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
             if (DB4_CHAINS == 2) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][0][r] += acc2[r];
+            }
+        } else if constexpr (BF3) {
+            // lane (row / column l31, half): channels 8 half .. 8 half + 7 of each 16-channel k-step, of its pixel (A) and of its column (B)
+            int ab3[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) ab3[mt] = abase[mt] - half + 4 * half;    // (16 bytes per half: eight bf16)
+            const int bb3 = wn * NT * 32 + l31 + 8 * half * BN;
+            for (int i = 0; i < nchunks; ++i) {
+                const float* patch = patch0 + (i & 1) * p.patch_stride;
+                const float* wl = wl0 + (i % p.nwb) * p.wl_stride + bb3;
+#pragma unroll
+                for (int tap = 0; tap < KK; ++tap) {
+                    const int tapoff = ((tap / KS) * PW + (tap % KS)) * CS;
+#pragma unroll
+                    for (int ks = 0; ks < CC / 16; ++ks) {
+                        bf16x8_t ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {      // already split by the staging waves: 16 bytes of hi parts, 16 bytes of lo parts
+                            const char* pc = reinterpret_cast<const char*>(patch + ab3[mt] + tapoff);
+                            union { uint4 u; bf16x8_t v; } Hq, Lq;
+                            Hq.u = *reinterpret_cast<const uint4*>(pc);
+                            Lq.u = *reinterpret_cast<const uint4*>(pc + 2 * CC);
+                            ah[mt] = Hq.v; al[mt] = Lq.v;
+                        }
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            float wv[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) wv[j] = wl[(tap * CC + 16 * ks + j) * BN + nt * 32];
+                            split_bf16x8(wv, bh[nt], bl[nt]);
+                        }
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                            }
+                    }
+                }
+                __syncthreads();    // stage i consumed; stage i + 1 (if any) ready
             }
         } else {
         for (int i = 0; i < nchunks; ++i) {
@@ -683,9 +772,35 @@ static int lean_launch(const ConvDev& d, int tile, int grid, size_t lds, hipStre
     }
 }
 
+#define FC_BF3_TILES(X, KS)                \
+    X(TILE_M128N32, 4, 1, 1, 1, 1, 16, KS, 4)  \
+    X(TILE_M128N64, 4, 1, 1, 1, 2, 16, KS, 4)  \
+    X(TILE_M256N64, 4, 1, 1, 2, 2, 16, KS, 4)
+template <int KS>
+static int bf3_attr_ks() {
+#define X(T, WM, WN, WK, MT, NT, CC, K, NL)                                                                                  \
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pipe_kernel<WM, WN, WK, MT, NT, CC, 8, K, NL, FL_ALL, 1>), \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FC_BF3_TILES(X, KS)
+#undef X
+    return FC_OK;
+}
+template <int KS>
+static int bf3_launch_ks(const ConvDev& d, int tile, int grid, size_t lds, hipStream_t s, int* occ) {
+    switch (tile) {
+#define X(T, WM, WN, WK, MT, NT, CC, K, NL) \
+    case T: return launch_or_query((conv_pipe_kernel<WM, WN, WK, MT, NT, CC, 8, K, NL, FL_ALL, 1>), 256 + 64 * NL, d, grid, lds, s, occ);
+        FC_BF3_TILES(X, KS)
+#undef X
+        default: return fail(FC_E_ARG, "conv: no split-bf16 form of this tile");
+    }
+}
+
 int conv_pipe_init() {
     static bool done = false;
     if (done) return FC_OK;
+    FC_TRY(bf3_attr_ks<1>());
+    FC_TRY(bf3_attr_ks<3>());
     FC_HIP(hipMalloc(reinterpret_cast<void**>(&g_zeros16), 256));
     FC_HIP(hipMemset(g_zeros16, 0, 256));
     FC_TRY(pipe_attr_ks<1>());
@@ -717,6 +832,7 @@ static int pipe_launch_ks(const ConvDev& d, int tile, int grid, size_t lds, hipS
 }
 
 static int conv_pipe_dispatch(const ConvDev& d, int tile, int grid, size_t lds, hipStream_t s, int* occ) {
+    if (d.bf3) return d.a.KS == 1 ? bf3_launch_ks<1>(d, tile, grid, lds, s, occ) : bf3_launch_ks<3>(d, tile, grid, lds, s, occ);
     static const bool lean = [] { const char* e = std::getenv("FLOCODER_AMD_LEAN_KERNELS"); return !(e && std::string(e) == "0"); }();
     if (lean) {                  // the smallest flavour that covers this launch
         const bool small_tile = tile == TILE_M32N32K4;

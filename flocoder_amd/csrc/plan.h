@@ -189,6 +189,7 @@ struct PlanBuilder {
     int err = FC_OK;
     std::string scope;  // reference module the ops being emitted belong to
     int* fin_err_word = nullptr;   // device word a timed-out fused tail sets (owned by the handle the plan belongs to)
+    int conv_prec = 0;             // ConvArgs::prec of every convolution this builder emits (codec plans: 1 = split-bf16 on request)
 
     // guard: 0 always | 1 only when the call has a mask | 2 only when it runs mask_fusion_conv | 3 only when it has NO mask | 4 mask but no fusion
     int guard = 0;
@@ -259,6 +260,7 @@ struct PlanBuilder {
         if (err) return;
         a.B = B; a.H = out.H; a.W = out.W; a.Cout = out.C; a.out = out.p;
         a.Cin = a.s0.C + a.s1.C;
+        a.prec = conv_prec;
         const bool fused = want_G > 0 && (out.H * out.W) % 16 == 0;
         ConvGeom g;
         if (fused) { a.Gout = want_G; a.stats_out = reinterpret_cast<float*>(1); }  // placeholder: geometry only

@@ -1116,6 +1116,9 @@ int fc_debug_copy(void* dst_dev, const void* src_dev, int64_t bytes, void* strea
     return FC_OK;
 }
 
+static int g_debug_conv_prec = 0;
+int fc_debug_set_conv_precision(int mode) { g_debug_conv_prec = mode == 1 ? 1 : 0; return FC_OK; }   // arithmetic of fc_debug_conv launches (tests)
+
 int fc_debug_conv(const float* src0, int c0, const float* src1, int c1, const float* w_oihw, const float* bias, const float* add,
                   float* out, float* stats_out, int groups_out, int* stats_T, float* stats_nt, int batch, int hs, int ws, int cout,
                   int ksize, int pad, int stride, int upsample, int out_act, int tile_cfg, int repeats, float* ms_out, void* stream) {
@@ -1129,6 +1132,7 @@ int fc_debug_conv(const float* src0, int c0, const float* src1, int c1, const fl
     a.W = upsample ? ws * 2 : (ws + 2 * pad - ksize) / stride + 1;
     a.bias = bias; a.add = add; a.out = out; a.out_act = out_act;
     a.stats_out = stats_out; a.Gout = groups_out;
+    a.prec = g_debug_conv_prec;
     float* wp = nullptr;
     FC_HIP(hipMalloc(reinterpret_cast<void**>(&wp), (size_t)cout * a.Cin * ksize * ksize * sizeof(float)));
     int r = pack_conv_launch(w_oihw, wp, cout, a.Cin, ksize, ksize, s);

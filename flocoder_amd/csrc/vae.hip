@@ -23,6 +23,7 @@ struct fc_vae : fc::ParamStore {
     std::vector<int> bo{128, 256, 512, 512};
     fc::Plan enc, dec;
     int enc_B = 0, enc_H = 0, enc_W = 0, dec_B = 0, dec_h = 0, dec_w = 0;
+    int prec = 0;     // fc_vae_set_precision: arithmetic of the plans built from now on (0 exact fp32, 1 split-bf16)
 };
 
 namespace fc {
@@ -150,6 +151,7 @@ static int build_encoder(fc_vae* v, int maxB, int H, int W) {
     const int L = (int)v->bo.size();
     if (!is_pow2(H) || !is_pow2(W) || (H >> (L - 1)) < 1 || (W >> (L - 1)) < 1) return fail(FC_E_SHAPE, "vae: image height/width must be powers of two >= 8");
     VBuilder b(v, &v->enc, maxB);
+    b.conv_prec = v->prec;
     const int G = v->groups, ic = v->in_ch;
     Act xin = b.act(4, H, W);
     float* xp = xin.p;
@@ -216,6 +218,7 @@ static int build_decoder(fc_vae* v, int maxB, int h, int w) {
     const int L = (int)v->bo.size();
     if (!is_pow2(h) || !is_pow2(w)) return fail(FC_E_SHAPE, "vae: latent height/width must be powers of two");
     VBuilder b(v, &v->dec, maxB);
+    b.conv_prec = v->prec;
     const int G = v->groups, lat = v->latent, top = v->bo[L - 1];
     Act zin = b.act(lat, h, w), z1 = b.act(lat, h, w);
     float* zp = zin.p;
@@ -332,6 +335,18 @@ int fc_vae_reserve_encode(fc_vae* v, int max_batch, int height, int width) {
     if (r != FC_OK) v->enc.release();
     return r;
 }
+int fc_vae_set_precision(fc_vae* v, int mode) {
+    if (!v || (mode != 0 && mode != 1)) return fail(FC_E_ARG, "fc_vae_set_precision: mode is 0 (fp32) or 1 (split-bf16)");
+    if (v->prec == mode) return FC_OK;
+    v->prec = mode;
+    if (v->device >= 0) {          // plans in place were built for the other arithmetic: drop them, the next reserve rebuilds
+        FC_HIP(hipSetDevice(v->device));
+        FC_HIP(hipDeviceSynchronize());
+        v->enc.release(); v->dec.release();
+    }
+    return FC_OK;
+}
+
 int fc_vae_reserve_decode(fc_vae* v, int max_batch, int lat_height, int lat_width) {
     if (!v || max_batch < 1 || v->device < 0) return fail(FC_E_ARG, "fc_vae_reserve_decode: bad argument");
     if (v->dec.maxB >= max_batch && v->dec.H == lat_height && v->dec.W == lat_width) return FC_OK;

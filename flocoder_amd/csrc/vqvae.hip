@@ -18,6 +18,7 @@ struct fc_vqvae : fc::ParamStore {
     int device = 0;
     fc_vqvae_config_s c{3, 256, 3, 256, 4, 1, 0};
     fc::Plan enc, dec;
+    int prec = 0;     // fc_vqvae_set_precision
 };
 
 namespace fc {
@@ -210,6 +211,7 @@ static int build_encoder(fc_vqvae* v, int maxB, int H, int W) {
     const int nd = c.num_downsamples, emb = c.vq_embedding_dim;
     if (!is_pow2(H) || !is_pow2(W) || (H >> nd) < 4 || (W >> nd) < 4) return fail(FC_E_SHAPE, "vqvae: image size must be a power of two, >= 4 latent pixels per side");
     QBuilder b(v, &v->enc, maxB);
+    b.conv_prec = v->prec;
     const int ic = c.in_channels, icp = pad4(ic);
     Act x = b.act(icp, H, W);
     float* xp = x.p;
@@ -260,6 +262,7 @@ static int build_decoder(fc_vqvae* v, int maxB, int h, int w) {
     if (!is_pow2(h) || !is_pow2(w) || h < 4 || w < 4) return fail(FC_E_SHAPE, "vqvae: latent size must be a power of two >= 4");
     if (emb & 3) return fail(FC_E_SHAPE, "vqvae: vq_embedding_dim must be a multiple of 4");
     QBuilder b(v, &v->dec, maxB);
+    b.conv_prec = v->prec;
     const std::string L = "decoder.layers.";
     Act z = b.act(emb, h, w);
     float* zp = z.p;
@@ -387,6 +390,18 @@ int fc_vqvae_load_params(fc_vqvae* v, const float* flat, int64_t numel, int on_d
     FC_HIP(hipSetDevice(v->device));
     return v->load(flat, numel, on_device, static_cast<hipStream_t>(stream));
 }
+int fc_vqvae_set_precision(fc_vqvae* v, int mode) {
+    if (!v || (mode != 0 && mode != 1)) return fail(FC_E_ARG, "fc_vqvae_set_precision: mode is 0 (fp32) or 1 (split-bf16)");
+    if (v->prec == mode) return FC_OK;
+    v->prec = mode;
+    if (v->device >= 0) {
+        FC_HIP(hipSetDevice(v->device));
+        FC_HIP(hipDeviceSynchronize());
+        v->enc.release(); v->dec.release();
+    }
+    return FC_OK;
+}
+
 int fc_vqvae_reserve_encode(fc_vqvae* v, int max_batch, int height, int width) {
     if (!v || max_batch < 1 || v->device < 0) return fail(FC_E_ARG, "fc_vqvae_reserve_encode: bad argument");
     if (v->enc.maxB >= max_batch && v->enc.H == height && v->enc.W == width) return FC_OK;

@@ -159,6 +159,7 @@ int fc_debug_set_conv_stamps(void* buf_dev);
  * Synchronises; allocates a scratch weight buffer. stats_out [B][G][T][2] gets (mean, M2) partials, T and the
  * per-slot count come back through stats_T / stats_nt. tile_cfg = -1 picks automatically.  repeats > 0 additionally
  * times that many back-to-back launches with HIP events (average milliseconds in *ms_out). */
+int fc_debug_set_conv_precision(int mode);    /* test hook: arithmetic of fc_debug_conv launches (0 fp32, 1 split-bf16) */
 int fc_debug_conv(const float* src0_nhwc, int c0, const float* src1_nhwc, int c1, const float* w_oihw_dev, const float* bias_dev,
                   const float* add_nhwc, float* out_nhwc, float* stats_out, int groups_out, int* stats_T, float* stats_nt, int batch,
                   int hs, int ws, int cout, int ksize, int pad, int stride, int upsample, int out_act, int tile_cfg, int repeats,
@@ -252,6 +253,11 @@ int fc_vae_reserve_decode(fc_vae* v, int max_batch, int lat_height, int lat_widt
 int fc_vae_encode(fc_vae* v, const float* x_dev, float* mean_out_dev, int batch, int height, int width, void* stream);
 /* x = vae.decode(z).sample  (codecs.py:651): z_dev [B,4,h,w] -> x_out_dev [B,3,8h,8w]. */
 int fc_vae_decode(fc_vae* v, const float* z_dev, float* x_out_dev, int batch, int lat_height, int lat_width, void* stream);
+/* Arithmetic of the plans built from now on: 0 = exact fp32 (default; what every parity test and the headline benchmark use), 1 = split-bf16
+ * -- each fp32 operand as bf16 hi + lo, a product as hi*hi + hi*lo + lo*hi on the bf16 matrix pipe with fp32 accumulation (~1e-5 relative per
+ * layer): an OPT-IN for callers that decode many images and accept that (sampling.py:150-183 decode_latents).  No counterpart upstream.
+ * Changing the mode drops the current plans. */
+int fc_vae_set_precision(fc_vae* v, int mode);
 double fc_vae_flops_per_sample(const fc_vae* v, int decode);
 int fc_vae_plan_launches(const fc_vae* v, int decode);
 /* Measurement only: launch i of the encode / decode plan, and every launch timed alone (see fc_unet_profile_ops). */
@@ -294,6 +300,7 @@ int fc_vqvae_reserve_decode(fc_vqvae* v, int max_batch, int lat_height, int lat_
 int fc_vqvae_encode(fc_vqvae* v, const float* x_dev, float* z_out_dev, int batch, int height, int width, void* stream);
 /* x = vqvae.decode(z_q)  (codecs.py:523-525, noise_strength 0): z_dev [B,vq_embedding_dim,h,w] -> x_out_dev [B,in_channels,H,W]. */
 int fc_vqvae_decode(fc_vqvae* v, const float* z_dev, float* x_out_dev, int batch, int lat_height, int lat_width, void* stream);
+int fc_vqvae_set_precision(fc_vqvae* v, int mode);     /* as fc_vae_set_precision */
 double fc_vqvae_flops_per_sample(const fc_vqvae* v, int decode);
 /* Measurement only (bench.py's config-5 leg): launches of the encode / decode plan, launch i's kernel family, module, algorithmic FLOPs
  * per sample and HBM bytes (per sample / per launch; 0 where not stated), and every launch timed alone as in fc_unet_profile_ops. */

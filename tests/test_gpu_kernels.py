@@ -195,3 +195,24 @@ def test_ot_python_surface():
     perm = compute_ot_pairing(s.to(dev()), t.to(dev()))
     assert perm.dtype == torch.int64 and perm.device.type == "cuda"
     assert torch.equal(perm.cpu(), fo.ot_pairing_greedy(s, t))
+
+
+@pytest.mark.parametrize("tile", ["M128N32", "M128N64", "M256N64"])
+@pytest.mark.parametrize("shape", [(2, 128, 128, 64, 64, 3, 1), (1, 256, 64, 32, 32, 1, 0), (2, 64, 192, 32, 32, 3, 1), (2, 48, 96, 32, 32, 3, 1)])
+def test_conv_split_bf16(tile, shape):
+    """The opt-in split-bf16 arithmetic of the codec tiles (conv_pipe.hip PREC = 1: x = hi + lo in bf16, hi*hi + hi*lo + lo*hi on the bf16 matrix
+    pipe, fp32 accumulation) against torch fp32: rel-L2 <= 2e-5 (each product carries ~2^-16 relative error, errors average over K), and
+    close to -- but not the same as -- the exact-fp32 kernel."""
+    from flocoder_amd._ops import conv_debug
+    B, ci, co, H, W, ks, pad = shape
+    x, w, b = rnd(B, ci, H, W, seed=21), rnd(co, ci, ks, ks, seed=22, scale=(ci * ks * ks) ** -0.5), rnd(co, seed=23)
+    ref = F.conv2d(x, w, b, padding=pad)
+    try:
+        out, _ = conv_debug(x.to(dev()), w.to(dev()), b.to(dev()), pad=pad, tile=tile, precision="bf16x3")
+        exact, _ = conv_debug(x.to(dev()), w.to(dev()), b.to(dev()), pad=pad, tile=tile)
+    except ValueError as e:
+        pytest.skip(str(e))
+    e3, e32 = rel_l2(out.cpu(), ref), rel_l2(exact.cpu(), ref)
+    print(tile, shape, "bf16x3", e3, "fp32", e32)
+    assert e3 < 2e-5 and e32 < TOL
+    assert not torch.equal(out, exact), "the split-bf16 instantiation must be the one that ran"
