@@ -100,6 +100,7 @@ struct ConvArgs {
     // operands straight from it, 16 bytes per lane (conv_pipe.hip)
     const float* w4 = nullptr;
     const float* res_w4 = nullptr;
+    const float* w_b3 = nullptr;   // the weights as split bf16 (pack kind 8) or null: needed by prec == 1
     int prec = 0;              // 1: split-bf16 arithmetic where the tile has that form (codec decoders on request; 0 = exact fp32, always for the U-Net)
     ConvFin fin;
 };
@@ -269,6 +270,8 @@ struct PackTable {                            // device-resident job list + (job
 int pack_conv_launch(const float* oihw, float* dst /*[KK][I][O]*/, int O, int I, int KH, int KW, hipStream_t s);
 // k-step-quad layout [KK][I/8][half][O][4] (I % 8 == 0): ConvArgs::w4
 int pack_conv_k8_launch(const float* oihw, float* dst, int O, int I, int KK, hipStream_t s);
+// split-bf16 copy: hi parts then lo parts, each [KK][Ipad/8][O][8] 16-bit values (Ipad a multiple of 16; KK * Ipad * O floats in all): ConvArgs::w_b3
+int pack_conv_b3_launch(const float* oihw, float* dst, int O, int I, int KK, int Ipad, hipStream_t s);
 // same with zero padding of either channel count: dst [KK][Ipad][Opad]
 int pack_conv_pad_launch(const float* oihw, float* dst, int O, int I, int KK, int Opad, int Ipad, hipStream_t s);
 // operand of the data-gradient pass (forward kernel on dY): [taps flipped][O][nci] for input channels ci0..ci0+nci

@@ -319,7 +319,8 @@ static int conv_geometry(const ConvArgs& a, int tile, bool pipe, ConvDev* d, Con
         // M32N32K4 at 3x3 loads its weights global -> registers (conv_pipe.hip "DB"): no slab stages in LDS
         const bool direct_b = (t.WMWN == 1 && t.MTNT == 1 && a.KS == 3);
         // split-bf16 form (ConvArgs::prec): the three codec tiles at 1x1 / 3x3, plain launches only (no fused res_conv / tail, shared weights)
-        p.bf3 = (a.prec == 1 && (tile == TILE_M128N32 || tile == TILE_M128N64 || tile == TILE_M256N64) && (a.KS == 1 || a.KS == 3) && !a.res_out &&
+        // whose weights exist pre-split (ConvArgs::w_b3, pack kind 8)
+        p.bf3 = (a.prec == 1 && a.w_b3 && (tile == TILE_M128N32 || tile == TILE_M128N64 || tile == TILE_M256N64) && (a.KS == 1 || a.KS == 3) && !a.res_out &&
                  !a.fin.gamma && !a.w_batch_stride) ? 1 : 0;
         p.patch_stride = align4(p.P * (t.CC + ((direct_b || p.bf3) ? 4 : 1)));    // (its k-step-quad form strides pixels by CC + 4 floats, and so does split-bf16)
         p.o_wl = o + 2 * p.patch_stride;

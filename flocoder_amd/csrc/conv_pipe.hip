@@ -85,23 +85,12 @@ __device__ __forceinline__ void loader_handover() {   // LDS stores of this wave
 // PREC = 1: split-bf16 arithmetic (round 3, codec decoders on request -- never the U-Net, never a default): every fp32 operand x is taken as
 // hi + lo with hi = bf16(x), lo = bf16(x - hi), and a product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulation; the
 // dropped lo*lo term is 2^-16 relative).  Three MFMAs of 32 cycles cover sixteen channels where the exact-fp32 pipe needs eight of 64: 5.3x
-// the matrix rate.  Staging, LDS layouts and the epilogue are the fp32 kernel's; the accumulator waves split their operands on the way from
-// LDS to the matrix pipe.
+// the matrix rate.  Nobody splits inside the accumulator waves' loop: the weights are split once, when the parameters are packed (pack kind 8,
+// ConvArgs::w_b3) and reach LDS by the same LDS-DMA pieces as the fp32 slab; the window is split by the staging waves on its way into LDS
+// (a pixel is read by up to nine taps).  The accumulator waves read 16-byte hi / lo operands and issue MFMAs.  The epilogue is the fp32 kernel's.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split_bf16x8(const float (&x)[8], bf16x8_t& hi, bf16x8_t& lo) {
-    union { bf16x8_t v; bf16x2_t p[4]; unsigned u[4]; } H, L;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        f32x2_t pr; pr[0] = x[2 * j]; pr[1] = x[2 * j + 1];
-        H.p[j] = __builtin_convertvector(pr, bf16x2_t);                       // v_cvt_pk_bf16_f32 (round to nearest even)
-        const float h0 = __uint_as_float(H.u[j] << 16), h1 = __uint_as_float(H.u[j] & 0xffff0000u);
-        f32x2_t rr; rr[0] = x[2 * j] - h0; rr[1] = x[2 * j + 1] - h1;
-        L.p[j] = __builtin_convertvector(rr, bf16x2_t);
-    }
-    hi = H.v; lo = L.v;
-}
 
 // four fp32 values -> their bf16 hi parts and lo parts, packed two per dword (channel order kept)
 __device__ __forceinline__ void split_bf16x4(const f32x4& x, uint2& hi, uint2& lo) {
@@ -336,15 +325,25 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
 #pragma unroll
         for (int m = 0; m < MAXP; ++m) {
             const int j = lw + NL * m, f = j * 256 + lane * 4, row = f / BN, n = n0 + (f % BN);
+            if constexpr (BF3) {
+                // split-bf16 slab [part hi/lo][tap][channel block of 8 (two per chunk)][BN] x 16 bytes, read from the pre-split copy of the
+                // weights (pack kind 8: per part [tap][Ipad/8][Cout] x 16 bytes, Ipad = 16 nchunks, zero beyond Cin): one lane, one column's
+                // eight channels.  Same byte count per chunk as the fp32 slab, so the piece bookkeeping is shared
+                const int e = j * 64 + lane, r = e / BN, nn = n0 + e % BN, part = r / (2 * KK), tap = (r >> 1) % KK, c8l = r & 1;
+                d_row[m] = 0;
+                d_ptr[m] = (nn >= Cout || part > 1) ? nullptr
+                         : a.w_b3 + (size_t)part * ((size_t)KK * nchunks * 8 * Cout) + ((size_t)(tap * 2 * nchunks + c8l) * Cout + nn) * 4;
+                continue;
+            }
             const bool res = row >= rows_main;
             d_row[m] = res ? row - rows_main : row % CC;
             d_ptr[m] = n >= Cout ? nullptr : (res ? a.res_w + (size_t)d_row[m] * Cout + n : wbase + ((size_t)(row / CC) * Cin + d_row[m]) * Cout + n);
         }
         auto dma_weights = [&](int i) {
             const int c0 = i * CC;
-            const size_t adv = (size_t)c0 * Cout;
+            const size_t adv = BF3 ? (size_t)i * 8 * Cout : (size_t)c0 * Cout;
             const unsigned wb = smem_lds + 4u * (unsigned)(p.o_wl + (i % nwb) * p.wl_stride + lw * 256);
-            const bool tail = c0 + CC > Cin;            // only the last chunk can run past Cin
+            const bool tail = !BF3 && c0 + CC > Cin;    // only the last chunk can run past Cin (the split-bf16 copy is padded with zeros)
 #pragma unroll
             for (int m = 0; m < MAXP; ++m) {
                 if (m >= my_pieces) break;
@@ -354,7 +353,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
         };
         f32x4 pv[NPL];
         const int nk = __builtin_amdgcn_readfirstlane((p.P * Q + LT - 1) / LT);   // element slots in use (scalar: cheap loop exits)
-        auto issue_patch = [&](int i) {           // input window of chunk i -> registers, every load issued back to back
+        auto issue_patch = [&](int i, f32x4 (&pv)[NPL]) {   // input window of chunk i -> registers, every load issued back to back
             const int c = i * CC + q4;
             const bool live = c < Cin, first = !(FL & FL_CAT) || c < C0;
             const float* base = first ? a.s0.p + c : a.s1.p + (c - C0);
@@ -365,7 +364,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
                 hidden_load16(pv[k], (live && e_po[k] >= 0) ? base + (size_t)e_po[k] * Cs : p.zeros16);
             }
         };
-        auto store_patch = [&](int i) {           // ... and on into LDS with GroupNorm / FiLM / SiLU applied
+        auto store_patch = [&](int i, f32x4 (&pv)[NPL]) {   // ... and on into LDS with GroupNorm / FiLM / SiLU applied
             const int c = i * CC + q4;
             float* pb = patch0 + (i & 1) * p.patch_stride;
             const bool live = c < Cin, act = (c < C0) ? p.act0 : p.act1;
@@ -410,7 +409,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
             }
         }
         gn_tables(true, ltid, LT);
-        store_patch(0);
+        store_patch(0, pv);
         if (FL & FL_STAMP) conv_stamp(p, 3);
         loader_handover();                        // stage 0 ready
         for (int g = 0; g < nchunks; ++g) {       // consumers are on chunk g
@@ -418,14 +417,14 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
             int ahead = 0;
             unsigned long long ta = ((FL & FL_STAMP) && p.stamps) ? __builtin_amdgcn_s_memtime() : 0ull;
             if (!DB && next && nwb == 2) dma_weights(g + 1);
-            if (next) issue_patch(g + 1);
+            if (next) issue_patch(g + 1, pv);
             unsigned long long tb_ = ((FL & FL_STAMP) && p.stamps) ? __builtin_amdgcn_s_memtime() : 0ull;
             if (!DB && nwb == 3 && g + 2 < nchunks) { dma_weights(g + 2); ahead = my_pieces; }
             unsigned long long t0 = ((FL & FL_STAMP) && p.stamps) ? __builtin_amdgcn_s_memtime() : 0ull;
             if ((FL & FL_STAMP) && p.stamps) { dbg_issue += tb_ - ta; dbg_dma += t0 - tb_; }
             wait_vmcnt(ahead);                    // window g+1 in registers, slab g+1 landed; slab g+2 stays in flight across the barrier
             unsigned long long t1 = ((FL & FL_STAMP) && p.stamps) ? __builtin_amdgcn_s_memtime() : 0ull;
-            if (next) store_patch(g + 1);
+            if (next) store_patch(g + 1, pv);
             unsigned long long t2 = ((FL & FL_STAMP) && p.stamps) ? __builtin_amdgcn_s_memtime() : 0ull;
             loader_handover();
             if ((FL & FL_STAMP) && p.stamps) { dbg_mem += t1 - t0; dbg_store += t2 - t1; dbg_bar += __builtin_amdgcn_s_memtime() - t2; }
@@ -563,40 +562,38 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
             int ab3[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) ab3[mt] = abase[mt] - half + 4 * half;    // (16 bytes per half: eight bf16)
-            const int bb3 = wn * NT * 32 + l31 + 8 * half * BN;
+            const int bb3 = 4 * (half * BN + wn * NT * 32 + l31);    // floats: 16 bytes per (channel block, column)
+            static_assert(CC == 16, "one k-step of sixteen channels per tap");
+            typedef union { uint4 u; bf16x8_t v; } opnd_t;
             for (int i = 0; i < nchunks; ++i) {
                 const float* patch = patch0 + (i & 1) * p.patch_stride;
                 const float* wl = wl0 + (i % p.nwb) * p.wl_stride + bb3;
+                // (The scheduler is left alone here.  A pinned schedule -- operands of tap t + 1 requested, then the 3 MT NT MFMAs of tap t
+                // back to back -- measured 376 images/s against 421 on the SD-VAE decode: the staging waves' VALU work does not overlap the
+                // MFMAs of the wave that shares their SIMD, DESIGN.md section 5, and a dense MFMA stream only moves the waiting around.)
 #pragma unroll
                 for (int tap = 0; tap < KK; ++tap) {
                     const int tapoff = ((tap / KS) * PW + (tap % KS)) * CS;
+                    opnd_t A[MT][2], Bq[NT][2];       // [tile][hi / lo]
 #pragma unroll
-                    for (int ks = 0; ks < CC / 16; ++ks) {
-                        bf16x8_t ah[MT], al[MT], bh[NT], bl[NT];
+                    for (int mt = 0; mt < MT; ++mt) {  // split by the staging waves: 16 bytes of hi parts, 16 bytes of lo parts per pixel and half
+                        const char* pc = reinterpret_cast<const char*>(patch + ab3[mt] + tapoff);
+                        A[mt][0].u = *reinterpret_cast<const uint4*>(pc);
+                        A[mt][1].u = *reinterpret_cast<const uint4*>(pc + 2 * CC);
+                    }
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) {      // already split by the staging waves: 16 bytes of hi parts, 16 bytes of lo parts
-                            const char* pc = reinterpret_cast<const char*>(patch + ab3[mt] + tapoff);
-                            union { uint4 u; bf16x8_t v; } Hq, Lq;
-                            Hq.u = *reinterpret_cast<const uint4*>(pc);
-                            Lq.u = *reinterpret_cast<const uint4*>(pc + 2 * CC);
-                            ah[mt] = Hq.v; al[mt] = Lq.v;
-                        }
+                    for (int nt = 0; nt < NT; ++nt) {  // split at pack time, staged by LDS-DMA
+                        Bq[nt][0].u = *reinterpret_cast<const uint4*>(wl + 4 * ((tap * 2) * BN + nt * 32));
+                        Bq[nt][1].u = *reinterpret_cast<const uint4*>(wl + 4 * (((KK + tap) * 2) * BN + nt * 32));
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
-                            float wv[8];
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) wv[j] = wl[(tap * CC + 16 * ks + j) * BN + nt * 32];
-                            split_bf16x8(wv, bh[nt], bl[nt]);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt][1].v, Bq[nt][0].v, acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt][0].v, Bq[nt][1].v, acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt][0].v, Bq[nt][0].v, acc[mt][nt], 0, 0, 0);
                         }
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) {
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-                            }
-                    }
                 }
                 __syncthreads();    // stage i consumed; stage i + 1 (if any) ready
             }
@@ -772,6 +769,7 @@ static int lean_launch(const ConvDev& d, int tile, int grid, size_t lds, hipStre
     }
 }
 
+// (four staging waves as in the fp32 form: eight measured 364 against 380 images/s on the SD-VAE decode)
 #define FC_BF3_TILES(X, KS)                \
     X(TILE_M128N32, 4, 1, 1, 1, 1, 16, KS, 4)  \
     X(TILE_M128N64, 4, 1, 1, 1, 2, 16, KS, 4)  \

@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) transpose_batched_kernel(const float* src
 // ---- a whole table of re-layout jobs in ONE launch (a training step re-packs ~190 weight tensors: launch latency, not bytes) ----
 // kinds: 0 conv OIHW -> [KK][I][O] (a=O b=I c=KK) | 1 s2d (a=O b=C) | 2 transpose (a=R b=Cc c=ld d=col0) | 3 copy (a=n)
 //        4 conv with channel padding (a=O b=I c=KK d=Opad e=Ipad) | 5 data-gradient operand (a=O b=I c=KS d=ci0 e=nci)
-//        6 conv in k-step-quad layout (a=O b=I c=KK)
+//        6 conv in k-step-quad layout (a=O b=I c=KK) | 8 conv as split bf16 (a=O b=I c=KK d=Ipad)
 __global__ void __launch_bounds__(256) pack_table_kernel(const PackJob* jobs, const int2* blocks) {
     const int2 bj = blocks[blockIdx.x];          // (job, block index inside the job)
     const PackJob j = jobs[bj.x];
@@ -103,6 +103,23 @@ __global__ void __launch_bounds__(256) pack_table_kernel(const PackJob* jobs, co
                 const int jj = (int)(t & 3); size_t r = t >> 2; const int o = (int)(r % j.a); r /= j.a; const int half = (int)(r & 1); r >>= 1;
                 const int c8 = (int)(r % (j.b / 8)), tap = (int)(r / (j.b / 8));
                 dst[t] = src[((size_t)o * j.b + 8 * c8 + 2 * jj + half) * j.c + tap]; break; }
+            case 8: {   // conv OIHW -> split bf16, two arrays (hi parts, then lo parts) of [tap][Ipad/8][O][8] 16-bit values, Ipad = d (channels
+                        // beyond I are zeros): the B operand of v_mfma_f32_32x32x16_bf16 for one column and eight consecutive channels is 16
+                        // contiguous bytes, and a 64-column row of one (tap, channel block) is one 1 KiB LDS-DMA piece; a=O b=I c=KK d=Ipad.
+                        // t runs over the elements of ONE part; x = hi + lo with hi = bf16(x) (nearest even), lo = bf16(x - hi)
+                const int jj = (int)(t & 7); size_t r = t >> 3; const int o = (int)(r % j.a); r /= j.a;
+                const int c8 = (int)(r % (j.d / 8)), tap = (int)(r / (j.d / 8)), ci = 8 * c8 + jj;
+                const float x = ci < j.b ? src[((size_t)o * j.b + ci) * j.c + tap] : 0.f;
+                unsigned u = __float_as_uint(x);
+                u += 0x7fffu + ((u >> 16) & 1u);
+                const unsigned short hi = (unsigned short)(u >> 16);
+                const float rem = x - __uint_as_float((unsigned)hi << 16);
+                unsigned v = __float_as_uint(rem);
+                v += 0x7fffu + ((v >> 16) & 1u);
+                unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
+                d16[t] = hi;
+                d16[(size_t)j.a * j.d * j.c + t] = (unsigned short)(v >> 16);
+                break; }
             default: { const int KK = j.c * j.c; const int i = (int)(t % j.e); const size_t r = t / j.e; const int o = (int)(r % j.a), tap = (int)(r / j.a);
                        const int ky = j.c - 1 - tap / j.c, kx = j.c - 1 - tap % j.c;
                        dst[t] = src[((size_t)o * j.b + j.d + i) * KK + ky * j.c + kx]; break; }
@@ -118,6 +135,7 @@ size_t pack_job_total(const PackJob& j) {
         case 3: return (size_t)j.a;
         case 4: return (size_t)j.d * j.e * j.c;
         case 6: return (size_t)j.a * j.b * j.c;
+        case 8: return (size_t)j.a * j.d * j.c;
         default: return (size_t)j.a * j.e * j.c * j.c;
     }
 }
@@ -170,6 +188,26 @@ __global__ void __launch_bounds__(256) pack_conv_k8_kernel(const float* src, flo
 }
 int pack_conv_k8_launch(const float* oihw, float* dst, int O, int I, int KK, hipStream_t s) {
     hipLaunchKernelGGL(pack_conv_k8_kernel, dim3(pgrid((size_t)O * I * KK)), dim3(256), 0, s, oihw, dst, O, I, KK);
+    FC_HIP(hipGetLastError());
+    return FC_OK;
+}
+__global__ void __launch_bounds__(256) pack_conv_b3_kernel(const float* src, unsigned short* dst, int O, int I, int KK, int Ipad) {
+    const size_t total = (size_t)O * Ipad * KK;
+    for (size_t t = blockIdx.x * 256ull + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        const int jj = (int)(t & 7); size_t r = t >> 3; const int o = (int)(r % O); r /= O;
+        const int c8 = (int)(r % (Ipad / 8)), tap = (int)(r / (Ipad / 8)), ci = 8 * c8 + jj;
+        const float x = ci < I ? src[((size_t)o * I + ci) * KK + tap] : 0.f;
+        unsigned u = __float_as_uint(x);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        const unsigned short hi = (unsigned short)(u >> 16);
+        unsigned v = __float_as_uint(x - __uint_as_float((unsigned)hi << 16));
+        v += 0x7fffu + ((v >> 16) & 1u);
+        dst[t] = hi;
+        dst[total + t] = (unsigned short)(v >> 16);
+    }
+}
+int pack_conv_b3_launch(const float* oihw, float* dst, int O, int I, int KK, int Ipad, hipStream_t s) {
+    hipLaunchKernelGGL(pack_conv_b3_kernel, dim3(pgrid((size_t)O * Ipad * KK)), dim3(256), 0, s, oihw, reinterpret_cast<unsigned short*>(dst), O, I, KK, Ipad);
     FC_HIP(hipGetLastError());
     return FC_OK;
 }

@@ -90,6 +90,12 @@ struct ParamStore {
     PackTable pack_table;                          // all of `packops` as one launch
     bool loaded = false;
 
+    bool want_b3 = false;   // also keep 3x3 / 1x1 conv weights as split bf16 (pack kind 8): the codecs, for their opt-in split-bf16 arithmetic
+    std::unordered_map<int64_t, int64_t> b3_of;   // packed offset of a weight -> packed offset of its split-bf16 copy
+    const float* B3(const float* w) const {         // the split-bf16 copy of packed weight pointer `w`, or null
+        auto it = b3_of.find(w - packed);
+        return it == b3_of.end() ? nullptr : packed + it->second;
+    }
     bool want_k8 = false;   // also keep 3x3 / 1x1 conv weights in the k-step-quad layout (pack kind 6) where the shapes allow: the U-Net's low-resolution layers
     // the k-step-quad copy of a convolution weight, or null when there is none
     const float* P8(const std::string& n) const { auto it = pk.find(n + "#k8"); return it == pk.end() ? nullptr : packed + it->second; }
@@ -119,6 +125,12 @@ struct ParamStore {
         if (bias) declare(n + ".bias", {O});
         const int64_t dst = pk_alloc(n + ".weight", (int64_t)O * I * K * K);
         packops.push_back({0, params[pidx[n + ".weight"]].offset, dst, O, I, K, K});
+        if (want_b3 && (K == 3 || K == 1)) {
+            const int Ipad = (I + 15) / 16 * 16;
+            const int64_t d3 = pk_alloc(n + ".weight#b3", (int64_t)O * Ipad * K * K);
+            packops.push_back({8, params[pidx[n + ".weight"]].offset, d3, O, I, K * K, Ipad});
+            b3_of[dst] = d3;
+        }
         if (want_k8 && (K == 3 || K == 1) && I % 32 == 0 && O % 32 == 0) {
             const int64_t d8 = pk_alloc(n + ".weight#k8", (int64_t)O * I * K * K);
             packops.push_back({6, params[pidx[n + ".weight"]].offset, d8, O, I, K * K, 0});
@@ -190,6 +202,7 @@ struct PlanBuilder {
     std::string scope;  // reference module the ops being emitted belong to
     int* fin_err_word = nullptr;   // device word a timed-out fused tail sets (owned by the handle the plan belongs to)
     int conv_prec = 0;             // ConvArgs::prec of every convolution this builder emits (codec plans: 1 = split-bf16 on request)
+    const ParamStore* store = nullptr;   // where conv() finds the split-bf16 copy of a weight (codec builders set it)
 
     // guard: 0 always | 1 only when the call has a mask | 2 only when it runs mask_fusion_conv | 3 only when it has NO mask | 4 mask but no fusion
     int guard = 0;
@@ -261,6 +274,7 @@ struct PlanBuilder {
         a.B = B; a.H = out.H; a.W = out.W; a.Cout = out.C; a.out = out.p;
         a.Cin = a.s0.C + a.s1.C;
         a.prec = conv_prec;
+        if (conv_prec && store && !a.w_batch_stride) a.w_b3 = store->B3(a.w);
         const bool fused = want_G > 0 && (out.H * out.W) % 16 == 0;
         ConvGeom g;
         if (fused) { a.Gout = want_G; a.stats_out = reinterpret_cast<float*>(1); }  // placeholder: geometry only

@@ -1143,6 +1143,13 @@ int fc_debug_conv(const float* src0, int c0, const float* src1, int c1, const fl
         r = pack_conv_k8_launch(w_oihw, wp8, cout, a.Cin, 9, s);
         a.w4 = wp8;
     }
+    float* wp3 = nullptr;       // ... and the split-bf16 copy when that arithmetic is asked for, as a codec plan would (pack kind 8)
+    if (r == FC_OK && a.prec == 1 && (ksize == 3 || ksize == 1)) {
+        const int ipad = (a.Cin + 15) / 16 * 16;
+        FC_HIP(hipMalloc(reinterpret_cast<void**>(&wp3), (size_t)cout * ipad * ksize * ksize * sizeof(float)));
+        r = pack_conv_b3_launch(w_oihw, wp3, cout, a.Cin, ksize * ksize, ipad, s);
+        a.w_b3 = wp3;
+    }
     ConvGeom g;
     if (r == FC_OK) r = conv_plan(a, tile_cfg, &g);
     if (r == FC_OK) { if (stats_T) *stats_T = g.T; if (stats_nt) *stats_nt = g.n_t; r = conv_launch(a, g.tile, s); }
@@ -1161,6 +1168,7 @@ int fc_debug_conv(const float* src0, int c0, const float* src1, int c1, const fl
     (void)hipStreamSynchronize(s);
     (void)hipFree(wp);
     if (wp8) (void)hipFree(wp8);
+    if (wp3) (void)hipFree(wp3);
     return r;
 }
 

@@ -90,7 +90,7 @@ static int declare_all(fc_vae* v) {
 
 struct VBuilder : PlanBuilder {
     fc_vae* v;
-    VBuilder(fc_vae* v_, Plan* pl_, int B_) : v(v_) { pl = pl_; B = B_; }
+    VBuilder(fc_vae* v_, Plan* pl_, int B_) : v(v_) { pl = pl_; B = B_; store = v_; }
 
     SrcXform gn(const Stat& st, const std::string& norm, int mode) { return xf_of(st, mode, v->R(norm + ".weight"), v->R(norm + ".bias"), nullptr, 0, kEps); }
 
@@ -290,6 +290,7 @@ int fc_vae_create(int device, fc_vae** out) {
     if (!out) return fail(FC_E_ARG, "fc_vae_create: null argument");
     std::unique_ptr<fc_vae> v(new fc_vae);
     v->device = device;
+    v->want_b3 = device >= 0;      // the split-bf16 copies of the conv weights (set_precision): +1x the conv weights in HBM
     FC_TRY(declare_all(v.get()));
     if (device < 0) { *out = v.release(); return FC_OK; }
     FC_TRY(fc_check_device(device));

@@ -115,7 +115,7 @@ static int declare_all(fc_vqvae* v) {
 
 struct QBuilder : PlanBuilder {
     fc_vqvae* v;
-    QBuilder(fc_vqvae* v_, Plan* pl_, int B_) : v(v_) { pl = pl_; B = B_; }
+    QBuilder(fc_vqvae* v_, Plan* pl_, int B_) : v(v_) { pl = pl_; B = B_; store = v_; }
 
     SrcXform gn(const Stat& st, const std::string& norm, int mode, float eps = 1e-5f) {
         return xf_of(st, mode, v->R(norm + ".weight"), v->R(norm + ".bias"), nullptr, 0, eps);
@@ -360,6 +360,7 @@ int fc_vqvae_create_ex(int in_channels, int hidden_channels, int num_downsamples
     std::unique_ptr<fc_vqvae> v(new fc_vqvae);
     v->device = device;
     v->c = {in_channels, hidden_channels, num_downsamples, internal_dim, vq_embedding_dim, decoder_nonlocal, natten_layout};
+    v->want_b3 = device >= 0;      // the split-bf16 copies of the conv weights (set_precision): +1x the conv weights in HBM
     FC_TRY(declare_all(v.get()));
     if (device < 0) { *out = v.release(); return FC_OK; }
     FC_TRY(fc_check_device(device));

@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--tiles", default=",".join(TILES))
     ap.add_argument("--repeats", type=int, default=50)
     ap.add_argument("--vae", action="store_true")
+    ap.add_argument("--precision", default="fp32", help="fp32 | bf16x3 (the split-bf16 form, codec tiles only)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     tiles = args.tiles.split(",")
@@ -67,7 +68,7 @@ def main():
         cells = []
         for t in tiles:
             try:
-                ms = conv_debug(x0, w, b, x1=x1, pad=pad, stride=stride, upsample=bool(ups), groups_out=G, tile=t, repeats=args.repeats)
+                ms = conv_debug(x0, w, b, x1=x1, pad=pad, stride=stride, upsample=bool(ups), groups_out=G, tile=t, repeats=args.repeats, precision=args.precision)
                 cells.append(f"{ms * 1e3:7.1f} |{flops / ms / 1e9:7.1f}")
             except ValueError:
                 cells.append(f"{'n/a':>16s}")

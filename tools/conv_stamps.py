@@ -5,22 +5,24 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from flocoder_amd import _binding as B
 from flocoder_amd._ops import conv_debug
-from tools.conv_microbench import LAYERS
+from tools.conv_microbench import LAYERS, VAE_LAYERS
 
 NAMES = ["start", "descr", "issue", "stored0", "barrier0", "mfma_done", "kreduce", "stores", "end"]
 dev = torch.device("cuda:0")
 only = sys.argv[1] if len(sys.argv) > 1 else ""
 tile = sys.argv[2] if len(sys.argv) > 2 else "auto"
-for name, c0, c1, co, H, ks, pad, stride, ups, G in LAYERS:
+vae = len(sys.argv) > 3 and sys.argv[3] == "vae"            # SD-VAE decoder shapes at batch 16
+prec = sys.argv[4] if len(sys.argv) > 4 else "fp32"          # "bf16x3": the split-bf16 form
+for name, c0, c1, co, H, ks, pad, stride, ups, G in (VAE_LAYERS if vae else LAYERS):
     if only and only not in name:
         continue
-    Bn = 64
+    Bn = 16 if vae else 64
     x0 = torch.randn(Bn, c0, H, H, device=dev); x1 = torch.randn(Bn, c1, H, H, device=dev) if c1 else None
     w = torch.randn(co, c0 + c1, ks, ks, device=dev) * 0.05; b = torch.randn(co, device=dev)
-    conv_debug(x0, w, b, x1=x1, pad=pad, stride=stride, upsample=bool(ups), groups_out=G, tile=tile)   # warm
+    conv_debug(x0, w, b, x1=x1, pad=pad, stride=stride, upsample=bool(ups), groups_out=G, tile=tile, precision=prec)   # warm
     buf = torch.zeros(8192 * 8 * 16, dtype=torch.int64, device=dev)
     B.check(B.lib().fc_debug_set_conv_stamps(buf.data_ptr()))
-    conv_debug(x0, w, b, x1=x1, pad=pad, stride=stride, upsample=bool(ups), groups_out=G, tile=tile)
+    conv_debug(x0, w, b, x1=x1, pad=pad, stride=stride, upsample=bool(ups), groups_out=G, tile=tile, precision=prec)
     B.check(B.lib().fc_debug_set_conv_stamps(None))
     torch.cuda.synchronize()
     st = buf.view(8192, 8, 16).cpu()

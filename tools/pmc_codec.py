@@ -2,7 +2,7 @@
 """Smallest run that exercises every kernel of a codec pass once per launch site, for `rocprofv3 --pmc <counter> --kernel-trace`
 (one counter group per pass): tools/pmc_summary.py turns the FETCH_SIZE / WRITE_SIZE passes into per-kernel HBM traffic per launch.
 
-    python tools/pmc_codec.py sdvae_decode|vqvae_encode|vqvae_decode [n_passes]
+    python tools/pmc_codec.py sdvae_decode|vqvae_encode|vqvae_decode [n_passes] [fp32|bf16x3]
 
 sdvae_decode: SD-VAE decode of one chunk of 16 latents 4x32x32 -> 3x256x256 (bench.py's DECODE_CHUNK, seeded random weights);
 vqvae_*: the midi_vqgan.yaml VQVAE at B=64, 128x128 (bench.py config5)."""
@@ -18,6 +18,7 @@ import bench  # noqa: E402
 def main():
     what = sys.argv[1]
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    prec = sys.argv[3] if len(sys.argv) > 3 else "fp32"
     dev = torch.device("cuda", 0)
     g = torch.Generator().manual_seed(55)
     if what == "sdvae_decode":
@@ -36,6 +37,7 @@ def main():
         else:
             z = torch.randn(bench.BATCH, 4, 16, 16, generator=g).to(dev)      # (no encode here: the counters should see decode launches only)
             fn = lambda: codec.decode(z)
+    codec.set_precision(prec)
     with torch.no_grad():
         for _ in range(n):
             out = fn()
