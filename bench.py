@@ -345,7 +345,8 @@ def secondary(model, noise, ids, device):
     t_enc, _ = _gpu_time(lambda: torch.cat([vae.encode(img[i:i + DECODE_CHUNK]) for i in range(0, BATCH, DECODE_CHUNK)]), device, 2)
     assert torch.isfinite(img).all()
     gf_dec, gf_enc = vae.flops_per_sample(True) / 1e9, vae.flops_per_sample(False) / 1e9
-    rows = vae.profile_ops(z[:DECODE_CHUNK].contiguous(), img[:DECODE_CHUNK].contiguous(), decode=True, repeats=3)
+    # (a scratch output: the per-launch timing repeats every launch in place, over pooled buffers -- what it leaves in `out` is not a decode)
+    rows = vae.profile_ops(z[:DECODE_CHUNK].contiguous(), torch.empty_like(img[:DECODE_CHUNK]), decode=True, repeats=3)
     by = _by_kernel(rows)
     name, dom = max(by.items(), key=lambda kv: kv[1]["ms"])
     tot = sum(v["ms"] for v in by.values())
@@ -376,7 +377,7 @@ def secondary(model, noise, ids, device):
         "ms": round(t_dec3 * 1e3, 1), "images_per_s": round(BATCH / t_dec3, 1), "speedup_vs_fp32": round(t_dec / t_dec3, 2),
         "rel_l2_vs_fp32_decode": float(f"{err3:.3e}"), "gate": 1e-3, "encode_images_per_s": round(BATCH / t_enc3, 1),
         "euler64_plus_decode_images_per_s": round(BATCH / (t_ode + t_dec3), 1)}
-    assert err3 < 1e-3
+    assert err3 < 1e-3, f"split-bf16 decode is {err3:.3e} rel-L2 away from the fp32 decode (gate 1e-3)"
     out["euler64_plus_decode"] = {"workload": "64-step Euler + SD-VAE decode (decoded images/s, SURVEY 8d secondary metric)",
                                   "images_per_s": round(BATCH / (t_ode + t_dec), 1), "ode_ms": round(t_ode * 1e3, 1), "decode_ms": round(t_dec * 1e3, 1)}
     del vae

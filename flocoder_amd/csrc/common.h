@@ -220,6 +220,8 @@ struct LaArgs {
     float eps2 = 1e-5f;
     float* out = nullptr;
     float* part = nullptr;         // [B][heads][n][C] scratch: every head's share of to_out.0
+    unsigned* tickets = nullptr;   // [B] arrival counters, zero when allocated: with them the module is ONE launch -- the workgroup of a sample that
+                                   // arrives last (ticket % heads == heads - 1) adds the shares, normalises and writes `out`; nobody waits
 };
 int linattn_fused_init();
 bool linattn_fused_supported(int n, int C, int heads);
@@ -229,6 +231,7 @@ int linattn_fused_launch(const LaArgs& a, hipStream_t s);
 // The whole Residual(PreNorm(LinearAttention)) module in two launches, a workgroup per (sample, head) then per sample (n <= 64 positions)
 int linattn_sample_init();
 bool linattn_sample_supported(int n, int C, int heads);
+bool linattn_sample_one_launch(int n, int C);      // may LaArgs::tickets be set for this shape
 int linattn_sample_launch(const LaArgs& a, hipStream_t s);
 // Residual(PreNorm(Attention)) on the same kernels (g2 / b2 unused: to_out has no norm)
 bool attn_sample_supported(int n, int C, int heads);

@@ -64,6 +64,75 @@ __device__ __forceinline__ void gemm_stream(const float* __restrict__ A, int lda
     }
 }
 
+// y = bias + sum_h part[b][h], GroupNorm(1) (to_out.1) by a two-pass block reduction, + x -> out[b]: the closing step of the module, run by the
+// LAST workgroup of a sample inside la_head (one-launch form) -- 256 threads, at most JE float4's each.  `red`: 8 floats of LDS.
+constexpr int JE = 8;
+template <bool GN>
+__device__ __forceinline__ void join_tail(const LaArgs& a, int b, float* red) {
+    const int tid = threadIdx.x, C = a.C, total4 = a.n * C / 4;
+    const size_t per = (size_t)a.n * C;
+    const float* pb = a.part + (size_t)b * HEADS * per;
+    const float* xb = a.x + (size_t)b * per;
+    float* ob = a.out + (size_t)b * per;
+    auto bsum = [&](float v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = v;
+        __syncthreads();
+        return (red[0] + red[1]) + (red[2] + red[3]);
+    };
+    auto share4 = [](const float* q) {      // four values another workgroup (another XCD) has just written: device-scope loads, past this XCD's L2
+        const unsigned long long lo = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long hi = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(q) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)), __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)));
+    };
+    float4 v[JE];
+    float S = 0.f;
+#pragma unroll
+    for (int e = 0; e < JE; ++e) {
+        const int i = tid + e * 256;
+        v[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < total4) {
+            const float4 p0 = share4(pb + (size_t)i * 4), p1 = share4(pb + per + (size_t)i * 4);
+            const float4 p2 = share4(pb + 2 * per + (size_t)i * 4), p3 = share4(pb + 3 * per + (size_t)i * 4);
+            const float4 bi = *reinterpret_cast<const float4*>(a.bout + (i * 4) % C);
+            v[e].x = bi.x + ((p0.x + p1.x) + (p2.x + p3.x)); v[e].y = bi.y + ((p0.y + p1.y) + (p2.y + p3.y));
+            v[e].z = bi.z + ((p0.z + p1.z) + (p2.z + p3.z)); v[e].w = bi.w + ((p0.w + p1.w) + (p2.w + p3.w));
+            S += (v[e].x + v[e].y) + (v[e].z + v[e].w);
+        }
+    }
+    float mu = 0.f, rs = 1.f;
+    if (GN) {
+        const float cnt = (float)a.n * (float)C;
+        mu = bsum(S) / cnt;
+        float Q = 0.f;
+#pragma unroll
+        for (int e = 0; e < JE; ++e)
+            if (tid + e * 256 < total4) {
+                const float dx = v[e].x - mu, dy = v[e].y - mu, dz = v[e].z - mu, dw = v[e].w - mu;
+                Q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+        rs = 1.0f / sqrtf(bsum(Q) / cnt + a.eps2);
+    }
+#pragma unroll
+    for (int e = 0; e < JE; ++e) {
+        const int i = tid + e * 256;
+        if (i < total4) {
+            const float4 x = *reinterpret_cast<const float4*>(xb + (size_t)i * 4);
+            float4 o;
+            if (GN) {
+                const float4 g = *reinterpret_cast<const float4*>(a.g2 + (i * 4) % C), be = *reinterpret_cast<const float4*>(a.b2 + (i * 4) % C);
+                o.x = ((v[e].x - mu) * rs * g.x + be.x) + x.x; o.y = ((v[e].y - mu) * rs * g.y + be.y) + x.y;
+                o.z = ((v[e].z - mu) * rs * g.z + be.z) + x.z; o.w = ((v[e].w - mu) * rs * g.w + be.w) + x.w;
+            } else {
+                o.x = v[e].x + x.x; o.y = v[e].y + x.y; o.z = v[e].z + x.z; o.w = v[e].w + x.w;
+            }
+            *reinterpret_cast<float4*>(ob + (size_t)i * 4) = o;
+        }
+    }
+}
+
 template <int MT, bool FULL>   // MT = ceil(n / 32) row tiles; FULL: softmax(q k^T) v (Attention, unet.py:99-122) instead of the linear form
 __global__ void __launch_bounds__(256) la_head_kernel(const LaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -301,8 +370,25 @@ __global__ void __launch_bounds__(256) la_head_kernel(const LaArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mt * 32 + acc_row(r, half);
-                if (row < n) pb[(size_t)row * C + ct * 32 + l31] = y[mt][r];
+                if (row >= n) continue;
+                float* dst = pb + (size_t)row * C + ct * 32 + l31;
+                if (a.tickets) __hip_atomic_store(dst, y[mt][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: through the per-XCD L2
+                else *dst = y[mt][r];
             }
+    }
+    if (a.tickets) {
+        // One-launch form: the workgroup of a sample that draws the last ticket of this launch closes the module for it.  No workgroup waits
+        // for another, so nothing here depends on how many of them are resident (unlike the convolution tails' meetings).  The heads of a
+        // sample sit on different XCDs, whose L2s are not coherent with each other: the shares travel as device-scope relaxed atomics (sc1
+        // stores above, sc1 loads in join_tail), ordered by vmcnt(0) + the workgroup barrier in front of the ticket -- NOT by a release /
+        // acquire fence pair, which writes back and invalidates the whole L2 in every workgroup (measured here: 58 instead of 22 us per
+        // module; conv_dev.h has the same finding for the convolution tails).  The counters only ever grow: `heads` per launch.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) sm[0] = (__hip_atomic_fetch_add(a.tickets + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) % HEADS == HEADS - 1) ? 1.f : 0.f;
+        __syncthreads();
+        if (sm[0] == 0.f) return;
+        join_tail<!FULL>(a, b, sm + 8);
     }
 }
 
@@ -388,6 +474,7 @@ static void launch_pair(const LaArgs& a, hipStream_t s) {
     const size_t lds = head_lds(a.n, a.C);
     if (a.n <= 32) hipLaunchKernelGGL((la_head_kernel<1, FULL>), dim3(HEADS, a.B), dim3(256), lds, s, a);
     else hipLaunchKernelGGL((la_head_kernel<2, FULL>), dim3(HEADS, a.B), dim3(256), lds, s, a);
+    if (a.tickets) return;          // the last workgroup of every sample has done la_join's work
     const int total4 = a.n * a.C / 4;
     if (total4 <= JT) hipLaunchKernelGGL((la_join_kernel<1, !FULL>), dim3(a.B), dim3(JT), 0, s, a);
     else if (total4 <= 2 * JT) hipLaunchKernelGGL((la_join_kernel<2, !FULL>), dim3(a.B), dim3(JT), 0, s, a);
@@ -408,12 +495,16 @@ bool linattn_sample_supported(int n, int C, int heads) {
            head_lds(n, C) <= 160 * 1024;
 }
 
+// the one-launch form (LaArgs::tickets): the closing workgroup holds a sample's n*C values in JE float4's per thread
+bool linattn_sample_one_launch(int n, int C) { return (size_t)n * C <= (size_t)JE * 256 * 4; }
+
 bool attn_sample_supported(int n, int C, int heads) { return linattn_sample_supported(n, C, heads) && C >= (n <= 32 ? 32 : 64); }
 
 int linattn_sample_launch(const LaArgs& a, hipStream_t s) {
     if (!linattn_sample_supported(a.n, a.C, a.heads)) return fail(FC_E_SHAPE, "linattn_sample: unsupported shape");
     if (a.xf.mode != 1 || a.xf.G != 1 || !a.xf.stats) return fail(FC_E_ARG, "linattn_sample: needs GroupNorm(1) statistics of x");
     if (!a.g2 || !a.b2 || !a.out || !a.part || !a.bout) return fail(FC_E_ARG, "linattn_sample: to_out parameters / scratch / output missing");
+    if (a.tickets && !linattn_sample_one_launch(a.n, a.C)) return fail(FC_E_SHAPE, "linattn_sample: sample too large for the one-launch form");
     launch_pair<false>(a, s);
     FC_HIP(hipGetLastError());
     return FC_OK;
@@ -424,6 +515,7 @@ int attn_sample_launch(const LaArgs& a, hipStream_t s) {
     if (!attn_sample_supported(a.n, a.C, a.heads)) return fail(FC_E_SHAPE, "attn_sample: unsupported shape");
     if (a.xf.mode != 1 || a.xf.G != 1 || !a.xf.stats) return fail(FC_E_ARG, "attn_sample: needs GroupNorm(1) statistics of x");
     if (!a.out || !a.part || !a.bout) return fail(FC_E_ARG, "attn_sample: to_out parameters / scratch / output missing");
+    if (a.tickets && !linattn_sample_one_launch(a.n, a.C)) return fail(FC_E_SHAPE, "attn_sample: sample too large for the one-launch form");
     launch_pair<true>(a, s);
     FC_HIP(hipGetLastError());
     return FC_OK;

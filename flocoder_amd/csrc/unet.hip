@@ -257,7 +257,17 @@ struct Builder : PlanBuilder {
         return out;
     }
 
-    // the whole module in two launches (linattn_sample.hip)
+    // arrival counters of the one-launch form of linattn_sample.hip (zeroed here, once: every launch adds `heads` per sample), or null:
+    // FLOCODER_AMD_LA_JOIN=separate keeps the closing step in a launch of its own (la_join)
+    unsigned* la_tickets(int n, int C) {
+        static const bool separate = [] { const char* e = std::getenv("FLOCODER_AMD_LA_JOIN"); return e && std::string(e) == "separate"; }();
+        if (separate || !linattn_sample_one_launch(n, C) || err) return nullptr;
+        unsigned* t = reinterpret_cast<unsigned*>(dmalloc((size_t)B));
+        if (t && hipMemset(t, 0, (size_t)B * sizeof(unsigned)) != hipSuccess) { err = fail(FC_E_HIP, "hipMemset failed on the attention tickets"); return nullptr; }
+        return t;
+    }
+
+    // the whole module in one launch, or two (linattn_sample.hip)
     Act linattn_sample(const std::string& p, const Act& x, const Stat& gn1) {
         const int n = x.H * x.W, heads = u->heads, hid = heads * 32;
         Act out = act(x.C, x.H, x.W);
@@ -267,6 +277,7 @@ struct Builder : PlanBuilder {
         a.g2 = u->R(p + ".fn.fn.to_out.1.weight"); a.b2 = u->R(p + ".fn.fn.to_out.1.bias"); a.out = out.p;
         a.n = n; a.C = x.C; a.heads = heads;
         a.part = dmalloc((size_t)B * heads * n * x.C);
+        a.tickets = la_tickets(n, x.C);
         const double fl = 2.0 * n * (double)x.C * 3 * hid + 2.0 * 2 * n * 32 * 32 * heads + 2.0 * n * (double)hid * x.C;
         if (!err) push([a](const FwdCtx& c, hipStream_t s) { LaArgs b = a; b.B = c.B; return linattn_sample_launch(b, s); }, "linattn_sample", fl);
         pl->named[p] = out;
@@ -285,6 +296,7 @@ struct Builder : PlanBuilder {
             a.wqkv = u->P("mid_attn.fn.fn.to_qkv.weight"); a.wout = u->P("mid_attn.fn.fn.to_out.weight"); a.bout = u->R("mid_attn.fn.fn.to_out.bias");
             a.out = out.p; a.n = n; a.C = x.C; a.heads = heads;
             a.part = dmalloc((size_t)B * heads * n * x.C);
+            a.tickets = la_tickets(n, x.C);
             const double fl = 2.0 * n * (double)x.C * 3 * hid + 2.0 * 2.0 * n * n * 32 * heads + 2.0 * n * (double)hid * x.C;
             if (!err) push([a](const FwdCtx& c, hipStream_t s) { LaArgs b = a; b.B = c.B; return attn_sample_launch(b, s); }, "attn_sample", fl);
             pl->named["mid_attn"] = out;
