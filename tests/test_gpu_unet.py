@@ -207,3 +207,44 @@ def _fused_tail_body(Unet):
     ref = fo.unet_forward(sd, x[:8], t[:8], {"class_cond": ids[:8]})
     assert rel_l2(v[:8].cpu(), ref) < FWD_TOL
     assert m.fused_tail_errors() == 0
+
+
+_LA_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from flocoder_amd.unet import Unet
+from flocoder_amd.sampling import euler_sampler
+torch.manual_seed(21)
+m = Unet(dim=32, dim_mults=(1, 2, 4, 8), channels=4, n_classes=102).eval().to("cuda:0")
+g = torch.Generator().manual_seed(22)
+x = torch.randn(12, 4, 32, 32, generator=g).to("cuda:0"); ids = torch.randint(102, (12,), generator=g).to("cuda:0")
+t = torch.full((12,), 420.0, device="cuda:0")
+with torch.no_grad():
+    v = m(x, t, {"class_cond": ids}).clone()
+    v2 = m(x, t, {"class_cond": ids}).clone()          # the arrival counters only grow: a second launch must close its modules too
+lat = euler_sampler(m, (12, 4, 32, 32), 5, cond=ids, source=x)[0]
+torch.save((v.cpu(), v2.cpu(), lat.cpu(), m.launches_per_forward), sys.argv[1])
+"""
+
+
+def test_low_resolution_attention_in_one_launch_equals_the_two_launch_form(tmp_path):
+    """linattn_sample.hip (round 3): at n <= 64 the workgroup of a sample that arrives last adds the heads' shares of to_out.0, applies
+    to_out.1's GroupNorm(1) and the residual (unet.py:125-161,250; the bottleneck Attention, unet.py:99-122, has no norm) -- one launch per
+    module instead of la_head + la_join.  FLOCODER_AMD_LA_JOIN=separate keeps the second launch.  Same arithmetic in the same order except
+    the statistics' block reduction (256 threads instead of 512): equal to fp32 rounding, and repeatable (the arrival counters only grow)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, env in (("one", {}), ("two", {"FLOCODER_AMD_LA_JOIN": "separate"})):
+        f = str(tmp_path / (tag + ".pt"))
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", _LA_SCRIPT % root, f], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = torch.load(f)
+    v, v2, lat, _ = outs["one"]
+    w, w2, lat2, _ = outs["two"]
+    assert torch.isfinite(v).all() and torch.isfinite(lat).all()
+    assert torch.equal(v, v2) and torch.equal(w, w2)
+    assert rel_l2(v, w) < 1e-6 and rel_l2(lat, lat2) < 1e-5
