@@ -1,5 +1,8 @@
+"""Codecs in fp32 and in the opt-in split-bf16 form, alternating on one box: SD-VAE decode / encode at B=64 in chunks of 16, the
+per-kernel table of the split-bf16 decode plan, VQVAE (midi_vqgan shape) encode / decode with the rel-L2 of the split-bf16 results
+(profiles/r03_split_bf16.txt)."""
 import os, sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from flocoder_amd.codecs import SD_VAE_Wrapper, VQVAE
 from flocoder_amd.sampling import decode_latents
@@ -13,7 +16,7 @@ for mode in ("fp32", "bf16x3", "fp32", "bf16x3"):
     te, lat = bench._gpu_time(lambda: torch.cat([vae.encode(img[i:i + 16]) for i in range(0, 64, 16)]), dev, 2)
     print(mode, "decode %.1f ms = %.1f images/s; encode %.1f images/s" % (t * 1e3, 64 / t, 64 / te), flush=True)
 vae.set_precision("bf16x3")
-rows = vae.profile_ops(z[:16].contiguous(), img[:16].contiguous(), decode=True, repeats=3)
+rows = vae.profile_ops(z[:16].contiguous(), torch.empty_like(img[:16]), decode=True, repeats=3)
 by = bench._by_kernel(rows)
 for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"]):
     print("  %-28s %8.3f ms %3d launches %7.1f TFLOP/s(equiv)" % (k, v["ms"], v["launches"], v["flops"] / max(v["ms"], 1e-9) / 1e9))

@@ -1,6 +1,6 @@
 """Split-bf16 against fp32, layer by layer (conv_debug) and for the whole SD-VAE decode at the bench's batch: rel-L2 of every case."""
-import sys, torch
-sys.path.insert(0, "/root/repo")
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from flocoder_amd._ops import conv_debug
 from flocoder_amd.codecs import SD_VAE_Wrapper
 from flocoder_amd.sampling import decode_latents

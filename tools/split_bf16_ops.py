@@ -1,6 +1,6 @@
 """Per-launch table of the SD-VAE decode plan (16 latents) in fp32 and in split-bf16: where does the 3-MFMA form fall short of 3x?"""
-import sys, torch
-sys.path.insert(0, "/root/repo")
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from flocoder_amd.codecs import SD_VAE_Wrapper
 from flocoder_amd.sampling import decode_latents
@@ -12,7 +12,7 @@ tabs = {}
 for mode in ("fp32", "bf16x3"):
     vae.set_precision(mode)
     img = decode_latents(vae, z, chunk_size=16)
-    tabs[mode] = vae.profile_ops(z, img, decode=True, repeats=5)
+    tabs[mode] = vae.profile_ops(z, torch.empty_like(img), decode=True, repeats=5)
 print("%-3s %-26s %-34s %9s %9s %6s %8s" % ("#", "kernel", "module", "fp32 ms", "bf16x3 ms", "x", "TF equiv"))
 for i, (a, b) in enumerate(zip(tabs["fp32"], tabs["bf16x3"])):
     fl = b["flops_per_sample"] * b["rows"]
