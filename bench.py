@@ -64,6 +64,9 @@ def synthetic_inputs(rank, world, device, per_rank=BATCH):
 PEAK_HBM_GBS = 8000.0             # same guide, HBM3E
 
 
+TWO_KERNEL_ENTRIES = 4 + (5 if os.environ.get("FLOCODER_AMD_LA_JOIN") == "separate" else 0)   # attention plan entries that are two kernels
+
+
 def pmc_traffic(kernel, pattern="*pmc_traffic.json"):
     """HBM bytes per launch of `kernel` from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
     tools/pmc_forward.py or tools/pmc_codec.py, summarised by tools/pmc_summary.py with the guide's gfx950 correction).  A process
@@ -542,11 +545,12 @@ def main():
                                "dim_mults [1,2,4,8] n_classes=102, class-conditional, no CFG, ODE loop only (no VAE decode)",
                    "global_batch": BATCH * world, "nfe_per_sample": N_EULER, "parallelism": f"sample-shard x{world}, weights broadcast once",
                    "gflop_per_sample": round(model.flops_per_sample * N_EULER / 1e9, 3),
-                   # plan entries of one forward; the nine attention entries are two kernels each, and inside the integrator the two
-                   # conditioning entries are replaced by a table computed once per call
+                   # plan entries of one forward; the four high-resolution attention entries are two kernels each (the five
+                   # low-resolution ones too under FLOCODER_AMD_LA_JOIN=separate), and inside the integrator the two conditioning
+                   # entries are replaced by a table computed once per call
                    "plan_entries_per_forward": model.launches_per_forward,
-                   "kernel_launches_per_forward": model.launches_per_forward + 9,
-                   "kernel_launches_per_euler_step": model.launches_per_forward + 9 - 2,
+                   "kernel_launches_per_forward": model.launches_per_forward + TWO_KERNEL_ENTRIES,
+                   "kernel_launches_per_euler_step": model.launches_per_forward + TWO_KERNEL_ENTRIES - 2,
                    "plan": "exclusive device (cross-workgroup Block tails)" if model.meeting_launches else "shared device (no cross-workgroup waits)",
                    "runtime_env": {k: os.environ.get(k) for k in ("AMD_DIRECT_DISPATCH", "FLOCODER_AMD_KEEP_ENV") if os.environ.get(k) is not None}},
     }
