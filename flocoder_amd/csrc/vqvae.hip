@@ -176,6 +176,16 @@ struct QBuilder : PlanBuilder {
             release(qkv); release(att); release(a1);
             mid_in = a2; mid_raw = true;
         }
+        // (round 3) without an attention in between, the activated tensor is materialised as well instead of being normalised in conv2's staging
+        // waves once per output-channel tile and halo copy (vae.hip prenorm_src has the measurements); FLOCODER_AMD_VAE_PRENORM=fused: as before
+        static const bool fused_prenorm = [] { const char* e = std::getenv("FLOCODER_AMD_VAE_PRENORM"); return e && std::string(e) == "fused"; }();
+        if (!mid_raw && !fused_prenorm && !err) {
+            Act a1 = act(co, Ho, Wo);
+            FinalizeArgs f;
+            f.h = h1.p; f.xf = mid_xf; f.y = a1.p; f.HW = Ho * Wo; f.C = co;
+            push([f](const FwdCtx& c, hipStream_t s) { FinalizeArgs g = f; g.B = c.B; return finalize_launch(g, s); }, "finalize");
+            mid_in = a1; mid_raw = true;
+        }
         Act h2 = act(co, Ho, Wo);
         ConvArgs b;
         b.s0.p = mid_in.p; b.s0.C = co;
