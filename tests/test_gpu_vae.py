@@ -87,3 +87,42 @@ def test_split_bf16_decode_is_within_the_image_gate_and_opt_in():
     assert rel_l2(ze, w.encode(exact)) < 2e-4
     with pytest.raises(ValueError):
         w.set_precision("fp16")
+
+
+_PRENORM_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from flocoder_amd.codecs import SD_VAE_Wrapper, VQVAE
+w = SD_VAE_Wrapper(weights="random", seed=7).eval().to("cuda:0")
+g = torch.Generator().manual_seed(14)
+z = (torch.randn(2, 4, 32, 32, generator=g) * 4.5).to("cuda:0")
+img = w.decode(z)
+lat = w.encode(img)
+torch.manual_seed(5)
+vq = VQVAE(in_channels=3, hidden_channels=64, num_downsamples=2, internal_dim=32, vq_embedding_dim=4, codebook_levels=2, vq_num_embeddings=32).eval().to("cuda:0")
+x = torch.rand(3, 3, 64, 64, generator=g).to("cuda:0")
+ze = vq.encode(x)
+torch.save((img.cpu(), lat.cpu(), ze.cpu(), vq.decode(ze).cpu(), len(w.plan_ops(True))), sys.argv[1])
+"""
+
+
+def test_materialised_prenorm_equals_the_in_loader_form(tmp_path):
+    """Round 3: the codecs' resnet convolutions read SiLU(GN(x)) written by one elementwise launch (vae.hip prenorm_src, vqvae.hip block)
+    instead of normalising in the convolution's staging waves; FLOCODER_AMD_VAE_PRENORM=fused keeps the form of rounds 1-2.  Same
+    arithmetic per element (GroupNorm affine, SiLU), so decode / encode of both codecs agree to fp32 rounding (measured: bit for bit) (AutoencoderKL resnets: codecs.py:631-652; EncDecResidualBlock: codecs.py:150-214)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, env in (("materialised", {}), ("fused", {"FLOCODER_AMD_VAE_PRENORM": "fused"})):
+        f = str(tmp_path / (tag + ".pt"))
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", _PRENORM_SCRIPT % root, f], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = torch.load(f)
+    assert outs["materialised"][4] > outs["fused"][4], "the switch must change the plan: one elementwise launch per pre-norm convolution"
+    for a, b, what in zip(outs["materialised"][:4], outs["fused"][:4], ("SD-VAE decode", "SD-VAE encode", "VQVAE encode", "VQVAE decode")):
+        e = rel_l2(a, b)
+        print("%s, materialised vs in-loader pre-norm: rel-L2 %.2e" % (what, e))
+        assert torch.isfinite(a).all() and e < 2e-6, what
