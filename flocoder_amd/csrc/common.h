@@ -101,6 +101,15 @@ struct ConvArgs {
     const float* w4 = nullptr;
     const float* res_w4 = nullptr;
     const float* w_b3 = nullptr;   // the weights as split bf16 (pack kind 8) or null: needed by prec == 1
+    // One parity class of "nearest x2 upsampling + 3x3" as a 2x2 convolution on the low-resolution input (pack kinds 9 / 10): the window
+    // starts pad_y / pad_x above / left of the output pixel (-1: `pad` for both) and output pixel (y, x) of this launch's H x W grid is
+    // pixel (2y + out_oy, 2x + out_ox) of a 2H x 2W image when out_sh = 1; its GroupNorm partials go to slot stats_toff of stats_tmul
+    // launches that share one statistics tensor.
+    int pad_y = -1, pad_x = -1;
+    int out_sh = 0, out_oy = 0, out_ox = 0;
+    int stats_tmul = 1, stats_toff = 0;
+    int par4 = 0;              // 1: ONE launch carries the four parity classes (quarter q of the grid = class q): w points at [4][4 taps][Cin][Cout]
+                               // (w_b3 likewise) and pad_y / pad_x / out_oy / out_ox / stats_toff are derived per workgroup (out_sh = 1, stats_tmul = 4)
     int prec = 0;              // 1: split-bf16 arithmetic where the tile has that form (codec decoders on request; 0 = exact fp32, always for the U-Net)
     ConvFin fin;
 };

@@ -60,6 +60,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
+// ConvArgs::par4: the quarter of the (remapped) grid a workgroup falls into is its parity class; returns the id inside that quarter
+__device__ __forceinline__ int conv_parity_select(ConvDev& p, int bid) {
+    if (!p.a.par4) return bid;
+    const int nb1 = p.nblocks >> 2, par = bid >= 2 * nb1 ? (bid >= 3 * nb1 ? 3 : 2) : (bid >= nb1 ? 1 : 0);
+    p.a.w += (size_t)par * 4 * p.a.Cin * p.a.Cout;
+    if (p.a.w_b3) p.a.w_b3 += (size_t)par * 4 * (16 * p.nchunks) * p.a.Cout;      // 4 taps x Ipad x Cout floats per class (hi + lo halves)
+    p.a.pad_y = 1 - (par >> 1); p.a.pad_x = 1 - (par & 1);
+    p.a.out_oy = par >> 1; p.a.out_ox = par & 1;
+    p.a.stats_toff = par;
+    return bid - par * nb1;
+}
 
 
 // The kernel's parameter block, read through the VECTOR memory path: every lane loads one dword of the kernarg segment (three
@@ -173,7 +184,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
         const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         const int tw = m & (TW - 1), th = (m >> p.TWl) & (TH - 1), tb = m >> (p.TWl + p.THl);
         const int b = b0 + tb;
-        return b < a.B ? (b * a.H + y0 + th) * a.W + x0 + tw : -1;
+        return b < a.B ? (b * (a.H << a.out_sh) + ((y0 + th) << a.out_sh) + a.out_oy) * (a.W << a.out_sh) + ((x0 + tw) << a.out_sh) + a.out_ox : -1;
     };
     if (FL & FL_STAMP) conv_stamp(p, 6);
     const bool owner = active && (wk == 0);
@@ -221,7 +232,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
         const int nsub = (cpg >= BN) ? (n0 % cpg) / BN : 0;
         const int msub = (p.TB > 1) ? 0 : ty * p.tiles_x + tx;
         const int T = (p.TB > 1 ? 1 : p.tiles_x * p.tiles_y) * NPG;
-        float* d = dst + ((size_t)(b * G + g) * T + msub * NPG + nsub) * 2;
+        float* d = dst + (((size_t)(b * G + g) * a.stats_tmul + a.stats_toff) * T + msub * NPG + nsub) * 2;
         if (ltab_on) {    // the tile holds the whole group: (mean, rstd) for the tail below, no trip through memory
             float* ltab = smem + p.o_fin;
             const int ngt = cpg >= BN ? 1 : BN / cpg;
@@ -571,7 +582,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                 const int b = b0 + tb;
                 if (b < a.B && n < Cout) {
                     const float4 v = *reinterpret_cast<const float4*>(ot + m * OS + c4);
-                    *reinterpret_cast<float4*>(gout + (size_t)((b * a.H + y0 + th) * a.W + x0 + tw) * Cout + n) = v;
+                    *reinterpret_cast<float4*>(gout + (size_t)((b * (a.H << a.out_sh) + ((y0 + th) << a.out_sh) + a.out_oy) * (a.W << a.out_sh) + ((x0 + tw) << a.out_sh) + a.out_ox) * Cout + n) = v;
                 }
             }
         }

@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvDev p) {
         const int Hin = a.Hs << a.ups, Win = a.Ws << a.ups;
         for (int i = tid; i < p.P; i += 256) {
             const int tb = i / PHW, r = i - tb * PHW, py = r / PW, px = r - py * PW;
-            const int iy = y0 * a.stride - a.pad + py, ix = x0 * a.stride - a.pad + px, b = b0 + tb;
+            const int iy = y0 * a.stride - (a.pad_y >= 0 ? a.pad_y : a.pad) + py, ix = x0 * a.stride - (a.pad_x >= 0 ? a.pad_x : a.pad) + px, b = b0 + tb;
             int off = -1;
             if (b < a.B && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) off = (b * a.Hs + (iy >> a.ups)) * a.Ws + (ix >> a.ups);
             pixoff[i] = off;
@@ -270,6 +270,10 @@ static int conv_geometry(const ConvArgs& a, int tile, bool pipe, ConvDev* d, Con
     if (a.ups && a.stride != 1) return fail(FC_E_SHAPE, "conv: upsample needs stride 1");
     if (a.res_out && (a.s0.xf.mode || a.s1.xf.mode)) return fail(FC_E_ARG, "conv: fused res needs untransformed input");
     if (a.res_out && (a.pad >= a.KS)) return fail(FC_E_ARG, "conv: fused res needs a centre tap");
+    if ((a.out_sh || a.pad_y >= 0 || a.pad_x >= 0) && (a.res_out || a.fin.gamma || a.stride != 1 || a.ups || a.out_sh > 1 || a.out_oy >> a.out_sh || a.out_ox >> a.out_sh))
+        return fail(FC_E_ARG, "conv: the parity form (pad_y / pad_x / out_sh) is a plain stride-1 convolution");
+    if (a.stats_tmul < 1 || a.stats_toff < 0 || a.stats_toff >= a.stats_tmul) return fail(FC_E_ARG, "conv: bad statistics slot");
+    if (a.par4 && (a.KS != 2 || a.out_sh != 1 || a.stats_tmul != 4 || a.w_batch_stride || a.w4)) return fail(FC_E_ARG, "conv: par4 is the four-class form of a folded upsampling (2x2 taps, out_sh 1)");
     const int TW = a.W < 16 ? a.W : 16;
     int TH = t.BM / TW;
     if (TH > a.H) TH = a.H;
@@ -286,7 +290,7 @@ static int conv_geometry(const ConvArgs& a, int tile, bool pipe, ConvDev* d, Con
     p.magic_pw = p.PW > 1 ? (unsigned)((1ull << 32) / (unsigned)p.PW) + 1u : 0u;
     p.tiles_x = a.W / TW; p.tiles_y = a.H / TH;
     p.ntiles = cdiv(a.Cout, t.BN);
-    p.nblocks = cdiv(a.B, TB) * p.tiles_x * p.tiles_y * p.ntiles;
+    p.nblocks = cdiv(a.B, TB) * p.tiles_x * p.tiles_y * p.ntiles * (a.par4 ? 4 : 1);
     p.txl = ilog2(p.tiles_x); p.tyl = ilog2(p.tiles_y);
     p.magic_nt = (p.ntiles > 1 && p.nblocks < 65536) ? (unsigned)((1ull << 32) / (unsigned)p.ntiles) + 1u : 0u;   // exact for x < 2^16
     p.loader_prio = 0; p.o_epoch = p.o_gran = 0; p.o_out = -1; p.bf3 = 0;
@@ -320,7 +324,7 @@ static int conv_geometry(const ConvArgs& a, int tile, bool pipe, ConvDev* d, Con
         const bool direct_b = (t.WMWN == 1 && t.MTNT == 1 && a.KS == 3);
         // split-bf16 form (ConvArgs::prec): the three codec tiles at 1x1 / 3x3, plain launches only (no fused res_conv / tail, shared weights)
         // whose weights exist pre-split (ConvArgs::w_b3, pack kind 8)
-        p.bf3 = (a.prec == 1 && a.w_b3 && (tile == TILE_M128N32 || tile == TILE_M128N64 || tile == TILE_M256N64) && (a.KS == 1 || a.KS == 3) && !a.res_out &&
+        p.bf3 = (a.prec == 1 && a.w_b3 && (tile == TILE_M128N32 || tile == TILE_M128N64 || tile == TILE_M256N64) && (a.KS == 1 || a.KS == 2 || a.KS == 3) && !a.res_out &&
                  !a.fin.gamma && !a.w_batch_stride) ? 1 : 0;
         p.patch_stride = align4(p.P * (t.CC + ((direct_b || p.bf3) ? 4 : 1)));    // (its k-step-quad form strides pixels by CC + 4 floats, and so does split-bf16)
         p.o_wl = o + 2 * p.patch_stride;

@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
     const int half = lane >> 5, l31 = lane & 31;
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
 
-    const int bid = xcd_remap(blockIdx.x, p.nblocks);
+    const int bid = conv_parity_select(p, xcd_remap(blockIdx.x, p.nblocks));
     // tile decode without integer division: tiles_x / tiles_y are powers of two, ntiles goes through a host-made reciprocal
     const int mt_i = p.ntiles == 1 ? bid : (p.magic_nt ? (int)__umulhi((unsigned)bid, p.magic_nt) : bid / p.ntiles);
     const int nt_i = bid - mt_i * p.ntiles;
@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
                 e_po[k] = -1; e_lds[k] = -1; e_tb[k] = 0;
                 if (pix < p.P) {
                     const int tb = fastdiv(pix, p.magic_phw), r = pix - tb * PHW, py = fastdiv(r, p.magic_pw), px = r - py * PW;
-                    const int iy = y0 * a.stride - a.pad + py, ix = x0 * a.stride - a.pad + px, b = b0 + tb;
+                    const int iy = y0 * a.stride - (a.pad_y >= 0 ? a.pad_y : a.pad) + py, ix = x0 * a.stride - (a.pad_x >= 0 ? a.pad_x : a.pad) + px, b = b0 + tb;
                     if (b < a.B && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) e_po[k] = (b * a.Hs + (iy >> a.ups)) * a.Ws + (ix >> a.ups);
                     e_lds[k] = pix * CS + (DB4 ? 8 * ((ltid % Q) >> 1) + 2 * ((ltid % Q) & 1) : q4);
                     e_tb[k] = tb;
@@ -798,6 +798,7 @@ int conv_pipe_init() {
     static bool done = false;
     if (done) return FC_OK;
     FC_TRY(bf3_attr_ks<1>());
+    FC_TRY(bf3_attr_ks<2>());
     FC_TRY(bf3_attr_ks<3>());
     FC_HIP(hipMalloc(reinterpret_cast<void**>(&g_zeros16), 256));
     FC_HIP(hipMemset(g_zeros16, 0, 256));
@@ -830,7 +831,7 @@ static int pipe_launch_ks(const ConvDev& d, int tile, int grid, size_t lds, hipS
 }
 
 static int conv_pipe_dispatch(const ConvDev& d, int tile, int grid, size_t lds, hipStream_t s, int* occ) {
-    if (d.bf3) return d.a.KS == 1 ? bf3_launch_ks<1>(d, tile, grid, lds, s, occ) : bf3_launch_ks<3>(d, tile, grid, lds, s, occ);
+    if (d.bf3) return d.a.KS == 1 ? bf3_launch_ks<1>(d, tile, grid, lds, s, occ) : d.a.KS == 2 ? bf3_launch_ks<2>(d, tile, grid, lds, s, occ) : bf3_launch_ks<3>(d, tile, grid, lds, s, occ);
     static const bool lean = [] { const char* e = std::getenv("FLOCODER_AMD_LEAN_KERNELS"); return !(e && std::string(e) == "0"); }();
     if (lean) {                  // the smallest flavour that covers this launch
         const bool small_tile = tile == TILE_M32N32K4;

@@ -120,6 +120,37 @@ __global__ void __launch_bounds__(256) pack_table_kernel(const PackJob* jobs, co
                 d16[t] = hi;
                 d16[(size_t)j.a * j.d * j.c + t] = (unsigned short)(v >> 16);
                 break; }
+            case 9: case 10: {
+                // nearest x2 upsampling folded into the weights of a 3x3 convolution (SD-VAE Upsample2D): output pixel (2y + a, 2x + b) reads
+                // the low-resolution pixels of a 2x2 window whose position depends on its parity (a, b), each through the SUM of the 3x3
+                // taps that land on it -- rows {ky} for ty: a = 0: {0}, {1, 2}; a = 1: {0, 1}, {2}; columns likewise.  Four 2x2 kernels,
+                // 16 taps instead of 36 per 2x2 output block.  a=O b=I c=9 d=Ipad (kind 10).
+                // kind 9: [parity][tap = 2 ty + tx][I][O] fp32; kind 10: per parity the split-bf16 form of kind 8 with KK = 4
+                const bool b3 = j.kind == 10;
+                const size_t per = b3 ? (size_t)4 * j.d * j.a : (size_t)4 * j.b * j.a;     // elements of one parity (one part)
+                const int par = (int)(t / per); const size_t e = t - (size_t)par * per;
+                int o, ci, tap;
+                if (b3) { const int jj = (int)(e & 7); size_t r = e >> 3; o = (int)(r % j.a); r /= j.a; const int c8 = (int)(r % (j.d / 8)); tap = (int)(r / (j.d / 8)); ci = 8 * c8 + jj; }
+                else { o = (int)(e % j.a); const size_t r = e / j.a; ci = (int)(r % j.b); tap = (int)(r / j.b); }
+                const int pa = par >> 1, pb = par & 1, ty = tap >> 1, tx = tap & 1;
+                const int ky0 = pa == 0 ? (ty == 0 ? 0 : 1) : (ty == 0 ? 0 : 2), ky1 = pa == 0 ? (ty == 0 ? 0 : 2) : (ty == 0 ? 1 : 2);
+                const int kx0 = pb == 0 ? (tx == 0 ? 0 : 1) : (tx == 0 ? 0 : 2), kx1 = pb == 0 ? (tx == 0 ? 0 : 2) : (tx == 0 ? 1 : 2);
+                float x = 0.f;
+                if (ci < j.b) {
+                    const float* w = src + ((size_t)o * j.b + ci) * 9;
+                    for (int ky = ky0; ky <= ky1; ++ky)
+                        for (int kx = kx0; kx <= kx1; ++kx) x += w[ky * 3 + kx];
+                }
+                if (!b3) { dst[t] = x; break; }
+                unsigned u = __float_as_uint(x);
+                u += 0x7fffu + ((u >> 16) & 1u);
+                const unsigned short hi = (unsigned short)(u >> 16);
+                unsigned v = __float_as_uint(x - __uint_as_float((unsigned)hi << 16));
+                v += 0x7fffu + ((v >> 16) & 1u);
+                unsigned short* d16 = reinterpret_cast<unsigned short*>(dst) + (size_t)par * 2 * per;
+                d16[e] = hi;
+                d16[per + e] = (unsigned short)(v >> 16);
+                break; }
             default: { const int KK = j.c * j.c; const int i = (int)(t % j.e); const size_t r = t / j.e; const int o = (int)(r % j.a), tap = (int)(r / j.a);
                        const int ky = j.c - 1 - tap / j.c, kx = j.c - 1 - tap % j.c;
                        dst[t] = src[((size_t)o * j.b + j.d + i) * KK + ky * j.c + kx]; break; }
@@ -136,6 +167,8 @@ size_t pack_job_total(const PackJob& j) {
         case 4: return (size_t)j.d * j.e * j.c;
         case 6: return (size_t)j.a * j.b * j.c;
         case 8: return (size_t)j.a * j.d * j.c;
+        case 9: return (size_t)16 * j.a * j.b;
+        case 10: return (size_t)16 * j.a * j.d;
         default: return (size_t)j.a * j.e * j.c * j.c;
     }
 }

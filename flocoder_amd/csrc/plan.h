@@ -57,7 +57,8 @@ struct Plan {                 // one launch plan + activation arena for up to ma
     std::vector<double> op_flops;                  // algorithmic FLOPs per sample of that launch
     std::vector<double> op_bytes_ps, op_bytes_fixed;   // algorithmic HBM bytes of that launch: per sample (activations in + out, each once) and per launch (weights); 0 = not stated
     std::vector<void*> allocs;
-    double flops = 0.0;
+    double flops = 0.0;            // per sample, the reference's arithmetic (2 x MACs of every module as upstream computes it)
+    double flops_executed = 0.0;   // per sample, what the launches execute (less where upsampling is folded into the weights)
     float *t_emb = nullptr, *ss = nullptr;
     std::map<std::string, Act> named;              // debug taps: block outputs by reference module name
     std::vector<ResRec> res; std::vector<LinRec> lin; std::vector<MidRec> mid; std::vector<ConvRec> convs; std::vector<InjRec> inj;
@@ -136,6 +137,22 @@ struct ParamStore {
             packops.push_back({6, params[pidx[n + ".weight"]].offset, d8, O, I, K * K, 0});
         }
     }
+    // a 3x3 convolution behind nn.Upsample(nearest, x2): besides the plain packed copy, the four parity kernels of the folded form (pack kinds 9 / 10)
+    void decl_conv_up2(const std::string& n, int O, int I) {
+        decl_conv(n, O, I, 3);
+        const int64_t d4 = pk_alloc(n + ".weight#up4", (int64_t)16 * O * I);
+        packops.push_back({9, params[pidx[n + ".weight"]].offset, d4, O, I, 9, 0});
+        if (want_b3) {
+            const int Ipad = (I + 15) / 16 * 16;
+            const int64_t d3 = pk_alloc(n + ".weight#up4b3", (int64_t)16 * O * Ipad);
+            packops.push_back({10, params[pidx[n + ".weight"]].offset, d3, O, I, 9, Ipad});
+            for (int par = 0; par < 4; ++par) b3_of[d4 + (int64_t)par * 4 * O * I] = d3 + (int64_t)par * 4 * O * Ipad;
+        }
+    }
+    const float* PUP(const std::string& n) const {     // [parity][4 taps][I][O], or null when the layer was not declared with decl_conv_up2
+        auto it = pk.find(n + "#up4");
+        return it == pk.end() ? nullptr : packed + it->second;
+    }
     void decl_linear_t(const std::string& n, int O, int I) {  // stored transposed [I][O]
         declare(n + ".weight", {O, I});
         declare(n + ".bias", {O});
@@ -206,7 +223,9 @@ struct PlanBuilder {
 
     // guard: 0 always | 1 only when the call has a mask | 2 only when it runs mask_fusion_conv | 3 only when it has NO mask | 4 mask but no fusion
     int guard = 0;
-    void push(Op op, const std::string& kernel, double flops = 0.0, double bytes_ps = 0.0, double bytes_fixed = 0.0) {
+    // flops: what the launch executes per sample (per-launch tables, rooflines); flops_ref (> 0): what the reference's arithmetic for the same
+    // module is, when that differs (folded upsampling) -- Plan::flops, the per-sample figure of SURVEY 8(d), adds up the reference's
+    void push(Op op, const std::string& kernel, double flops = 0.0, double bytes_ps = 0.0, double bytes_fixed = 0.0, double flops_ref = 0.0) {
         if (guard) {
             const int g = guard;
             Op inner = std::move(op);
@@ -221,7 +240,8 @@ struct PlanBuilder {
         pl->op_flops.push_back(flops);
         pl->op_bytes_ps.push_back(bytes_ps);
         pl->op_bytes_fixed.push_back(bytes_fixed);
-        pl->flops += flops;
+        pl->flops += flops_ref > 0.0 ? flops_ref : flops;
+        pl->flops_executed += flops;
     }
     float* dmalloc(size_t floats) {
         void* p = nullptr;
@@ -297,6 +317,43 @@ struct PlanBuilder {
             float* sp = st->p; const float* xp = out.p; const int HW = out.H * out.W, C = out.C, G = want_G;
             push([=](const FwdCtx& c, hipStream_t s) { return gn_stats_launch(xp, sp, c.B, HW, C, G, s); }, "gn_stats");
         }
+    }
+
+    // nn.Upsample(nearest, x2) + 3x3 convolution as four 2x2 convolutions on the low-resolution input, one per output parity, with the taps
+    // that fall on the same source pixel summed at pack time (ParamStore::decl_conv_up2): 16 instead of 36 multiply-adds per 2x2 output
+    // block and channel pair -- exact in real arithmetic, a different summation order in fp32.  One launch carries the four classes
+    // (ConvArgs::par4).  `w4` = PUP(name); x low resolution, out 2x.  Returns false, emitting nothing, when the shape is not covered
+    // (the caller then emits the 3x3 convolution over the upsampled window).
+    bool conv_up2(const ConvSrc& src, const Act& x, const float* w4, const float* bias, const Act& out, int want_G, Stat* st) {
+        if (err || !w4) return false;
+        static const bool no_fold = [] { const char* e = std::getenv("FLOCODER_AMD_UPS_FOLD"); return e && std::string(e) == "0"; }();
+        if (no_fold || (want_G > 0 && (x.H * x.W) % 16 != 0)) return false;
+        ConvArgs a;
+        a.s0 = src; a.Hs = x.H; a.Ws = x.W; a.KS = 2; a.pad = 0; a.stride = 1;
+        a.B = B; a.H = x.H; a.W = x.W; a.Cout = out.C; a.out = out.p; a.bias = bias;
+        a.Cin = a.s0.C;
+        a.prec = conv_prec;
+        a.w = w4;
+        if (conv_prec && store) a.w_b3 = store->B3(w4);
+        a.par4 = 1; a.out_sh = 1; a.stats_tmul = 4; a.pad_y = 1; a.pad_x = 1;
+        const bool fused = want_G > 0;
+        ConvGeom g;
+        if (fused) { a.Gout = want_G; a.stats_out = reinterpret_cast<float*>(1); }
+        if (conv_plan(a, TILE_AUTO, &g) != FC_OK || !g.pipe) return false;
+        if (fused) { *st = stat(want_G, 4 * g.T, g.n_t); a.stats_out = st->p; }
+        const int tile = g.tile;
+        const double fl = 2.0 * out.H * out.W * 4.0 * (double)a.Cin * a.Cout;      // four taps per OUTPUT pixel
+        push([a, tile](const FwdCtx& c, hipStream_t s) { ConvArgs b = a; b.B = c.B; return conv_launch(b, tile, s); }, kTileNames[tile], fl,
+             4.0 * ((double)x.H * x.W * a.Cin + (double)out.H * out.W * a.Cout), 4.0 * 16.0 * a.Cin * a.Cout,
+             2.0 * out.H * out.W * 9.0 * (double)a.Cin * a.Cout);
+        if (fused && st->T > 16) {
+            const Stat raw = *st;
+            *st = stat(want_G, 1, raw.n_t * (float)raw.T);
+            const float* ip = raw.p; float* op = st->p;
+            const int G = want_G, T = raw.T; const float nt = raw.n_t;
+            push([=](const FwdCtx& c, hipStream_t s) { return gn_fold_launch(ip, op, c.B, G, T, nt, s); }, "gn_fold");
+        }
+        return true;
     }
 
     // A convolution whose epilogue finishes the Block: out = SiLU(GroupNorm(conv)) + res, the GroupNorm statistics exchanged between

@@ -98,7 +98,8 @@ static int declare_all(fc_unet* u) {
         decl_resblock(u, p + ".0", dout + din, dout);
         decl_resblock(u, p + ".1", dout + din, dout);
         decl_linattn(u, p + ".2", dout);
-        decl_conv(u, i == L - 1 ? p + ".3" : p + ".3.1", din, dout, 3);
+        if (i == L - 1) decl_conv(u, p + ".3", din, dout, 3);
+        else u->decl_conv_up2(p + ".3.1", din, dout);      // Upsample: also the four parity kernels of the folded form (plan.h conv_up2)
     }
     const int mid = cs[L];
     decl_resblock(u, "mid_block1", mid, mid);
@@ -534,9 +535,13 @@ static int build_plan(fc_unet* u, Plan* pl, int maxB, int H, int W) {
             pl->convs.push_back({p + ".3", x, o, 3, 1, 1, 0});
             x = o;
         } else {  // nn.Upsample(nearest x2) folded into the conv's loader (unet.py:42-46)
-            a.ups = 1; a.w = u->P(p + ".3.1.weight"); a.bias = u->R(p + ".3.1.bias"); a.w4 = u->P8(p + ".3.1.weight");
             Act o = b.act(din, x.H * 2, x.W * 2);
-            b.conv(a, o, 0, nullptr);
+            // inference plans (round 3): the upsampling folded into the WEIGHTS -- four 2x2 parity convolutions on x in one launch, 4/9 of the
+            // multiply-adds (plan.h conv_up2; FLOCODER_AMD_UPS_FOLD=0: off).  Training plans keep the 3x3 form their backward differentiates.
+            if (u->keep_all || !b.conv_up2(a.s0, x, u->PUP(p + ".3.1.weight"), u->R(p + ".3.1.bias"), o, 0, nullptr)) {
+                a.ups = 1; a.w = u->P(p + ".3.1.weight"); a.bias = u->R(p + ".3.1.bias"); a.w4 = u->P8(p + ".3.1.weight");
+                b.conv(a, o, 0, nullptr);
+            }
             pl->tape.push_back({3, (int)pl->convs.size()});
             pl->convs.push_back({p + ".3.1", x, o, 3, 1, 1, 1});
             x = o;

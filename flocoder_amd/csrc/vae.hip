@@ -80,7 +80,7 @@ static int declare_all(fc_vae* v) {
     for (int i = 0; i < L; ++i) {
         const int co = bo[L - 1 - i];
         for (int j = 0; j < v->lpb + 1; ++j) decl_resnet(v, "decoder.up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), j == 0 ? ci : co, co);
-        if (i < L - 1) v->decl_conv("decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv", co, co, 3);
+        if (i < L - 1) v->decl_conv_up2("decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv", co, co);
         ci = co;
     }
     v->decl_norm("decoder.conv_norm_out", bo[0]);
@@ -281,10 +281,15 @@ static int build_decoder(fc_vae* v, int maxB, int h, int w) {
         if (i < L - 1 && !b.err) {   // Upsample2D: nearest x2 + conv3x3
             b.scope = blk + ".upsamplers.0";
             Act y = b.act(co, x.H * 2, x.W * 2);
-            ConvArgs a;
-            a.s0.p = x.p; a.s0.C = x.C; a.Hs = x.H; a.Ws = x.W; a.KS = 3; a.pad = 1; a.ups = 1;
-            a.w = v->P(blk + ".upsamplers.0.conv.weight"); a.bias = v->R(blk + ".upsamplers.0.conv.bias");
-            b.conv(a, y, G, &st);
+            // (round 3) the upsampling is folded into the weights: four 2x2 convolutions on x, 4/9 of the multiply-adds (plan.h conv_up2);
+            // FLOCODER_AMD_UPS_FOLD=0: the 3x3 convolution over the upsampled window as in rounds 1-2
+            ConvSrc src; src.p = x.p; src.C = x.C;
+            if (!b.conv_up2(src, x, v->PUP(blk + ".upsamplers.0.conv.weight"), v->R(blk + ".upsamplers.0.conv.bias"), y, G, &st)) {
+                ConvArgs a;
+                a.s0.p = x.p; a.s0.C = x.C; a.Hs = x.H; a.Ws = x.W; a.KS = 3; a.pad = 1; a.ups = 1;
+                a.w = v->P(blk + ".upsamplers.0.conv.weight"); a.bias = v->R(blk + ".upsamplers.0.conv.bias");
+                b.conv(a, y, G, &st);
+            }
             b.release(x);
             x = y;
         }

@@ -132,8 +132,11 @@ int fc_debug_unet_break_meeting(fc_unet* u);
 /* Experiment switch: plans built after the call use (1) / do not use (0) the cross-workgroup Block tails; < 0 restores the default
  * (on, unless FLOCODER_AMD_FUSED_TAIL says otherwise). */
 int fc_debug_set_fused_tail(int on);
+/* FLOPs per sample and evaluation as the REFERENCE computes the network (2 x MACs of every module, unet.py:289-372; SURVEY 8(d): 1.0008e9 at
+ * dim 32) -- the unit of every end-to-end TFLOP/s figure.  Inference plans execute less where nn.Upsample + conv3x3 is folded into four 2x2
+ * kernels (9 -> 4 taps per output pixel): fc_unet_op_info reports what each launch executes. */
 double fc_unet_flops_per_sample(const fc_unet* u);
-/* Launch i of the plan: kernel family, the reference module it implements, its algorithmic FLOPs per sample. */
+/* Launch i of the plan: kernel family, the reference module it implements, the FLOPs per sample it executes. */
 int fc_unet_op_info(const fc_unet* u, int i, const char** kernel, const char** module, double* flops_per_sample);
 /* Algorithmic HBM bytes of launch i (convolution launches; 0 for the others): per sample = every input / output / residual element
  * once, per launch = the weights once -- the figure bench.py's roofline.traffic is read against. */
