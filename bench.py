@@ -143,6 +143,10 @@ def roofline(model, batch):
         "share_of_forward_time": round(dom["ms"] / total_ms, 3), "forward_sum_of_kernels_ms": round(total_ms, 4),
         "rows_per_launch": rows_timed, "chains": model.chains[0],
         "forward_tflops_all_kernels": round(model.flops_per_sample * rows_timed / (total_ms * 1e-3) / 1e12, 3),
+        # flops_per_sample is the reference's arithmetic; the launches execute less since nn.Upsample + conv3x3 runs as four 2x2
+        # kernels -- the per-kernel figures here and `achieved` count what is executed
+        "gflop_per_sample_reference": round(model.flops_per_sample / 1e9, 4),
+        "gflop_per_sample_executed": round(sum(r["flops_per_sample"] for r in rows) / 1e9, 4),
         "slices": {k: _entry(v, k) for k, v in _slices(rows, name).items()},
         "per_kernel": {k: dict(ms=round(v["ms"], 4), launches=v["launches"], tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 3))
                        for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])},

@@ -248,3 +248,49 @@ def test_low_resolution_attention_in_one_launch_equals_the_two_launch_form(tmp_p
     assert torch.isfinite(v).all() and torch.isfinite(lat).all()
     assert torch.equal(v, v2) and torch.equal(w, w2)
     assert rel_l2(v, w) < 1e-6 and rel_l2(lat, lat2) < 1e-5
+
+
+_FOLD_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from flocoder_amd.unet import Unet
+from flocoder_amd.codecs import SD_VAE_Wrapper
+torch.manual_seed(31)
+m = Unet(dim=32, dim_mults=(1, 2, 4, 8), channels=4, n_classes=102).eval().to("cuda:0")
+g = torch.Generator().manual_seed(32)
+x = torch.randn(6, 4, 32, 32, generator=g).to("cuda:0"); ids = torch.randint(102, (6,), generator=g).to("cuda:0")
+t = torch.full((6,), 333.0, device="cuda:0")
+with torch.no_grad():
+    v = m(x, t, {"class_cond": ids}).clone()
+executed = sum(r["flops_per_sample"] for r in m.profile_ops(6, repeats=1))
+w = SD_VAE_Wrapper(weights="random", seed=7).eval().to("cuda:0")
+z = (torch.randn(2, 4, 32, 32, generator=g) * 4.5).to("cuda:0")
+img = w.decode(z)
+torch.save((v.cpu(), img.cpu(), m.flops_per_sample, executed), sys.argv[1])
+"""
+
+
+def test_folded_upsampling_equals_the_conv_over_the_upsampled_window(tmp_path):
+    """Upsample = nn.Upsample(scale_factor=2, nearest) + Conv2d(3x3, padding 1) (unet.py:42-46; AutoencoderKL's Upsample2D behind
+    codecs.py:631-652).  Output pixel (2y + a, 2x + b) only ever sees a 2x2 block of source pixels, each through the sum of the taps that land
+    on it, so inference plans run four 2x2 convolutions on the low-resolution tensor (plan.h conv_up2, pack kinds 9 / 10) -- 4/9 of the
+    multiply-adds, exact in real arithmetic.  FLOCODER_AMD_UPS_FOLD=0 keeps the 3x3 form: same result to fp32 rounding for the U-Net's three
+    Upsample layers and the SD-VAE decoder's three; the FLOPs per sample stay the reference's figure, the executed ones drop."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, env in (("folded", {}), ("plain", {"FLOCODER_AMD_UPS_FOLD": "0"})):
+        f = str(tmp_path / (tag + ".pt"))
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", _FOLD_SCRIPT % root, f], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = torch.load(f)
+    (v, img, fl, ex), (v0, img0, fl0, ex0) = outs["folded"], outs["plain"]
+    print("folded vs 3x3 upsampling: U-Net forward rel-L2 %.2e, SD-VAE decode %.2e; GFLOP/sample reference %.4f executed %.4f (plain %.4f)"
+          % (rel_l2(v, v0), rel_l2(img, img0), fl / 1e9, ex / 1e9, ex0 / 1e9))
+    assert torch.isfinite(v).all() and torch.isfinite(img).all()
+    # (either form is ~2e-6 from the fp64-accumulating oracle on this decoder: tests/test_gpu_vae.py)
+    assert rel_l2(v, v0) < 2e-6 and rel_l2(img, img0) < 1e-5
+    assert fl == fl0 and abs(ex0 - fl0) < 1e-3 * fl0 and ex < 0.95 * ex0
