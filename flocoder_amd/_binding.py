@@ -39,6 +39,7 @@ SIGNATURES = {
     "fc_unet_param_numel": (_i64, [_vp]),
     "fc_unet_load_params": (_i, [_vp, _vp, _i64, _i, _vp]),
     "fc_unet_reserve": (_i, [_vp, _i, _i, _i]),
+    "fc_unet_reserved": (_i, [_vp, _pi, _pi, _pi]),
     "fc_unet_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     "fc_unet_integrate": (_i, [_vp, _i, _vp, _i, _i, _i, _pf, _i, _f, _f, _vp, _f, _vp, _i, _vp]),
     "fc_unet_chains": (_i, [_vp, _pi]),

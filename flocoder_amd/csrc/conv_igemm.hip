@@ -416,7 +416,7 @@ bool conv_fin_possible(const ConvArgs& a, int tile) {
 static int auto_tile(const ConvArgs& a) {
     const long M = (long)a.B * a.H * a.W;
     const int hw = a.H * a.W;
-    auto blocks = [&](int t) { return (M / kTiles[t].BM) * cdiv(a.Cout, kTiles[t].BN); };
+    auto blocks = [&](int t) { return (M / kTiles[t].BM) * cdiv(a.Cout, kTiles[t].BN) * (a.par4 ? 4 : 1); };   // (par4: four classes per launch)
     auto ok = [&](int t) { return !(a.w_batch_stride && hw < kTiles[t].BM) && M >= kTiles[t].BM; };
     // measured on the SD-VAE shapes (tools/conv_microbench.py --vae, B=16): M256N64 113 / 109 / 101 TFLOP/s at 512@64^2 / 256@128^2 /
     // 128@256^2 against 101 / 97 / 90 for M128N64 and 98 / 105 / 98 for M128N32; the 64-wide column tile only pays for 1x1 layers
@@ -424,6 +424,12 @@ static int auto_tile(const ConvArgs& a) {
         ConvDev d;
         ConvGeom g;
         if (conv_geometry(a, TILE_M256N64, true, &d, &g) == FC_OK) return TILE_M256N64;   // else: patch / LDS limits, fall through
+    }
+    if (a.par4) {   // four 2x2-tap classes in one launch: a workgroup has 4/9 of a 3x3 layer's matrix work, so the grid wants to be twice as full
+                    // before a larger tile pays (measured at B = 64: 128->64 @8->16 M32N32K4 18.7 against M128N32 21.7 us; 64->32 @16->32 M128N32 14.6 against M64N32K2 18.3)
+        if (ok(TILE_M128N32) && blocks(TILE_M128N32) >= 512) return TILE_M128N32;
+        if (ok(TILE_M64N32K2) && blocks(TILE_M64N32K2) >= 512) return TILE_M64N32K2;
+        return TILE_M32N32K4;
     }
     if ((a.KS == 1 || a.Cout >= 512) && a.Cout >= 64 && ok(TILE_M128N64) && blocks(TILE_M128N64) >= 512) return TILE_M128N64;
     if (ok(TILE_M128N32) && blocks(TILE_M128N32) >= 256) return TILE_M128N32;   // one full wave of workgroups: measured 20 vs 29 us on the 64-channel 16x16 layers (profiles/r01_c_conv_microbench.txt)

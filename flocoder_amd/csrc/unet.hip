@@ -791,6 +791,14 @@ int fc_unet_load_params(fc_unet* u, const float* flat, int64_t numel, int on_dev
     return u->load(flat, numel, on_device, static_cast<hipStream_t>(stream));
 }
 
+int fc_unet_reserved(const fc_unet* u, int* max_batch, int* height, int* width) {
+    if (!u) return fail(FC_E_ARG, "fc_unet_reserved: null handle");
+    if (max_batch) *max_batch = u->maxB;
+    if (height) *height = u->maxB ? u->H : 0;
+    if (width) *width = u->maxB ? u->W : 0;
+    return FC_OK;
+}
+
 int fc_unet_reserve(fc_unet* u, int max_batch, int height, int width) {
     if (!u || max_batch < 1) return fail(FC_E_ARG, "fc_unet_reserve: bad argument");
     if (u->device < 0) return fail(FC_E_STATE, "unet: created with device < 0 (description only)");

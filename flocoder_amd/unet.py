@@ -225,7 +225,13 @@ class Unet(nn.Module):
                     mask_cond=bool(c.mask_cond), use_checkpoint=self.use_checkpoint)
         twin.load_state_dict(self.state_dict())
         twin.train(self.training)
-        return twin.to(next(self.parameters()).device)
+        twin = twin.to(next(self.parameters()).device)
+        if self._handle:          # same reservation -> same tiles -> bit-identical results (the plan is built for the reserved row count)
+            rows, h, w = C.c_int(0), C.c_int(0), C.c_int(0)
+            B.check(B.lib().fc_unet_reserved(self._handle, C.byref(rows), C.byref(h), C.byref(w)))
+            if rows.value > 0:
+                twin.reserve(rows.value, h.value, w.value)
+        return twin
 
     # ------------------------------------------------------------------ device sharing (fc_unet_set_shared)
     def set_shared_device(self, shared: Optional[bool]) -> None:

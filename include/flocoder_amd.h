@@ -69,6 +69,9 @@ int fc_unet_load_params(fc_unet* u, const float* flat, int64_t numel, int on_dev
 /* Build the launch plan and allocate the activation arena for batches up to `max_batch` of HxW latents.
  * `max_batch` counts U-Net rows: a CFG sampler of B samples needs 2B. */
 int fc_unet_reserve(fc_unet* u, int max_batch, int height, int width);
+/* The current reservation (0, 0, 0 before the first one).  The launch plan depends on it -- tiles are picked for max_batch rows -- so two
+ * handles give bit-identical results only under equal reservations: Unet.replica() copies it (sampling.sample_many, bench.py two-in-flight). */
+int fc_unet_reserved(const fc_unet* u, int* max_batch, int* height, int* width);
 
 /* v = Unet(x, time, cond)   (unet.py:374-377).
  *   x_dev [B,C,H,W]; time_dev [B] (already multiplied by t_scale, sampling.py:63);
