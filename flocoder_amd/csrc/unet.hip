@@ -536,9 +536,10 @@ static int build_plan(fc_unet* u, Plan* pl, int maxB, int H, int W) {
             x = o;
         } else {  // nn.Upsample(nearest x2) folded into the conv's loader (unet.py:42-46)
             Act o = b.act(din, x.H * 2, x.W * 2);
-            // inference plans (round 3): the upsampling folded into the WEIGHTS -- four 2x2 parity convolutions on x in one launch, 4/9 of the
-            // multiply-adds (plan.h conv_up2; FLOCODER_AMD_UPS_FOLD=0: off).  Training plans keep the 3x3 form their backward differentiates.
-            if (u->keep_all || !b.conv_up2(a.s0, x, u->PUP(p + ".3.1.weight"), u->R(p + ".3.1.bias"), o, 0, nullptr)) {
+            // (round 3) the upsampling folded into the WEIGHTS -- four 2x2 parity convolutions on x in one launch, 4/9 of the multiply-adds
+            // (plan.h conv_up2; FLOCODER_AMD_UPS_FOLD=0: off).  Training plans too: it is the same function of (x, w) up to fp32 rounding, and
+            // the backward differentiates it in its 3x3 form from the same saved x (flowers-sized step 6.49 -> 6.45 ms).
+            if (!b.conv_up2(a.s0, x, u->PUP(p + ".3.1.weight"), u->R(p + ".3.1.bias"), o, 0, nullptr)) {
                 a.ups = 1; a.w = u->P(p + ".3.1.weight"); a.bias = u->R(p + ".3.1.bias"); a.w4 = u->P8(p + ".3.1.weight");
                 b.conv(a, o, 0, nullptr);
             }
