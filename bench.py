@@ -67,6 +67,11 @@ PEAK_HBM_GBS = 8000.0             # same guide, HBM3E
 TWO_KERNEL_ENTRIES = 4 + (5 if os.environ.get("FLOCODER_AMD_LA_JOIN") == "separate" else 0)   # attention plan entries that are two kernels
 
 
+def _phase(name):
+    """Phase marker on stderr (stdout carries the one JSON line): a fault or a hang in a long bench run is then attributable to its leg."""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {name}", file=sys.stderr, flush=True)
+
+
 def pmc_traffic(kernel, pattern="*pmc_traffic.json"):
     """HBM bytes per launch of `kernel` from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
     tools/pmc_forward.py or tools/pmc_codec.py, summarised by tools/pmc_summary.py with the guide's gfx950 correction).  A process
@@ -341,11 +346,14 @@ def secondary(model, noise, ids, device):
     from flocoder_amd.sampling import decode_latents, euler_sampler
     out = {}
     shape = (BATCH,) + LATENT
-    out["euler64_two_in_flight"] = two_in_flight(model, noise, ids, device)     # first: both replicas still hold their 64-row plans
+    _phase("secondary: two trajectories in flight")
+    out["euler64_two_in_flight"] = two_in_flight(model, noise, ids, device)
+    _phase("secondary: euler / cfg")     # first: both replicas still hold their 64-row plans
     t_ode, lat = _gpu_time(lambda: euler_sampler(model, shape, N_EULER, cond=ids, source=noise)[0], device, 2)
     t_cfg, _ = _gpu_time(lambda: euler_sampler(model, shape, N_EULER, cond=ids, source=noise, cfg_strength=CFG)[0], device, 2)
     out["euler64_cfg"] = {"workload": f"64-step Euler with CFG {CFG} (128 U-Net rows per evaluation), B={BATCH}", "ms": round(t_cfg * 1e3, 1),
                           "samples_per_s": round(BATCH / t_cfg, 1), "tflops": round(BATCH * N_EULER * 2 * model.flops_per_sample / t_cfg / 1e12, 2)}
+    _phase("secondary: SD-VAE decode / encode")
     vae = SD_VAE_Wrapper(weights="random", seed=0).eval().to(device)       # seeded random weights: no real checkpoint offline
     z = lat * (4.5 / float(lat.std()))                                       # unscaled SD latents have std ~4.5
     t_dec, img = _gpu_time(lambda: decode_latents(vae, z, chunk_size=DECODE_CHUNK), device, 2)
@@ -374,6 +382,7 @@ def secondary(model, noise, ids, device):
                            "images_per_s": round(BATCH / t_enc, 1), "gflop_per_image": round(gf_enc, 1),
                            "tflops": round(BATCH * gf_enc / t_enc / 1e3, 1)}
     # opt-in split-bf16 arithmetic of the codec (fc_vae_set_precision): reported BESIDE the fp32 numbers with its measured error, never instead
+    _phase("secondary: SD-VAE split-bf16")
     vae.set_precision("bf16x3")
     t_dec3, img3 = _gpu_time(lambda: decode_latents(vae, z, chunk_size=DECODE_CHUNK), device, 2)
     t_enc3, _ = _gpu_time(lambda: torch.cat([vae.encode(img[i:i + DECODE_CHUNK]) for i in range(0, BATCH, DECODE_CHUNK)]), device, 2)
@@ -388,8 +397,10 @@ def secondary(model, noise, ids, device):
     out["euler64_plus_decode"] = {"workload": "64-step Euler + SD-VAE decode (decoded images/s, SURVEY 8d secondary metric)",
                                   "images_per_s": round(BATCH / (t_ode + t_dec), 1), "ode_ms": round(t_ode * 1e3, 1), "decode_ms": round(t_dec * 1e3, 1)}
     del vae
+    _phase("secondary: training steps")
     out["train_step_stl_sd"] = train_step_secondary(device, dim=16, hw=16, batch=32, classes=10)
     out["train_step_flowers_sized"] = train_step_secondary(device, dim=32, hw=32, batch=64, classes=102)
+    _phase("secondary: config 5")
     out["config5_midi"] = config5(device)
     return out
 
@@ -487,7 +498,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--secondary-only", action="store_true", help="(internal) run the one-GPU secondary legs and print their JSON: the main run "
+                    "starts this in a child process, so that nothing in them can cost the headline line")
     args = ap.parse_args()
+
+    if args.secondary_only:
+        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(device)
+        model = build_model(device)
+        noise, ids = synthetic_inputs(0, 1, device)
+        print(json.dumps(secondary(model, noise, ids, device)), flush=True)
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
@@ -524,9 +545,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(device)
 
+    _phase("warm-up")
     for _ in range(args.warmup):
         out = step()
     barrier()
+    _phase("timed steps")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -565,17 +588,28 @@ def main():
         line["rccl_ranks" if comm["backend"] == "nccl" else comm["backend"] + "_ranks"] = comm["ranks_counted_by_allreduce"]
         line["comm"] = comm
     sec = {}
+    _phase("rk4 share")
     if not args.no_secondary:
         sec["rk4_100_cfg"] = rk4_share(model, rank, world, device)         # every rank takes part (max over ranks)
     if rank == 0:
         if not args.no_roofline:
+            _phase("roofline (per-launch timing)")
             line["roofline"] = roofline(model, BATCH)
         if world == 1 and not args.no_secondary:
-            sec.update(secondary(model, noise, ids, device))
+            # the secondary legs (codecs, two trajectories in flight, training steps, config 5) run in a process of their own: they are
+            # informative, a failure in one of them must not cost the headline line above
+            _phase("secondary legs (child process)")
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--secondary-only"], capture_output=True, text=True, timeout=900)
+                sys.stderr.write(r.stderr[-4000:])
+                sec.update(json.loads(r.stdout.strip().splitlines()[-1]))
+            except Exception as e:      # noqa: BLE001
+                sec["secondary_error"] = repr(e)[:300]
         if sec:
             line["secondary"] = sec
         mode = "none" if args.no_cpu_baseline else args.cpu_baseline
         if world == 1 and mode != "none":
+            _phase("cpu baseline")
             line["cpu_baseline"] = cpu_baseline(model, mode)
             line["speedup_vs_cpu_baseline"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
