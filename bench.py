@@ -64,7 +64,7 @@ def synthetic_inputs(rank, world, device, per_rank=BATCH):
 PEAK_HBM_GBS = 8000.0             # same guide, HBM3E
 
 
-TWO_KERNEL_ENTRIES = 4 + (5 if os.environ.get("FLOCODER_AMD_LA_JOIN") == "separate" else 0)   # attention plan entries that are two kernels
+TWO_KERNEL_ENTRIES = 4 + (0 if os.environ.get("FLOCODER_AMD_LA_JOIN") == "one" else 5)   # attention plan entries that are two kernels
 
 
 def _phase(name):
@@ -572,8 +572,8 @@ def main():
                                "dim_mults [1,2,4,8] n_classes=102, class-conditional, no CFG, ODE loop only (no VAE decode)",
                    "global_batch": BATCH * world, "nfe_per_sample": N_EULER, "parallelism": f"sample-shard x{world}, weights broadcast once",
                    "gflop_per_sample": round(model.flops_per_sample * N_EULER / 1e9, 3),
-                   # plan entries of one forward; the four high-resolution attention entries are two kernels each (the five
-                   # low-resolution ones too under FLOCODER_AMD_LA_JOIN=separate), and inside the integrator the two conditioning
+                   # plan entries of one forward; the nine attention entries are two kernels each (the five low-resolution ones
+                   # are one under FLOCODER_AMD_LA_JOIN=one), and inside the integrator the two conditioning
                    # entries are replaced by a table computed once per call
                    "plan_entries_per_forward": model.launches_per_forward,
                    "kernel_launches_per_forward": model.launches_per_forward + TWO_KERNEL_ENTRIES,

@@ -258,11 +258,13 @@ struct Builder : PlanBuilder {
         return out;
     }
 
-    // arrival counters of the one-launch form of linattn_sample.hip (zeroed here, once: every launch adds `heads` per sample), or null:
-    // FLOCODER_AMD_LA_JOIN=separate keeps the closing step in a launch of its own (la_join)
+    // arrival counters of the one-launch form of linattn_sample.hip (zeroed here, once: every launch adds `heads` per sample), or null.
+    // Default: null -- the closing step stays a launch of its own (la_join).  FLOCODER_AMD_LA_JOIN=one selects the one-launch form: built and
+    // tested in round 3, but it measures the same or slightly below the two-launch form (789 against 793 samples/s, three alternating pairs;
+    // 1286 against 1279 us of kernel time per forward), so it is not the default.
     unsigned* la_tickets(int n, int C) {
-        static const bool separate = [] { const char* e = std::getenv("FLOCODER_AMD_LA_JOIN"); return e && std::string(e) == "separate"; }();
-        if (separate || !linattn_sample_one_launch(n, C) || err) return nullptr;
+        static const bool one = [] { const char* e = std::getenv("FLOCODER_AMD_LA_JOIN"); return e && std::string(e) == "one"; }();
+        if (!one || !linattn_sample_one_launch(n, C) || err) return nullptr;
         unsigned* t = reinterpret_cast<unsigned*>(dmalloc((size_t)B));
         if (t && hipMemset(t, 0, (size_t)B * sizeof(unsigned)) != hipSuccess) { err = fail(FC_E_HIP, "hipMemset failed on the attention tickets"); return nullptr; }
         return t;

@@ -230,14 +230,14 @@ torch.save((v.cpu(), v2.cpu(), lat.cpu(), m.launches_per_forward), sys.argv[1])
 def test_low_resolution_attention_in_one_launch_equals_the_two_launch_form(tmp_path):
     """linattn_sample.hip (round 3): at n <= 64 the workgroup of a sample that arrives last adds the heads' shares of to_out.0, applies
     to_out.1's GroupNorm(1) and the residual (unet.py:125-161,250; the bottleneck Attention, unet.py:99-122, has no norm) -- one launch per
-    module instead of la_head + la_join.  FLOCODER_AMD_LA_JOIN=separate keeps the second launch.  Same arithmetic in the same order except
+    module instead of la_head + la_join (FLOCODER_AMD_LA_JOIN=one; the two-launch form is the default, it measures the same or better).  Same arithmetic in the same order except
     the statistics' block reduction (256 threads instead of 512): equal to fp32 rounding, and repeatable (the arrival counters only grow)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
-    for tag, env in (("one", {}), ("two", {"FLOCODER_AMD_LA_JOIN": "separate"})):
+    for tag, env in (("one", {"FLOCODER_AMD_LA_JOIN": "one"}), ("two", {})):
         f = str(tmp_path / (tag + ".pt"))
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, "-c", _LA_SCRIPT % root, f], env=e, capture_output=True, text=True, timeout=600)
