@@ -50,6 +50,8 @@ SIGNATURES = {
     "fc_unet_set_time_freqs": (_i, [_vp, _pf, _i]),
     "fc_unet_debug_tensor": (_i, [_vp, C.c_char_p, C.POINTER(_vp), _pi, _pi, _pi]),
     "fc_debug_copy": (_i, [_vp, _vp, _i64, _vp]),
+    "fc_debug_set_poison": (_i, [_i]),
+    "fc_debug_poison_check": (_i, [_pi, _pi]),
     "fc_debug_set_conv_stamps": (_i, [_vp]),
     "fc_debug_conv": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _pi, _pf, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _pf, _vp]),
     "fc_debug_set_fused_tail": (_i, [_i]),

@@ -25,6 +25,10 @@ int fail(int code, const std::string& msg);
         if (_r != FC_OK) return _r; \
     } while (0)
 
+// Long-lived device buffers (devmem.hip): hipMalloc / hipFree, or poisoned + fenced allocations under FLOCODER_AMD_POISON=1
+int dev_alloc(void** out, size_t bytes, const char* tag);
+void dev_free(void* p);
+
 static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

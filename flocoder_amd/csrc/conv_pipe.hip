@@ -411,6 +411,21 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
         gn_tables(true, ltid, LT);
         store_patch(0, pv);
         if (FL & FL_STAMP) conv_stamp(p, 3);
+        // EXPLICIT, unconditional wait for this wave's slab pieces before stage 0 is handed over (round 4; the root cause of the results
+        // that differed when two replicas ran side by side).  The LDS-DMA above is invisible to the compiler, so until now the only thing
+        // that retired it was the compiler's own wait for the window loads in store_patch -- and that wait sits INSIDE the `e_lds >= 0`
+        // branch: a loader wave none of whose lanes has a window element (the folded-upsampling launch at 4x4: 2 samples x 5 x 5 window
+        // pixels x 8 channel quads = 400 elements for 512 loader threads, wave 7 idle) skipped it (s_cbranch_execz) and reached the barrier
+        // with its pieces -- rows 56..63 of taps 1 and 3 -- possibly still in flight; the consumers then multiplied whatever the previous
+        // workgroup had left in that LDS.  Alone on the GPU the pieces, requested a memory round trip before the window, had always landed;
+        // beside a second stream's kernels they sometimes had not (tools/race_hunt.py: first differing tensor ups.0.3, one parity class, one
+        // 32-column tile, exactly the pixels tap 1 or tap 3 reaches).  Busy waves drained to zero here already (the compiler's wait counts
+        // only its own, younger loads), so this costs nothing.  Issued as the BUILTIN (a real S_WAITCNT instruction, vmcnt(0) with the other
+        // counters left alone), not as inline asm: the compiler's wait-count pass reads it and then KNOWS that the window loads above have
+        // completed on every path.  Without that knowledge it assumed they might still be pending wherever a lane had skipped its store, and
+        // protected the registers they share with the hidden loads of the loop by an `s_waitcnt vmcnt(0)` in front of the loop's window
+        // requests and another in front of every LDS store -- each of which also drained the slab that was meant to stay in flight.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         loader_handover();                        // stage 0 ready
         for (int g = 0; g < nchunks; ++g) {       // consumers are on chunk g
             const bool next = g + 1 < nchunks;

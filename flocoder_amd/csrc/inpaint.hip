@@ -185,7 +185,7 @@ int fc_mask_encoder_create(int device, fc_mask_encoder** out) {
 }
 
 static void me_free_buffers(fc_mask_encoder* m) {
-    for (float** p : {&m->t1, &m->s1, &m->t2, &m->s2, &m->zb, &m->ga, &m->gb}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    for (float** p : {&m->t1, &m->s1, &m->t2, &m->s2, &m->zb, &m->ga, &m->gb}) { if (*p) dev_free(*p); *p = nullptr; }
     m->B = 0;
 }
 
@@ -214,10 +214,10 @@ int fc_mask_encoder_reserve(fc_mask_encoder* m, int max_batch, int height, int w
     FC_HIP(hipDeviceSynchronize());
     me_free_buffers(m);
     const size_t h1 = height / k, w1 = width / k, h2 = h1 / k, w2 = w1 / k, b = max_batch;
-    FC_HIP(hipMalloc(reinterpret_cast<void**>(&m->t1), b * 16 * h1 * w1 * sizeof(float)));
-    FC_HIP(hipMalloc(reinterpret_cast<void**>(&m->s1), b * 17 * h1 * w1 * sizeof(float)));
-    FC_HIP(hipMalloc(reinterpret_cast<void**>(&m->t2), b * 32 * h2 * w2 * sizeof(float)));
-    FC_HIP(hipMalloc(reinterpret_cast<void**>(&m->s2), b * 33 * h2 * w2 * sizeof(float)));
+    FC_TRY(dev_alloc(reinterpret_cast<void**>(&m->t1), b * 16 * h1 * w1 * sizeof(float), "mask_encoder.t1"));
+    FC_TRY(dev_alloc(reinterpret_cast<void**>(&m->s1), b * 17 * h1 * w1 * sizeof(float), "mask_encoder.s1"));
+    FC_TRY(dev_alloc(reinterpret_cast<void**>(&m->t2), b * 32 * h2 * w2 * sizeof(float), "mask_encoder.t2"));
+    FC_TRY(dev_alloc(reinterpret_cast<void**>(&m->s2), b * 33 * h2 * w2 * sizeof(float), "mask_encoder.s2"));
     m->B = max_batch; m->H = height; m->W = width;
     return FC_OK;
 }
@@ -257,9 +257,9 @@ int fc_mask_encoder_backward(fc_mask_encoder* m, const float* mask_pixels_dev, c
     const int k = m->shrink, B = batch, h1 = height / k, w1 = width / k, h2 = h1 / k, w2 = w1 / k, oc = m->out_ch;
     if (!m->zb) {
         const size_t big = (size_t)m->B * 17 * h1 * w1;
-        FC_HIP(hipMalloc(reinterpret_cast<void**>(&m->zb), big * sizeof(float)));
-        FC_HIP(hipMalloc(reinterpret_cast<void**>(&m->ga), big * sizeof(float)));
-        FC_HIP(hipMalloc(reinterpret_cast<void**>(&m->gb), big * sizeof(float)));
+        FC_TRY(dev_alloc(reinterpret_cast<void**>(&m->zb), big * sizeof(float), "mask_encoder.zb"));
+        FC_TRY(dev_alloc(reinterpret_cast<void**>(&m->ga), big * sizeof(float), "mask_encoder.ga"));
+        FC_TRY(dev_alloc(reinterpret_cast<void**>(&m->gb), big * sizeof(float), "mask_encoder.gb"));
     }
     if (!accumulate) FC_HIP(hipMemsetAsync(grads_flat_dev, 0, (size_t)numel * sizeof(float), s));
     auto G = [&](const char* n) { return grads_flat_dev + m->params[m->pidx.at(n)].offset; };

@@ -182,8 +182,8 @@ int pack_table_build(std::vector<PackJob> jobs, PackTable* out) {
         const int nb = (int)((jobs[i].total + kPackPerBlock - 1) / kPackPerBlock);
         for (int b = 0; b < nb; ++b) blocks.push_back(make_int2((int)i, b));
     }
-    FC_HIP(hipMalloc(reinterpret_cast<void**>(&out->jobs), jobs.size() * sizeof(PackJob)));
-    FC_HIP(hipMalloc(reinterpret_cast<void**>(&out->blocks), blocks.size() * sizeof(int2)));
+    FC_TRY(dev_alloc(reinterpret_cast<void**>(&out->jobs), jobs.size() * sizeof(PackJob), "pack.jobs"));
+    FC_TRY(dev_alloc(reinterpret_cast<void**>(&out->blocks), blocks.size() * sizeof(int2), "pack.blocks"));
     FC_HIP(hipMemcpy(out->jobs, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
     FC_HIP(hipMemcpy(out->blocks, blocks.data(), blocks.size() * sizeof(int2), hipMemcpyHostToDevice));
     out->nblocks = (int)blocks.size();
@@ -191,8 +191,8 @@ int pack_table_build(std::vector<PackJob> jobs, PackTable* out) {
 }
 
 void PackTable::release() {
-    if (jobs) (void)hipFree(jobs);
-    if (blocks) (void)hipFree(blocks);
+    if (jobs) dev_free(jobs);
+    if (blocks) dev_free(blocks);
     jobs = nullptr; blocks = nullptr; nblocks = 0;
 }
 

@@ -68,7 +68,7 @@ struct Plan {                 // one launch plan + activation arena for up to ma
     int n_meet = 0;                                 // launches whose workgroups wait for each other (fused Block tails across workgroups)
     std::vector<unsigned*> fin_sync;                // their arrival counters (fc_debug_unet_break_meeting)
     void release() {
-        for (void* p : allocs) (void)hipFree(p);
+        for (void* p : allocs) dev_free(p);
         *this = Plan();
     }
 };
@@ -164,8 +164,8 @@ struct ParamStore {
         declare(n + ".bias", {C});
     }
     int alloc_device() {
-        FC_HIP(hipMalloc(reinterpret_cast<void**>(&raw), (size_t)(raw_numel ? raw_numel : 4) * sizeof(float)));
-        FC_HIP(hipMalloc(reinterpret_cast<void**>(&packed), (size_t)(packed_numel ? packed_numel : 4) * sizeof(float)));
+        FC_TRY(dev_alloc(reinterpret_cast<void**>(&raw), (size_t)(raw_numel ? raw_numel : 4) * sizeof(float), "params.raw"));
+        FC_TRY(dev_alloc(reinterpret_cast<void**>(&packed), (size_t)(packed_numel ? packed_numel : 4) * sizeof(float), "params.packed"));
         FC_HIP(hipMemset(raw, 0, (size_t)(raw_numel ? raw_numel : 4) * sizeof(float)));
         std::vector<PackJob> jobs;
         for (const PackOp& o : packops) jobs.push_back({raw + o.src, packed + o.dst, o.kind, o.a, o.b, o.kind == 0 ? o.c * o.d : o.c, o.d, o.e, 0});
@@ -173,8 +173,8 @@ struct ParamStore {
     }
     void free_device() {
         pack_table.release();
-        if (raw) (void)hipFree(raw);
-        if (packed) (void)hipFree(packed);
+        if (raw) dev_free(raw);
+        if (packed) dev_free(packed);
         raw = packed = nullptr;
     }
     int run_pack(hipStream_t s) const {
@@ -245,7 +245,7 @@ struct PlanBuilder {
     }
     float* dmalloc(size_t floats) {
         void* p = nullptr;
-        if (hipMalloc(&p, (floats ? floats : 1) * sizeof(float)) != hipSuccess) { err = fail(FC_E_HIP, "hipMalloc failed while reserving the arena"); return nullptr; }
+        if (dev_alloc(&p, (floats ? floats : 1) * sizeof(float), scope.c_str()) != FC_OK) { err = fail(FC_E_HIP, "hipMalloc failed while reserving the arena"); return nullptr; }
         pl->allocs.push_back(p);
         return static_cast<float*>(p);
     }

@@ -369,7 +369,7 @@ static void free_plan(fc_unet* u) {
     u->bwd.release();                       // the backward plan points into the forward arena
     u->dgrad_packs.clear();
     u->dgrad_table.release();
-    for (void* p : u->int_allocs) (void)hipFree(p);
+    for (void* p : u->int_allocs) dev_free(p);
     u->int_allocs.clear();
     u->maxB = 0;
     // a rebuilt plan starts clean (callers of free_plan have synchronised the device)
@@ -571,7 +571,7 @@ static int alloc_integrator(fc_unet* u, int rows, int H, int W) {
     const size_t nstate = (size_t)rows * u->cfg.channels * H * W;
     auto get = [&](size_t floats, float** out) -> int {
         void* p = nullptr;
-        FC_HIP(hipMalloc(&p, (floats ? floats : 1) * sizeof(float)));
+        FC_TRY(dev_alloc(&p, (floats ? floats : 1) * sizeof(float), "integrator"));
         u->int_allocs.push_back(p);
         *out = static_cast<float*>(p);
         return FC_OK;
@@ -754,8 +754,8 @@ void fc_unet_destroy(fc_unet* u) {
     (void)hipSetDevice(u->device);
     (void)hipDeviceSynchronize();
     free_plan(u);
-    if (u->ts_dev) (void)hipFree(u->ts_dev);
-    if (u->pre) (void)hipFree(u->pre);
+    if (u->ts_dev) dev_free(u->ts_dev);
+    if (u->pre) dev_free(u->pre);
     u->free_device();
     if (u->freqs) (void)hipFree(u->freqs);
     if (u->stream) (void)hipStreamDestroy(u->stream);
@@ -1005,9 +1005,9 @@ int fc_unet_integrate(fc_unet* u, int method, float* x_dev, int B, int H, int W,
     FC_HIP(hipSetDevice(u->device));
     if (n_points + 1 > u->ts_cap) {  // grows only when a longer grid than ever before arrives
         FC_HIP(hipStreamSynchronize(s));
-        if (u->ts_dev) FC_HIP(hipFree(u->ts_dev));
+        if (u->ts_dev) dev_free(u->ts_dev);
         u->ts_cap = n_points < 1024 ? 1024 : n_points + 1;   // + 1: the fused Euler tail reads one entry past the grid after the last step
-        FC_HIP(hipMalloc(reinterpret_cast<void**>(&u->ts_dev), u->ts_cap * sizeof(float)));
+        FC_TRY(dev_alloc(reinterpret_cast<void**>(&u->ts_dev), u->ts_cap * sizeof(float), "integrator.ts"));
         for (auto& kv : u->graphs) (void)hipGraphExecDestroy(kv.second);
         u->graphs.clear();  // captured graphs hold the old ts pointer
     }
@@ -1033,9 +1033,9 @@ int fc_unet_integrate(fc_unet* u, int method, float* x_dev, int B, int H, int W,
     if (pre_on) {
         if (need > u->pre_cap) {
             FC_HIP(hipStreamSynchronize(s));
-            if (u->pre) FC_HIP(hipFree(u->pre));
+            if (u->pre) dev_free(u->pre);
             u->pre = nullptr; u->pre_cap = 0;
-            FC_HIP(hipMalloc(reinterpret_cast<void**>(&u->pre), need * sizeof(float)));
+            FC_TRY(dev_alloc(reinterpret_cast<void**>(&u->pre), need * sizeof(float), "integrator.cond_table"));
             u->pre_cap = need;
             for (auto& kv : u->graphs) (void)hipGraphExecDestroy(kv.second);
             u->graphs.clear();  // captured graphs hold the old table pointer
@@ -1094,6 +1094,17 @@ int fc_unet_integrate(fc_unet* u, int method, float* x_dev, int B, int H, int W,
                 FC_HIP(hipGraphDestroy(graph));
                 it = u->graphs.emplace(key, exec).first;
             }
+            // The FIRST replay of a call waits, on the host, for everything this call has put on the stream in front of it (round 4).  Under
+            // AMD_DIRECT_DISPATCH=0 -- the mode the sampler ships with -- ROCm 7.2 submits a graph from the calling thread while the plain
+            // launches and copies issued just before it are still queued in the runtime's own submission thread: the replay overtook them.
+            // Measured (tools/inflight_distinct.py: five calls with different noise / class ids, one at a time): a call's trajectory ran on
+            // the PREVIOUS call's conditioning table (rel-L2 1.6e-2 against the oracle, the same value every time, in two or three calls of
+            // five); FLOCODER_AMD_NO_GRAPH=1, AMD_DIRECT_DISPATCH=1 and this wait each give 1e-7 in all of them, an event wait on the
+            // same stream does not.  bench.py never saw it: every timed step integrates the same samples, so a stale table is the right
+            // one.  Replays that follow a replay are ordered (RK4: five graphs per call); work issued behind a replay is ordered as well.
+            // Cost: the host idles for the prologue (~0.1 ms per call of 80 ms).  FLOCODER_AMD_GRAPH_FENCE=0 removes the wait (measurements only).
+            static const bool fence = [] { const char* e = std::getenv("FLOCODER_AMD_GRAPH_FENCE"); return !(e && std::atoi(e) == 0); }();
+            if (fence && left == n_steps) FC_HIP(hipStreamSynchronize(s));
             FC_HIP(hipGraphLaunch(it->second, s));
             left -= k;
         }

@@ -137,6 +137,7 @@ def generate_latents(model, shape, method='rk4', n_steps=50, cond=None, cfg_stre
     if method == "rk45":
         raise NameError("generate_latents_rk45 is not defined in the reference either (sampling.py:142-143)")
     if method == "euler":
+        # (the legacy sampler has no guidance upstream: generate_latents keeps that; sample_many forwards its cfg_strength itself)
         return euler_sampler(model, shape, n_steps, device=device, cond=cond, source=source)
     return generate_latents_rk4(model, shape, n_steps, cond, cfg_strength, source=source, init_latents=init_latents,
                                 init_strength=init_strength)
@@ -236,7 +237,10 @@ def sample_many(model, shape, batches, method="euler", n_steps=64, cfg_strength=
         for i, (cond, source) in enumerate(batches):
             k = i % len(models)
             with torch.cuda.stream(streams[k]):
-                lat, _ = generate_latents(models[k], shape, method=method, n_steps=n_steps, cond=cond, cfg_strength=cfg_strength, source=source)
+                if method == "euler":       # generate_latents' euler branch has no guidance (as upstream); euler_sampler's extension does
+                    lat, _ = euler_sampler(models[k], shape, n_steps, cond=cond, source=source, cfg_strength=cfg_strength)
+                else:
+                    lat, _ = generate_latents(models[k], shape, method=method, n_steps=n_steps, cond=cond, cfg_strength=cfg_strength, source=source)
                 outs.append(lat)
         for st in streams:
             cur.wait_stream(st)

@@ -199,7 +199,7 @@ class FlowTrainer:
         v = m._forward_native(x, time, cls, mask, train=True)
         dv = torch.empty_like(v)
         B.check(lib.fc_mse_loss_grad(B.ptr(v), B.ptr(v_target), B.ptr(dv), self._scal.data_ptr(), self._ws.data_ptr(), v.numel(), st))
-        self._pending = None
+        self._drain_pending()      # a collective an aborted step left in flight still writes self.grads: wait before the backward zeroes it
         nb, split = m.grad_buckets() if overlap else (1, 0)
         if overlap and nb == 2 and 0 < split < self.grads.numel() and all(hi <= split for _, hi in self._groups.values()):
             m.backward_native(x, time, cls, dv, self.grads, mask=mask, parts=(0, 0))
@@ -208,6 +208,13 @@ class FlowTrainer:
         else:
             m.backward_native(x, time, cls, dv, self.grads, mask=mask)
         return self._scal[0], v
+
+    def _drain_pending(self) -> None:
+        """Wait for an early-bucket all-reduce that was started but never finished (a step that raised between ``loss_and_grads`` and
+        ``finish_gradients``, e.g. the input check of ``_agree``): its communication stream may still be writing ``self.grads``."""
+        pend, self._pending = getattr(self, "_pending", None), None
+        if pend is not None:
+            pend[0].wait()
 
     def finish_gradients(self) -> None:
         """DDP's gradient averaging over the flat vector: what ``loss_and_grads(overlap=True)`` left in flight is waited for, the remaining

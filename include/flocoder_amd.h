@@ -158,6 +158,13 @@ int fc_unet_set_time_freqs(fc_unet* u, const float* freqs_host, int n);
  * ("downs.0.0", "downs.0.2", "mid_attn", "ups.3.3", ...). */
 int fc_unet_debug_tensor(const fc_unet* u, const char* name, const float** ptr, int* channels, int* height, int* width);
 int fc_debug_copy(void* dst_dev, const void* src_dev, int64_t bytes, void* stream);
+/* Memory diagnostics (csrc/devmem.hip): with the switch on (or FLOCODER_AMD_POISON=1 in the environment) every long-lived buffer the
+ * library allocates FROM THEN ON -- arenas, statistics, integrator state, parameter stores, job tables -- is filled with 0xFFFFFFFF words
+ * (NaN as fp32) and fenced by 64 KiB of the same pattern on both sides: a value read before it was written, or read past a buffer's end,
+ * poisons the result instead of depending on what the memory held before; fc_debug_poison_check counts the buffers whose fences were
+ * WRITTEN (fc_last_error names them) and synchronises the device. */
+int fc_debug_set_poison(int on);
+int fc_debug_poison_check(int* corrupted, int* live);
 /* Diagnostics: subsequent pipelined-conv launches write shader-clock phase stamps to buf_dev
  * ([block][wave][16] uint64); NULL switches them off again. */
 int fc_debug_set_conv_stamps(void* buf_dev);

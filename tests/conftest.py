@@ -36,3 +36,21 @@ def rel_l2(a, b):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _poison_fences():
+    """Under FLOCODER_AMD_POISON=1 (csrc/devmem.hip: every library buffer NaN-filled and fenced) the whole GPU suite doubles as a memory
+    check: a value read before it was written shows up as NaN in the test that reads it, and after every module the fences of all live
+    buffers are inspected for writes past a buffer's ends."""
+    yield
+    if os.environ.get("FLOCODER_AMD_POISON", "0") in ("", "0"):
+        return
+    import torch
+    if torch.cuda.device_count() == 0:
+        return
+    import ctypes as C
+    from flocoder_amd import _binding as B
+    bad, live = C.c_int(0), C.c_int(0)
+    B.check(B.lib().fc_debug_poison_check(C.byref(bad), C.byref(live)))
+    assert bad.value == 0, B.lib().fc_last_error().decode(errors="replace")
