@@ -674,8 +674,13 @@ def main():
         out = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        mine = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(every, mine)                  # each rank's own clock around the same K steps
+        per_rank = [round(BATCH * args.steps / float(e.item()), 1) for e in every]
+        t = mine.clone()
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(out).all()
@@ -710,6 +715,8 @@ def main():
     if comm:
         # the count is what the collective library itself summed; it is RCCL's only when the backend is "nccl" (= RCCL on ROCm)
         line["rccl_ranks" if comm["backend"] == "nccl" else comm["backend"] + "_ranks"] = comm["ranks_counted_by_allreduce"]
+        comm["per_rank_samples_per_s"] = per_rank          # value = global batch x steps / the SLOWEST rank's time; these are each rank's own
+        comm["per_step_collectives"] = 0                   # the sampling path has none: one weight broadcast before the loop
         line["comm"] = comm
     sec = {}
     _phase("rk4 share")

@@ -11,6 +11,7 @@
 // At the 32x32 level this replaces a 100 MB qkv round trip (to_qkv 32->384 over 65536 pixels) and two 33 MB passes by one
 // read of x per kernel.  fp32 MFMA throughout (exact products), so results match the unfused kernels to summation order.
 #include <cstdlib>
+#include <string>
 
 #include "common.h"
 #include "stats_dev.h"
@@ -297,18 +298,22 @@ __device__ __forceinline__ void store_x(const LaArgs& a, const float* Ab, const 
     }
 }
 
-template <int NQ>
-__global__ void __launch_bounds__(256) la_ctx_fast_kernel(const LaArgs a) {
+// NW = waves per workgroup (4 or 8).  Eight (round 4) where a (sample, head) has at least eight 32-position blocks: the workgroup is the
+// only one on its CU, so with four waves every SIMD held ONE wave and nothing covered its LDS round trips and softmax arithmetic between
+// the matrix phases; with eight, two waves share a SIMD's matrix pipe.  The split over positions stays inside the workgroup (the merge of
+// the partial (max, sum, context) triples is the same LDS pass over NW instead of four entries).
+template <int NQ, int NW>
+__global__ void __launch_bounds__(64 * NW) la_ctx_fast_kernel(const LaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    constexpr int C = NQ * 8, XS = C + 1;
+    constexpr int C = NQ * 8, XS = C + 1, NT = 64 * NW;
     float* Ab = sm;
     float* Bb = Ab + C;
     float* Wl = Bb + C;                 // [C][64]
-    float* xt = Wl + C * 64;            // [4][32][XS]
-    float* Et = xt + 4 * 32 * XS;       // [4][32][PS]
-    float* Vt = Et + 4 * 32 * PS;
-    float* sct = Vt + 4 * 32 * PS;      // [4][32]
-    float* mz = sct + 128;              // [4][2][32]
+    float* xt = Wl + C * 64;            // [NW][32][XS]
+    float* Et = xt + NW * 32 * XS;      // [NW][32][PS]
+    float* Vt = Et + NW * 32 * PS;
+    float* sct = Vt + NW * 32 * PS;     // [NW][32]
+    float* mz = sct + NW * 32;          // [NW][2][32]
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int nblk = (a.n + 31) >> 5;
     // every cold operand is requested before anything is waited for: first x tile, statistics, norm parameters, weights
@@ -319,15 +324,15 @@ __global__ void __launch_bounds__(256) la_ctx_fast_kernel(const LaArgs a) {
     const float pg = tid < C ? a.xf.gamma[tid] : 0.f, pbt = tid < C ? a.xf.beta[tid] : 0.f;   // C <= 64 < 256 threads
     // explicit registers: written as a load -> LDS store loop the compiler waits for every load before the next (ISA: vmcnt(0) per
     // iteration) -- dependent cold round trips at the head of the kernel
-    constexpr int NWL = C / 4;
+    constexpr int NWL = C * 64 / NT;
     float wl[NWL];
 #pragma unroll
     for (int k = 0; k < NWL; ++k) {
-        const int i = tid + 256 * k, c = i >> 6, j = i & 63;
+        const int i = tid + NT * k, c = i >> 6, j = i & 63;
         wl[k] = a.wqkv[(size_t)c * LC3 + (j < 32 ? LHID + h * LDH + j : 2 * LHID + h * LDH + (j - 32))];
     }
 #pragma unroll
-    for (int k = 0; k < NWL; ++k) Wl[tid + 256 * k] = wl[k];
+    for (int k = 0; k < NWL; ++k) Wl[tid + NT * k] = wl[k];
     float mean, rstd;
     partials_finish(a.xf, b, 0, pp, &mean, &rstd);
     if (tid < C) {
@@ -344,11 +349,11 @@ __global__ void __launch_bounds__(256) la_ctx_fast_kernel(const LaArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) cacc[r] = 0.f;
     float m_run = -INFINITY, z_run = 0.f;
-    for (int rb = wave; rb < nblk; rb += 4) {
+    for (int rb = wave; rb < nblk; rb += NW) {
         const int r0 = rb * 32;
         store_x<NQ>(a, Ab, Bb, xw, XS, r0, lane, pre);
         __builtin_amdgcn_wave_barrier();
-        if (rb + 4 < nblk) fetch_x<NQ>(a, b, r0 + 128, lane, pre);
+        if (rb + NW < nblk) fetch_x<NQ>(a, b, r0 + 32 * NW, lane, pre);
         f32x16 ak, av;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { ak[r] = 0.f; av[r] = 0.f; }
@@ -388,12 +393,12 @@ __global__ void __launch_bounds__(256) la_ctx_fast_kernel(const LaArgs a) {
     __syncthreads();
     if (half == 0) { mz[(wave * 2) * 32 + l31] = m_run; mz[(wave * 2 + 1) * 32 + l31] = z_run; }
     __syncthreads();
-    if (tid < 128) {
+    if (tid < 32 * NW) {
         const int w = tid >> 5, d = tid & 31;
         float M = mz[d];
-        for (int k = 1; k < 4; ++k) M = fmaxf(M, mz[(k * 2) * 32 + d]);
+        for (int k = 1; k < NW; ++k) M = fmaxf(M, mz[(k * 2) * 32 + d]);
         float Z = 0.f;
-        for (int k = 0; k < 4; ++k) Z += mz[(k * 2 + 1) * 32 + d] * __expf(mz[(k * 2) * 32 + d] - M);
+        for (int k = 0; k < NW; ++k) Z += mz[(k * 2 + 1) * 32 + d] * __expf(mz[(k * 2) * 32 + d] - M);
         sct[w * 32 + d] = __expf(mz[(w * 2) * 32 + d] - M) / Z;
     }
     __syncthreads();
@@ -403,9 +408,11 @@ __global__ void __launch_bounds__(256) la_ctx_fast_kernel(const LaArgs a) {
         Et[(wave * 32 + d) * PS + l31] = cacc[r] * sct[wave * 32 + d];
     }
     __syncthreads();
-    for (int i = tid; i < LDH * LDH; i += 256) {
+    for (int i = tid; i < LDH * LDH; i += NT) {
         const int d = i >> 5, e = i & 31;
-        a.ctx[((size_t)(b * LHEADS + h) * LDH + d) * LDH + e] = (Et[d * PS + e] + Et[(32 + d) * PS + e]) + (Et[(64 + d) * PS + e] + Et[(96 + d) * PS + e]);
+        float v = (Et[d * PS + e] + Et[(32 + d) * PS + e]) + (Et[(64 + d) * PS + e] + Et[(96 + d) * PS + e]);
+        if (NW == 8) v += (Et[(128 + d) * PS + e] + Et[(160 + d) * PS + e]) + (Et[(192 + d) * PS + e] + Et[(224 + d) * PS + e]);
+        a.ctx[((size_t)(b * LHEADS + h) * LDH + d) * LDH + e] = v;
     }
 }
 
@@ -567,20 +574,31 @@ __global__ void __launch_bounds__(256) la_apply_fast_kernel(const LaArgs a, int 
     }
 }
 
-static size_t la_ctx_fast_lds(int C) { return (size_t)(2 * C + C * 64 + 4 * 32 * (C + 1) + 2 * 4 * 32 * PS + 128 + 256) * sizeof(float); }
+static size_t la_ctx_fast_lds(int C, int NW) { return (size_t)(2 * C + C * 64 + NW * 32 * (C + 1) + 2 * NW * 32 * PS + 32 * NW + 64 * NW) * sizeof(float); }
+static int la_ctx_waves(int n) {      // eight waves once every one of them has a 32-position block of its own (FLOCODER_AMD_LA_CTX_WAVES=4: never)
+    static const int forced = [] { const char* e = std::getenv("FLOCODER_AMD_LA_CTX_WAVES"); return e ? std::atoi(e) : 0; }();
+    if (forced == 4 || forced == 8) return (forced == 8 && n >= 256) ? 8 : 4;
+    return n >= 256 ? 8 : 4;
+}
 static size_t la_apply_fast_lds(int C, int CT) {
     const int XS = C + 1 > PS ? C + 1 : PS;
     return (size_t)(2 * C + C * LHID + LHID * CT * 32 + LHEADS * LDH * PS + 4 * 32 * XS) * sizeof(float);
 }
 template <int NQ>
 static int launch_fast(const LaArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(la_ctx_fast_kernel<NQ>, dim3(LHEADS, a.B), dim3(256), la_ctx_fast_lds(a.C), s, a);
+    if (la_ctx_waves(a.n) == 8) hipLaunchKernelGGL((la_ctx_fast_kernel<NQ, 8>), dim3(LHEADS, a.B), dim3(512), la_ctx_fast_lds(a.C, 8), s, a);
+    else hipLaunchKernelGGL((la_ctx_fast_kernel<NQ, 4>), dim3(LHEADS, a.B), dim3(256), la_ctx_fast_lds(a.C, 4), s, a);
     FC_HIP(hipGetLastError());
     const int T = linattn_fused_tiles(a.n);
     const float n_t = linattn_fused_nt(a.n, a.C);
     const int tiles = cdiv(a.n, 128);
     int gx = tiles;                                   // two tiles per workgroup once that still leaves >= 256 workgroups
-    if (tiles >= 2 && (tiles / 2) * a.B >= 256) gx = tiles / 2;
+    // Round 4: one 128-position tile per workgroup again.  Two tiles per workgroup (round 2: half the weight staging) leave 256 workgroups of
+    // four waves -- one wave per SIMD, nothing to cover the LDS round trips between the five dependent phases of a head; with one tile each,
+    // two workgroups share a CU (67 KB of LDS each).  Measured per module at n = 1024: 55.0 -> 51.0 and 50.9 -> 47.0 us; sampler 793 -> 805
+    // samples/s on one box (791 / 788 with four-wave la_ctx and two tiles).  FLOCODER_AMD_LA_APPLY_GX=half: the old form.
+    static const bool gx_half = [] { const char* e = std::getenv("FLOCODER_AMD_LA_APPLY_GX"); return e && std::string(e) == "half"; }();
+    if (gx_half && tiles >= 2 && (tiles / 2) * a.B >= 256) gx = tiles / 2;
     const dim3 grid(gx, a.B);
     if (a.C <= 32) hipLaunchKernelGGL((la_apply_fast_kernel<NQ, 1>), grid, dim3(256), la_apply_fast_lds(a.C, 1), s, a, T, n_t);
     else hipLaunchKernelGGL((la_apply_fast_kernel<NQ, 2>), grid, dim3(256), la_apply_fast_lds(a.C, 2), s, a, T, n_t);
@@ -589,7 +607,8 @@ static int launch_fast(const LaArgs& a, hipStream_t s) {
 }
 template <int NQ>
 static int init_fast() {
-    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_ctx_fast_kernel<NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_ctx_fast_kernel<NQ, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_ctx_fast_kernel<NQ, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_apply_fast_kernel<NQ, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_apply_fast_kernel<NQ, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     return FC_OK;
