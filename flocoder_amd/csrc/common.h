@@ -222,6 +222,7 @@ struct LaArgs {
     SrcXform xf;                   // mode 1, G = 1: statistics / gamma / beta of fn.norm
     const float* wqkv = nullptr;   // packed [C][3*128]
     const float* wout = nullptr;   // packed [128][C]
+    const float* wqkv4 = nullptr;  // wqkv in the k-step-quad layout [C/8][half][384][4] (pack kind 6) or null: the eight-wave la_head reads it
     const float* bout = nullptr;   // [C]
     float* ctx = nullptr;          // [B][4][32][32] scratch
     float* y = nullptr;            // NHWC [B][n][C]: to_out.0 output (before to_out.1's GroupNorm)

@@ -12,6 +12,9 @@
 //
 // A one-launch form with a workgroup per sample was measured first: 24 - 37 us per module, bound by one CU's fp32 matrix pipe
 // (6.3 MFLOP of to_qkv per sample at 256 FLOP/clk = 10 us).  Splitting by head puts a sample on four CUs.
+#include <cstdlib>
+#include <string>
+
 #include "common.h"
 #include "stats_dev.h"
 
@@ -392,6 +395,286 @@ __global__ void __launch_bounds__(256) la_head_kernel(const LaArgs a) {
     }
 }
 
+// ---- eight-wave form (round 4) ------------------------------------------------------------------------------------------------
+// The same module with 512 threads: the q / k / v projections are K-split over two waves each (waves 0-2: channels [0, C/2), waves 3-5:
+// [C/2, C)), the halves meet in LDS; waves 6-7 bring the head's rows of to_out.0 into LDS.  The weights come from the k-step-quad copy
+// (pack kind 6: a lane's B operands of four k-steps are ONE 16-byte load, four loads per round of 16 k-steps instead of sixteen), two
+// register sets swapping roles.  Why: with four waves a (sample, head) workgroup -- the only one on its CU -- ran the projections on
+// three waves of one SIMD each, 4 KB of weights in flight per wave, and the phase took 9.3 of the kernel's ~15 us for 3.4 us of matrix
+// work (round-3 knock-outs): it waits for weights.  Twice the waves stream twice the bytes at a time and halve the dependent MFMA chain.
+constexpr int PQ = 4;   // 16-byte weight quads per round = 16 k-steps
+__device__ __forceinline__ void wfetch4(const float4* __restrict__ wq, int blk_stride, int blk0, float4 (&w)[PQ]) {
+#pragma unroll
+    for (int i = 0; i < PQ; ++i) w[i] = wq[(size_t)(blk0 + i) * blk_stride];
+}
+template <int MT>
+__device__ __forceinline__ void gemm_stream4(const float* __restrict__ A, int lda, const float4* __restrict__ wq, int blk_stride, int blk0, int nblk, int l31, int half,
+                                             float4 (&cur)[PQ], f32x16 (&acc)[MT]) {
+    float4 nxt[PQ];
+    auto round = [&](int b0, float4 (&wc)[PQ], float4 (&wn)[PQ]) {
+        wfetch4(wq, blk_stride, b0 + PQ < blk0 + nblk ? b0 + PQ : b0, wn);      // unconditional: the last round re-requests itself
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < PQ; ++i) {
+            const float* ap = A + 8 * (b0 + i) + half;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float* ar = ap + (mt * 32 + l31) * lda;
+                acc[mt] = FC_MFMA(ar[0], wc[i].x, acc[mt]);
+                acc[mt] = FC_MFMA(ar[2], wc[i].y, acc[mt]);
+                acc[mt] = FC_MFMA(ar[4], wc[i].z, acc[mt]);
+                acc[mt] = FC_MFMA(ar[6], wc[i].w, acc[mt]);
+            }
+        }
+    };
+    const int rounds = nblk / PQ;
+    for (int r = 0; r < rounds; r += 2) {
+        round(blk0 + r * PQ, cur, nxt);
+        if (r + 1 < rounds) round(blk0 + (r + 1) * PQ, nxt, cur);
+    }
+}
+
+template <int MT, bool FULL>
+__global__ void __launch_bounds__(512) la_head8_kernel(const LaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int NP = MT * 32, NT = 512, XP8 = XPT / 2;
+    const int C = a.C, n = a.n, XS = C + 1, WS = C + 32, CT = C >> 5;
+    float* Ab = sm;
+    float* Bb = Ab + C;
+    float* ctxl = Bb + C;            // [32][PS]
+    float* qkv = ctxl + DH * PS;     // [NP][QS]: q | k | v of this head
+    float* os = qkv + NP * QS;       // [NP][PS]
+    float* Wo = os + NP * PS;        // [32][WS]: rows 32h .. 32h+32 of to_out.0
+    float* xs = Wo + DH * WS;        // [NP][XS]
+    float* red = xs + NP * XS;       // [3][MT][16][64]: the upper K-halves' partial accumulators
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const float* xb = a.x + (size_t)b * n * C;
+    const int proj = wave % 3, part = wave / 3;          // waves 0-5: projection, K half; waves 6-7 (part == 2): to_out rows
+    const int nb = C >> 3, nbh = nb >> 1;                // 8-channel blocks: all, per K half
+    // every cold operand first: the first round of weights, the x tile, the norm parameters -- then the statistics
+    const float4* wq = reinterpret_cast<const float4*>(a.wqkv4) + (size_t)half * C3 + proj * HID + h * DH + l31;
+    float4 cur[PQ];
+    if (part < 2) wfetch4(wq, 2 * C3, part * nbh, cur);
+    const int q4 = C >> 2, nx = n * q4;
+    float4 xr[XP8];
+#pragma unroll
+    for (int k = 0; k < XP8; ++k) {
+        const int i = tid + NT * k;
+        xr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < nx) xr[k] = *reinterpret_cast<const float4*>(xb + (size_t)i * 4);
+    }
+    const float pg = tid < C ? a.xf.gamma[tid] : 0.f, pbt = tid < C ? a.xf.beta[tid] : 0.f;     // C <= 512 = threads
+    float mean, rstd;
+    combine_partials(a.xf, b, 0, &mean, &rstd);
+    if (tid < C) {
+        const float sc = rstd * pg;
+        Ab[tid] = sc;
+        Bb[tid] = pbt - mean * sc;
+    }
+    for (int i = tid + nx; i < NP * q4; i += NT) {     // padding rows
+        const int row = i / q4, c = (i - row * q4) * 4;
+        float* d = xs + row * XS + c;
+        d[0] = 0.f; d[1] = 0.f; d[2] = 0.f; d[3] = 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < XP8; ++k) {
+        const int i = tid + NT * k;
+        if (i < nx) {
+            const int row = i / q4, c = (i - row * q4) * 4;
+            float4 v = xr[k];
+            v.x = Ab[c] * v.x + Bb[c]; v.y = Ab[c + 1] * v.y + Bb[c + 1]; v.z = Ab[c + 2] * v.z + Bb[c + 2]; v.w = Ab[c + 3] * v.w + Bb[c + 3];
+            float* d = xs + row * XS + c;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+    if (part < 2) {
+        gemm_stream4<MT>(xs, XS, wq, 2 * C3, part * nbh, nbh, l31, half, cur, acc);
+        if (part == 1) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((proj * MT + mt) * 16 + r) * 64 + lane] = acc[mt][r];
+        }
+    } else {
+        // the head's 32 rows of to_out.0 on two waves, sixteen 16-byte loads in flight per lane
+        const float* wo = a.wout + (size_t)h * DH * C;
+        const int tot = DH * q4, t2 = tid - 384;       // 0..127
+        for (int i0 = t2; i0 < tot; i0 += 128 * 16) {
+            float4 wv[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int i = i0 + 128 * k;
+                wv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < tot) { const int r = i / q4, c = (i - r * q4) * 4; wv[k] = *reinterpret_cast<const float4*>(wo + (size_t)r * C + c); }
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int i = i0 + 128 * k;
+                if (i < tot) { const int r = i / q4, c = (i - r * q4) * 4; *reinterpret_cast<float4*>(Wo + r * WS + c) = wv[k]; }
+            }
+        }
+    }
+    __syncthreads();
+    if (part == 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] += red[((proj * MT + mt) * 16 + r) * 64 + lane];
+        if (FULL) {
+            if (wave == 0) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][r] *= 0.17677669529663687f;
+            }
+        } else if (wave == 0) {   // q: softmax over the head's 32 channels (the 32 lanes of a half-wave), * dim_head^-0.5
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[mt][r];
+                    float m = v;
+                    m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
+                    m = fmaxf(m, __shfl_xor(m, 8)); m = fmaxf(m, __shfl_xor(m, 16));
+                    const float e = __expf(v - m);
+                    float s_ = e;
+                    s_ += __shfl_xor(s_, 1); s_ += __shfl_xor(s_, 2); s_ += __shfl_xor(s_, 4); s_ += __shfl_xor(s_, 8); s_ += __shfl_xor(s_, 16);
+                    acc[mt][r] = e * (0.17677669529663687f / s_);
+                }
+        } else if (wave == 1) {   // k: softmax over the positions = the 16*MT rows here and the 16*MT of lane ^ 32
+            float m = -INFINITY;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) if (mt * 32 + acc_row(r, half) < n) m = fmaxf(m, acc[mt][r]);
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float s_ = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = (mt * 32 + acc_row(r, half) < n) ? __expf(acc[mt][r] - m) : 0.f;
+                    acc[mt][r] = e;
+                    s_ += e;
+                }
+            s_ += __shfl_xor(s_, 32);
+            const float f = 1.0f / s_;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][r] *= f;
+        }
+        float* dst = qkv + wave * DH + l31;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(mt * 32 + acc_row(r, half)) * QS] = acc[mt][r];
+    }
+    __syncthreads();
+
+    if (FULL) {
+        constexpr int PSS = NP + 1;
+        float* ps = xs;
+        if (wave < MT) {
+            f32x16 st[MT];
+#pragma unroll
+            for (int nt = 0; nt < MT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[nt][r] = 0.f;
+            const float* qp = qkv + (wave * 32 + l31) * QS;
+#pragma unroll 4
+            for (int s_ = 0; s_ < DH / 2; ++s_) {
+                const float qa = qp[2 * s_ + half];
+#pragma unroll
+                for (int nt = 0; nt < MT; ++nt) st[nt] = FC_MFMA(qa, qkv[(nt * 32 + l31) * QS + DH + 2 * s_ + half], st[nt]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float m = -INFINITY;
+#pragma unroll
+                for (int nt = 0; nt < MT; ++nt) if (nt * 32 + l31 < n) m = fmaxf(m, st[nt][r]);
+                m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
+                m = fmaxf(m, __shfl_xor(m, 8)); m = fmaxf(m, __shfl_xor(m, 16));
+                float e[MT], sum = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < MT; ++nt) { e[nt] = (nt * 32 + l31 < n) ? __expf(st[nt][r] - m) : 0.f; sum += e[nt]; }
+                sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8); sum += __shfl_xor(sum, 16);
+                const float inv = 1.0f / sum;
+#pragma unroll
+                for (int nt = 0; nt < MT; ++nt) ps[(wave * 32 + acc_row(r, half)) * PSS + nt * 32 + l31] = e[nt] * inv;
+            }
+        }
+        __syncthreads();
+        if (wave < MT) {
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.f;
+            const float* pp = ps + (wave * 32 + l31) * PSS;
+            const float* vp = qkv + 2 * DH + l31;
+#pragma unroll 4
+            for (int s_ = 0; s_ < NP / 2; ++s_) o = FC_MFMA(pp[2 * s_ + half], vp[(2 * s_ + half) * QS], o);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) os[(wave * 32 + acc_row(r, half)) * PS + l31] = o[r];
+        }
+        __syncthreads();
+    } else {
+        if (wave == 0) {
+            f32x16 c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[r] = 0.f;
+            const float* kp = qkv + DH + l31;
+            const float* vp = qkv + 2 * DH + l31;
+#pragma unroll 4
+            for (int s_ = 0; s_ < NP / 2; ++s_) c = FC_MFMA(kp[(2 * s_ + half) * QS], vp[(2 * s_ + half) * QS], c);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ctxl[acc_row(r, half) * PS + l31] = c[r];
+        }
+        __syncthreads();
+        if (wave < MT) {
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.f;
+            const float* qp = qkv + (wave * 32 + l31) * QS;
+#pragma unroll 4
+            for (int s_ = 0; s_ < DH / 2; ++s_) o = FC_MFMA(qp[2 * s_ + half], ctxl[(2 * s_ + half) * PS + l31], o);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) os[(wave * 32 + acc_row(r, half)) * PS + l31] = o[r];
+        }
+        __syncthreads();
+    }
+    // this head's share of to_out.0: part[b][h][n][C] = o . Wout[32h .. 32h+32, :]; wave -> channel tiles wave, wave + 8
+    float* pb = a.part + ((size_t)b * HEADS + h) * n * C;
+    for (int ct = wave; ct < CT; ct += 8) {
+        f32x16 y[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[mt][r] = 0.f;
+#pragma unroll 4
+        for (int s_ = 0; s_ < DH / 2; ++s_) {
+            const float w = Wo[(2 * s_ + half) * WS + ct * 32 + l31];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) y[mt] = FC_MFMA(os[(mt * 32 + l31) * PS + 2 * s_ + half], w, y[mt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mt * 32 + acc_row(r, half);
+                if (row >= n) continue;
+                pb[(size_t)row * C + ct * 32 + l31] = y[mt][r];
+            }
+    }
+}
+
 __device__ __forceinline__ float block_sum_j(float v, float* red /*[JT/64]*/) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -469,10 +752,21 @@ size_t head_lds(int n, int C) {
 }
 }  // namespace
 
+// the eight-wave form needs the k-step-quad copy of to_qkv, whole rounds of 16 k-steps in each K half (C % 64 == 0), C <= 512 threads, no tickets
+static bool head8_ok(const LaArgs& a) {
+    static const bool off = [] { const char* e = std::getenv("FLOCODER_AMD_LA_HEAD"); return e && std::string(e) == "4"; }();
+    return !off && a.wqkv4 && !a.tickets && (a.C % 64) == 0 && a.C <= 512 && (size_t)a.n * a.C <= (size_t)(XPT / 2) * 512 * 4 &&
+           head_lds(a.n, a.C) + (size_t)3 * (a.n <= 32 ? 1 : 2) * 1024 * sizeof(float) <= 160 * 1024;
+}
 template <bool FULL>
 static void launch_pair(const LaArgs& a, hipStream_t s) {
     const size_t lds = head_lds(a.n, a.C);
-    if (a.n <= 32) hipLaunchKernelGGL((la_head_kernel<1, FULL>), dim3(HEADS, a.B), dim3(256), lds, s, a);
+    if (head8_ok(a)) {
+        const size_t lds8 = lds + (size_t)3 * (a.n <= 32 ? 1 : 2) * 1024 * sizeof(float);
+        if (a.n <= 32) hipLaunchKernelGGL((la_head8_kernel<1, FULL>), dim3(HEADS, a.B), dim3(512), lds8, s, a);
+        else hipLaunchKernelGGL((la_head8_kernel<2, FULL>), dim3(HEADS, a.B), dim3(512), lds8, s, a);
+    }
+    else if (a.n <= 32) hipLaunchKernelGGL((la_head_kernel<1, FULL>), dim3(HEADS, a.B), dim3(256), lds, s, a);
     else hipLaunchKernelGGL((la_head_kernel<2, FULL>), dim3(HEADS, a.B), dim3(256), lds, s, a);
     if (a.tickets) return;          // the last workgroup of every sample has done la_join's work
     const int total4 = a.n * a.C / 4;
@@ -487,6 +781,10 @@ int linattn_sample_init() {
     FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_head_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_head_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_head_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_head8_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_head8_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_head8_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(la_head8_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return FC_OK;
 }
 

@@ -277,6 +277,7 @@ struct Builder : PlanBuilder {
         LaArgs a;
         a.x = x.p; a.xf = xf_of(gn1, 1, u->R(p + ".fn.norm.weight"), u->R(p + ".fn.norm.bias"));
         a.wqkv = u->P(p + ".fn.fn.to_qkv.weight"); a.wout = u->P(p + ".fn.fn.to_out.0.weight"); a.bout = u->R(p + ".fn.fn.to_out.0.bias");
+        a.wqkv4 = u->P8(p + ".fn.fn.to_qkv.weight");
         a.g2 = u->R(p + ".fn.fn.to_out.1.weight"); a.b2 = u->R(p + ".fn.fn.to_out.1.bias"); a.out = out.p;
         a.n = n; a.C = x.C; a.heads = heads;
         a.part = dmalloc((size_t)B * heads * n * x.C);
@@ -297,6 +298,7 @@ struct Builder : PlanBuilder {
             LaArgs a;
             a.x = x.p; a.xf = xf_of(gn1, 1, u->R("mid_attn.fn.norm.weight"), u->R("mid_attn.fn.norm.bias"));
             a.wqkv = u->P("mid_attn.fn.fn.to_qkv.weight"); a.wout = u->P("mid_attn.fn.fn.to_out.weight"); a.bout = u->R("mid_attn.fn.fn.to_out.bias");
+            a.wqkv4 = u->P8("mid_attn.fn.fn.to_qkv.weight");
             a.out = out.p; a.n = n; a.C = x.C; a.heads = heads;
             a.part = dmalloc((size_t)B * heads * n * x.C);
             a.tickets = la_tickets(n, x.C);
