@@ -18,6 +18,7 @@
 
 #include "plan.h"
 #include "unet_priv.h"
+#include "unet_sample.h"
 
 namespace fc {
 
@@ -380,6 +381,169 @@ static void free_plan(fc_unet* u) {
     u->tail_failed = false;
 }
 
+// ---- one workgroup per sample (unet_sample.hip): the forward as a program over LDS-resident activations -------------------------------
+// Used for inference plans of models whose whole per-sample state fits a CU's LDS (the dim-8 inpainting flow at 4x8x8: BASELINE config 5).
+// Returns FC_OK and leaves ONE launch in the plan, or 1 when the model does not qualify (the caller then builds the ordinary plan).
+static int build_sample_plan(fc_unet* u, Plan* pl, Builder& b, int H, int W) {
+    // OFF unless FLOCODER_AMD_SAMPLE_KERNEL=1 (round 4: built, parity-green, and SLOWER than the plan it was meant to replace -- 1373 us per
+    // evaluation at the dim-8 / 4x8x8 shape against 842 us for the 115 launches: with four waves on a CU nothing covers a step's dependent
+    // round trips to L2 for its weights, and 120 steps of 5-50 us each add up; profiles/r04_sample_kernel_stamps.txt)
+    static const bool off = [] { const char* e = std::getenv("FLOCODER_AMD_SAMPLE_KERNEL"); return !(e && std::string(e) == "1"); }();
+    const fc_unet_config& c = u->cfg;
+    const int L = c.n_levels, dim = c.dim, ch = c.channels, G = c.groups, heads = u->heads;
+    if (off || u->keep_all || G > 8 || heads != 4 || u->nchains > 1) return 1;
+    const std::vector<int>& cs = u->chans;
+    struct T { int off = -1, C = 0, H = 0, W = 0; };
+    std::vector<SStep> prog;
+    int top = 0, peak = 0;
+    double flops = 0.0;
+    auto alloc = [&](int floats) { const int o = top; top += (floats + 3) & ~3; if (top > peak) peak = top; return o; };
+    auto tensor = [&](int C, int h, int w) { T t; t.C = C; t.H = h; t.W = w; t.off = alloc(C * h * w); return t; };
+    auto conv = [&](const T& x, const T* x1, const T& out, const std::string& name, int KS, int pad, int stride, int ups, int act, int res, int guard, bool bias = true) {
+        SStep s;
+        s.op = S_CONV; s.guard = guard; s.in0 = x.off; s.C0 = x.C; s.in1 = x1 ? x1->off : -1; s.C1 = x1 ? x1->C : 0;
+        s.out = out.off; s.Cout = out.C; s.Hi = x.H; s.Wi = x.W; s.Ho = out.H; s.Wo = out.W; s.KS = KS; s.pad = pad; s.stride = stride; s.ups = ups;
+        s.act = act; s.res = res; s.w = u->P(name + ".weight"); s.bias = bias ? u->R(name + ".bias") : nullptr;
+        prog.push_back(s);
+        return 2.0 * out.H * out.W * KS * KS * (double)(s.C0 + s.C1) * out.C;
+    };
+    auto norm = [&](const T& x, const T& out, const std::string& name, int groups, int ss_off, int act, int res) {
+        SStep s;
+        s.op = S_NORM; s.in0 = x.off; s.out = out.off; s.C0 = x.C; s.Hi = x.H; s.Wi = x.W; s.G = groups; s.ss_off = ss_off; s.act = act; s.res = res;
+        s.gamma = u->R(name + ".weight"); s.beta = u->R(name + ".bias");
+        prog.push_back(s);
+    };
+    auto copy = [&](const T& x, const T& out, int guard) {
+        SStep s;
+        s.op = S_COPY; s.guard = guard; s.in0 = x.off; s.out = out.off; s.Cout = x.C * x.H * x.W;
+        prog.push_back(s);
+    };
+    auto resblock = [&](const std::string& p, const T& x, const T* skip, int cout) {
+        T out = tensor(cout, x.H, x.W);
+        const int mark = top, cin = x.C + (skip ? skip->C : 0);
+        T h1 = tensor(cout, x.H, x.W), a1 = tensor(cout, x.H, x.W), h2 = tensor(cout, x.H, x.W);
+        flops += conv(x, skip, h1, p + ".block1.proj", 3, 1, 1, 0, 0, -1, 0);
+        norm(h1, a1, p + ".block1.norm", G, u->ss_off.at(p), 1, -1);
+        flops += conv(a1, nullptr, h2, p + ".block2.proj", 3, 1, 1, 0, 0, -1, 0);
+        int res = x.off;
+        if (cin != cout) {
+            T rb = tensor(cout, x.H, x.W);
+            flops += conv(x, skip, rb, p + ".res_conv", 1, 0, 1, 0, 0, -1, 0);
+            res = rb.off;
+        }
+        norm(h2, out, p + ".block2.norm", G, -1, 1, res);
+        top = mark;
+        return out;
+    };
+    auto attention = [&](const std::string& p, const T& x, bool full) {
+        T out = tensor(x.C, x.H, x.W);
+        const int mark = top, n = x.H * x.W, hid = heads * 32;
+        SStep s;
+        s.op = full ? S_ATTN : S_LINATTN; s.in0 = x.off; s.out = out.off; s.C0 = x.C; s.Hi = x.H; s.Wi = x.W;
+        s.scratch = alloc(2 * n * x.C + 3 * n * 32 + (full ? n * n : 32 * 32) + n * 32);
+        s.gamma = u->R(p + ".fn.norm.weight"); s.beta = u->R(p + ".fn.norm.bias");
+        s.w = u->P(p + ".fn.fn.to_qkv.weight");
+        if (full) { s.w2 = u->P(p + ".fn.fn.to_out.weight"); s.b2 = u->R(p + ".fn.fn.to_out.bias"); }
+        else {
+            s.w2 = u->P(p + ".fn.fn.to_out.0.weight"); s.b2 = u->R(p + ".fn.fn.to_out.0.bias");
+            s.g2 = u->R(p + ".fn.fn.to_out.1.weight"); s.be2 = u->R(p + ".fn.fn.to_out.1.bias");
+        }
+        prog.push_back(s);
+        flops += 2.0 * n * (double)x.C * 3 * hid + (full ? 2.0 * 2.0 * n * n * 32 * heads : 2.0 * 2 * n * 32 * 32 * heads) + 2.0 * n * (double)hid * x.C;
+        top = mark;
+        return out;
+    };
+    T xin = tensor(ch, H, W), mask;
+    if (c.mask_cond) mask = tensor(ch, H, W);
+    T xi = tensor(dim, H, W), x0 = xi;
+    flops += conv(xin, nullptr, xi, "init_conv", 1, 0, 1, 0, 0, -1, 0);
+    if (c.mask_cond) {                                   // unet.py:298-305: replaces x when a mask is given that is not all ones
+        x0 = tensor(dim, H, W);
+        const int mark = top;
+        T f1 = tensor(2 * dim, H, W), f2 = tensor(2 * dim, H, W);
+        conv(xi, &mask, f1, "mask_fusion_conv.0", 5, 2, 1, 0, 1, -1, 2);
+        conv(f1, nullptr, f2, "mask_fusion_conv.2", 3, 1, 1, 0, 1, -1, 2);
+        conv(f2, nullptr, x0, "mask_fusion_conv.4", 3, 1, 1, 0, 0, -1, 2);
+        copy(xi, x0, 5);
+        flops += 2.0 * H * W * (25.0 * (dim + ch) * 2 * dim + 9.0 * 2 * dim * 2 * dim + 9.0 * 2 * dim * dim);
+        top = mark;
+    }
+    auto inject = [&](const std::string& name, const T& x) {       // x + SiLU(conv3x3(cat[x, bilinear(mask)])), unet.py:336-340,360-364
+        T out = tensor(x.C, x.H, x.W);
+        const int mark = top;
+        T mr = tensor(ch, x.H, x.W);
+        SStep s;
+        s.op = S_BILINEAR; s.guard = 1; s.in0 = mask.off; s.out = mr.off; s.C0 = ch; s.Hi = H; s.Wi = W; s.Ho = x.H; s.Wo = x.W;
+        prog.push_back(s);
+        flops += conv(x, &mr, out, name, 3, 1, 1, 0, 1, x.off, 1);
+        copy(x, out, 3);
+        top = mark;
+        return out;
+    };
+    std::vector<T> skips;
+    T x = x0;
+    for (int i = 0; i < L; ++i) {
+        const std::string p = "downs." + std::to_string(i);
+        x = resblock(p + ".0", x, nullptr, cs[i]);
+        skips.push_back(x);
+        x = resblock(p + ".1", x, nullptr, cs[i]);
+        x = attention(p + ".2", x, false);
+        skips.push_back(x);
+        if (c.mask_cond && i < 2) x = inject("down_mask_fusions." + std::to_string(i) + ".0", x);
+        if (i == L - 1) { T o = tensor(cs[i + 1], x.H, x.W); flops += conv(x, nullptr, o, p + ".3", 3, 1, 1, 0, 0, -1, 0); x = o; }
+        else { T o = tensor(cs[i + 1], x.H / 2, x.W / 2); flops += conv(x, nullptr, o, p + ".3.1", 2, 0, 2, 0, 0, -1, 0); x = o; }
+    }
+    x = resblock("mid_block1", x, nullptr, cs[L]);
+    x = attention("mid_attn", x, true);
+    x = resblock("mid_block2", x, nullptr, cs[L]);
+    for (int i = 0; i < L; ++i) {
+        const std::string p = "ups." + std::to_string(i);
+        const int din = cs[L - 1 - i], dout = cs[L - i];
+        T s1 = skips.back(); skips.pop_back();
+        x = resblock(p + ".0", x, &s1, dout);
+        T s2 = skips.back(); skips.pop_back();
+        x = resblock(p + ".1", x, &s2, dout);
+        x = attention(p + ".2", x, false);
+        if (c.mask_cond && i < 2) x = inject("up_mask_fusions." + std::to_string(i) + ".0", x);
+        if (i == L - 1) { T o = tensor(din, x.H, x.W); flops += conv(x, nullptr, o, p + ".3", 3, 1, 1, 0, 0, -1, 0); x = o; }
+        else { T o = tensor(din, x.H * 2, x.W * 2); flops += conv(x, nullptr, o, p + ".3.1", 3, 1, 1, 1, 0, -1, 0); x = o; }
+    }
+    x = resblock("final_res_block", x, &x0, dim);
+    T v = tensor(ch, H, W);
+    flops += conv(x, nullptr, v, "final_conv", 1, 0, 1, 0, 0, -1, 0);
+    // every tensor at most four elements per thread, attention at most 64 channels / 64 keys (unet_sample.hip's register and staging budgets)
+    for (const SStep& s : prog) {
+        if (s.op == S_CONV && s.Ho * s.Wo * s.Cout > 1024) return 1;
+        if (s.op == S_NORM && s.Hi * s.Wi * s.C0 > 1024) return 1;
+        if ((s.op == S_ATTN || s.op == S_LINATTN) && (s.C0 > 64 || (s.C0 & 3))) return 1;
+        if (s.op == S_ATTN && s.Hi * s.Wi > 64) return 1;
+        if (s.op == S_CONV && (s.Cout & 3)) return 1;
+    }
+    top = peak;                                           // behind every temporary (they were released, not forgotten)
+    const int wbuf_off = alloc(2 * 4096), prog_off = alloc((int)(prog.size() * sizeof(SStep) / 4) + 4);
+    const size_t lds = (size_t)peak * sizeof(float);
+    if (lds > 150 * 1024) return 1;                       // the sample does not fit a CU: ordinary plan
+    FC_TRY(unet_sample_init());
+    SStep* dev = reinterpret_cast<SStep*>(b.dmalloc((prog.size() * sizeof(SStep) + 3) / 4 + 4));
+    unsigned* done = reinterpret_cast<unsigned*>(b.dmalloc(4));
+    if (b.err) return b.err;
+    FC_HIP(hipMemcpy(dev, prog.data(), prog.size() * sizeof(SStep), hipMemcpyHostToDevice));
+    FC_HIP(hipMemset(done, 0, 4 * sizeof(unsigned)));
+    SampleArgs a;
+    a.prog = dev; a.nsteps = (int)prog.size(); a.S = u->S; a.ss = pl->ss; a.ch = ch; a.HW = H * W;
+    a.x_off = xin.off; a.mask_off = mask.off; a.v_off = v.off; a.done = done; a.wbuf_off = wbuf_off; a.prog_off = prog_off;
+    const bool mask_cond = c.mask_cond != 0;
+    b.scope = "unet (one workgroup per sample)";
+    b.push([a, lds, mask_cond](const FwdCtx& cx, hipStream_t s) {
+        SampleArgs q = a;
+        q.x = cx.x; q.x_mod = cx.x_mod; q.mask = mask_cond ? cx.mask : nullptr; q.mask_fuse = cx.mask_fuse;
+        q.ss_all = cx.fetch.all; q.evalc = cx.fetch.all ? cx.fetch.evalc : nullptr; q.rows = cx.B; q.out = cx.out; q.euler = cx.euler;
+        q.stamps = conv_stamp_buffer();
+        return unet_sample_launch(q, cx.B, lds, s);
+    }, "unet_sample", flops);
+    return FC_OK;
+}
+
 static int build_plan(fc_unet* u, Plan* pl, int maxB, int H, int W) {
     const fc_unet_config& c = u->cfg;
     const int L = c.n_levels, dim = c.dim, ch = c.channels, HW = H * W;
@@ -421,6 +585,15 @@ static int build_plan(fc_unet* u, Plan* pl, int maxB, int H, int W) {
         pl->side_ops = (int)pl->ops.size();   // the conditioning chain reads only time / class ids: it runs beside init_conv and the first conv1
     }
 
+    {   // small models: the whole forward of a sample in one workgroup (unet_sample.hip); 1 = does not qualify
+        const int r = build_sample_plan(u, pl, b, H, W);
+        if (r != 1) {
+            if (r != FC_OK) return r;
+            pl->join_at = (int)pl->ops.size();
+            pl->maxB = maxB; pl->H = H; pl->W = W;
+            return FC_OK;
+        }
+    }
     // -- init_conv (unet.py:295) and mask fusion (unet.py:298-305) --
     Act x0 = b.act(dim, H, W);
     pl->named["init"] = x0;

@@ -110,6 +110,8 @@ class FlowTrainer:
     """One object per rank.  Owns the flat parameter / gradient / Adam / EMA vectors (library table layout); the model's
     parameters become views into the flat parameter vector, so ``model.state_dict()`` always shows the trained weights."""
 
+    FLAG_TAIL = 8          # floats behind the gradient table (five used; keeps the buffer's length a multiple of four)
+
     def __init__(self, model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 1.0, ema_decay: float = 0.999,
                  t_eps: float = 1e-3, t_scale: float = 999.0, device=None, process_group=None, distributed: Optional[bool] = None):
         device = torch.device(device) if device is not None else next(model.parameters()).device
@@ -120,7 +122,12 @@ class FlowTrainer:
         self.t_eps, self.t_scale = t_eps, t_scale
         n = model._flat_numel
         z = lambda: torch.zeros(n, dtype=torch.float32, device=device)
-        self.params, self.grads, self.exp_avg, self.exp_avg_sq = z(), z(), z(), z()
+        self.params, self.exp_avg, self.exp_avg_sq = z(), z(), z()
+        # the gradient vector carries FLAG_TAIL extra floats behind the library's table: the replicas' agreement flags (three parameter-group
+        # presences, two input-validity bits) ride in the early gradient bucket of a data-parallel step as SUMs instead of an all-reduce of
+        # their own (``_flag_tail`` / ``_agree_from_tail``); the library never sees them (it is given ``self.grads``, the first n floats)
+        self._gbuf = torch.zeros(n + self.FLAG_TAIL, dtype=torch.float32, device=device)
+        self.grads = self._gbuf[:n]
         model.to(device)
         model.adopt_flat(self.params)
         self.ema = self.params.clone()
@@ -187,7 +194,7 @@ class FlowTrainer:
             raise IndexError("; ".join(what) + " (a training step since the last check was given others; no optimiser update has been "
                                                "applied from that step on)")
 
-    def loss_and_grads(self, x, t, cls, v_target, mask=None, time=None, overlap: bool = False):
+    def loss_and_grads(self, x, t, cls, v_target, mask=None, time=None, overlap: bool = False, tail: Optional[torch.Tensor] = None):
         """forward -> loss -> backward; leaves the gradients in ``self.grads`` and returns (loss 0-d tensor, v_model).  With ``overlap``
         (data-parallel steps) the backward runs in its two parts and the SUM all-reduce of the early bucket -- final_*, mid_*, ups.*:
         parameters every step has gradients for, so it needs no agreement between the ranks first -- is started in between: RCCL moves
@@ -203,7 +210,12 @@ class FlowTrainer:
         nb, split = m.grad_buckets() if overlap else (1, 0)
         if overlap and nb == 2 and 0 < split < self.grads.numel() and all(hi <= split for _, hi in self._groups.values()):
             m.backward_native(x, time, cls, dv, self.grads, mask=mask, parts=(0, 0))
-            self._pending = (torch.distributed.all_reduce(self.grads[split:], op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True), split)
+            n, hi = self.grads.numel(), self.grads.numel()
+            if tail is not None:                # the agreement flags ride behind the late layers' gradients: one collective fewer per step
+                self._gbuf[n:n + tail.numel()].copy_(tail)
+                hi = n + tail.numel()
+            self._pending = (torch.distributed.all_reduce(self._gbuf[split:hi], op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True), split,
+                             tail is not None)
             m.backward_native(x, time, cls, dv, self.grads, mask=mask, parts=(1, 1))
         else:
             m.backward_native(x, time, cls, dv, self.grads, mask=mask)
@@ -213,7 +225,7 @@ class FlowTrainer:
         """Wait for an early-bucket all-reduce that was started but never finished (a step that raised between ``loss_and_grads`` and
         ``finish_gradients``, e.g. the input check of ``_agree``): its communication stream may still be writing ``self.grads``."""
         pend, self._pending = getattr(self, "_pending", None), None
-        if pend is not None:
+        if pend is not None and pend[0] is not None:
             pend[0].wait()
 
     def finish_gradients(self) -> None:
@@ -223,9 +235,10 @@ class FlowTrainer:
         if pend is None:
             average_gradients(self.grads, self.pg)
             return
-        work, split = pend
+        work, split = pend[0], pend[1]
         torch.distributed.all_reduce(self.grads[:split], op=torch.distributed.ReduceOp.SUM, group=self.pg)
-        work.wait()
+        if work is not None:
+            work.wait()
         self.grads.div_(torch.distributed.get_world_size(self.pg))
 
     @property
@@ -268,6 +281,35 @@ class FlowTrainer:
         self.model.sync_flat()
 
     # ---- data-parallel agreement -------------------------------------------------------------------------------------
+    def _flag_tail(self, present: Dict[str, bool]) -> torch.Tensor:
+        """What ``_agree`` exchanges, as five non-negative floats whose SUM over the ranks answers the same questions (a group is stepped
+        if ANY rank has a gradient for it <=> the sum of the 0/1 presences is positive; SOME rank was given bad inputs <=> the sum of that
+        bit is positive): they can then ride in the early gradient bucket, a SUM all-reduce, instead of a MAX all-reduce of their own."""
+        keys = sorted(self._groups)
+        bits = torch.stack((self._id_flag & 1, (self._id_flag >> 1) & 1)).flatten().to(torch.float32)
+        return torch.cat([torch.tensor([float(present[k]) for k in keys], device=self.device), bits])
+
+    def _agree_from_tail(self, present: Dict[str, bool]) -> Dict[str, bool]:
+        """``_agree`` for a step whose flags travelled with the early gradient bucket (``loss_and_grads(tail=...)``): wait for that bucket,
+        zero the groups this rank has no gradient for (they lie in the bucket still to be reduced), read the summed flags."""
+        work, split, _ = self._pending
+        work.wait()
+        self._pending = (None, split, True)
+        keys = sorted(self._groups)
+        for k in keys:
+            lo, hi = self._groups[k]
+            if hi > lo and not present[k]:
+                self.grads[lo:hi].zero_()
+        n = self.grads.numel()
+        vals = self._gbuf[n:n + len(keys) + 2].tolist()
+        bad = (1 if vals[-2] > 0 else 0) | (2 if vals[-1] > 0 else 0)
+        if bad:
+            self._pending = None                             # every rank raises here, none enters the second bucket
+            if not int(self._id_flag.item()):
+                self._id_flag.fill_(bad)                     # another rank's batch: raise the same error here
+            self.check_class_ids()
+        return {k: v > 0 for k, v in zip(keys, vals)}
+
     def _agree(self, present: Dict[str, bool]) -> Dict[str, bool]:
         """Replicas must take the SAME Adam decisions.  Which parameter groups received a gradient is a per-rank fact (one rank may
         have dropped its conditioning, another not); Adam over a group on one rank but not the other would let parameters, moments
@@ -322,12 +364,17 @@ class FlowTrainer:
         if int(self._id_flag_host[0]):
             self.check_class_ids()                                   # an earlier step's inputs were out of range: raise now
         t, time, x, v_target = self.prepare(source, target, u, cls, pairing)
-        loss, _ = self.loss_and_grads(x, t, cls, v_target, mask, time=time, overlap=self.distributed and self.overlap_comm)
-        loss = loss.clone()
-        if (cls is not None or pairing is not None) and (self.step_main & 63) == 0:
-            self.check_class_ids()                                   # every 64th step (and from the state-dict methods): one host sync
         fused = mask is not None and not bool(torch.allclose(mask, torch.ones_like(mask)))    # unet.py:301 (host sync, as upstream)
-        present = self._agree({"class": cls is not None, "inject": mask is not None, "fusion": fused})
+        mine = {"class": cls is not None, "inject": mask is not None, "fusion": fused}
+        overlap = self.distributed and self.overlap_comm
+        loss, _ = self.loss_and_grads(x, t, cls, v_target, mask, time=time, overlap=overlap, tail=self._flag_tail(mine) if overlap else None)
+        loss = loss.clone()
+        if (cls is not None or pairing is not None) and (self.step_main & 63) == 0 and not self.distributed:
+            self.check_class_ids()                                   # every 64th step (and from the state-dict methods): one host sync
+        # (data-parallel steps learn about bad inputs from the agreement below, on every rank at once: a rank that raised alone here
+        # would leave the others waiting in the gradient all-reduce)
+        rode = self._pending is not None and len(self._pending) > 2 and self._pending[2]
+        present = self._agree_from_tail(mine) if rode else self._agree(mine)
         if self.distributed:                                     # DDP semantics: average the gradients over ranks
             self.finish_gradients()
         self.optimizer_step(has_class_grads=present["class"], has_mask_grads=present["inject"], has_fusion_grads=present["fusion"])

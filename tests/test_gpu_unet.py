@@ -4,10 +4,13 @@ Checked against (1) the golden vectors produced by the reference itself and (2) 
 inputs.  Tolerances (fp32 everywhere; differences are summation order + exp/erf ulps):
     single forward      rel-L2 <= 2e-5      trajectories (<= 64 forwards)   rel-L2 <= 2e-4
 north_star's budget for decoded images is 1e-3."""
+import os
+import sys
+
 import pytest
 import torch
 
-from conftest import load_golden, rel_l2
+from conftest import ROOT, load_golden, rel_l2
 from oracle import flow_oracle as fo
 from oracle.synth import synth_input, synth_state_dict
 
@@ -294,3 +297,16 @@ def test_folded_upsampling_equals_the_conv_over_the_upsampled_window(tmp_path):
     # (either form is ~2e-6 from the fp64-accumulating oracle on this decoder: tests/test_gpu_vae.py)
     assert rel_l2(v, v0) < 2e-6 and rel_l2(img, img0) < 1e-5
     assert fl == fl0 and abs(ex0 - fl0) < 1e-3 * fl0 and ex < 0.95 * ex0
+
+
+def test_one_workgroup_per_sample_kernel_matches_the_goldens():
+    """csrc/unet_sample.hip (the whole forward of a sample in one workgroup, for models whose activations fit a CU's LDS; opt-in,
+    FLOCODER_AMD_SAMPLE_KERNEL=1 -- slower than the ordinary plan today): the mask-conditioned dim-8 model's forward goldens,
+    the mask-conditioned sampler against the oracle and the batch-size / determinism test once more on that kernel, in a child process
+    (the switch is read once per process)."""
+    import subprocess
+    env = dict(os.environ, FLOCODER_AMD_SAMPLE_KERNEL="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "d8mask or mask_cond_sampling"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
+    assert r.returncode == 0 and " passed" in tail and "no tests ran" not in tail, (r.returncode, r.stdout[-2000:], r.stderr[-500:])
