@@ -404,6 +404,26 @@ static int build_sample_plan(fc_unet* u, Plan* pl, Builder& b, int H, int W) {
         s.op = S_CONV; s.guard = guard; s.in0 = x.off; s.C0 = x.C; s.in1 = x1 ? x1->off : -1; s.C1 = x1 ? x1->C : 0;
         s.out = out.off; s.Cout = out.C; s.Hi = x.H; s.Wi = x.W; s.Ho = out.H; s.Wo = out.W; s.KS = KS; s.pad = pad; s.stride = stride; s.ups = ups;
         s.act = act; s.res = res; s.w = u->P(name + ".weight"); s.bias = bias ? u->R(name + ".bias") : nullptr;
+        s.lco = ilog2(out.C);
+        {   // the weight rows some output pixel can reach, merged where contiguous, cut into chunks of <= 4096 floats
+            const int Cin = s.C0 + s.C1, Hin = x.H << ups, Win = x.W << ups, RW = 4096 / out.C;
+            int kx_lo = KS, kx_hi = -1;
+            for (int kx = 0; kx < KS; ++kx) if ((out.W - 1) * stride - pad + kx >= 0 && -pad + kx < Win) { if (kx < kx_lo) kx_lo = kx; kx_hi = kx; }
+            std::vector<std::pair<int, int>> ranges;
+            for (int ky = 0; ky < KS && kx_hi >= kx_lo; ++ky) {
+                if (!((out.H - 1) * stride - pad + ky >= 0 && -pad + ky < Hin)) continue;
+                const int r0 = (ky * KS + kx_lo) * Cin, r1 = (ky * KS + kx_hi + 1) * Cin;
+                if (!ranges.empty() && ranges.back().second == r0) ranges.back().second = r1;
+                else ranges.push_back({r0, r1});
+            }
+            int nck = 0;
+            for (auto& rg : ranges)
+                for (int r = rg.first; r < rg.second; r += RW) {
+                    if (nck < 8) { s.crow[nck] = r; s.cn[nck] = rg.second - r < RW ? rg.second - r : RW; }
+                    ++nck;
+                }
+            s.nchunk = nck;                              // > 8: the model does not qualify (checked below)
+        }
         prog.push_back(s);
         return 2.0 * out.H * out.W * KS * KS * (double)(s.C0 + s.C1) * out.C;
     };
@@ -411,6 +431,7 @@ static int build_sample_plan(fc_unet* u, Plan* pl, Builder& b, int H, int W) {
         SStep s;
         s.op = S_NORM; s.in0 = x.off; s.out = out.off; s.C0 = x.C; s.Hi = x.H; s.Wi = x.W; s.G = groups; s.ss_off = ss_off; s.act = act; s.res = res;
         s.gamma = u->R(name + ".weight"); s.beta = u->R(name + ".bias");
+        s.lc = ilog2(x.C); s.lcpg = ilog2(x.C / groups);
         prog.push_back(s);
     };
     auto copy = [&](const T& x, const T& out, int guard) {
@@ -442,6 +463,7 @@ static int build_sample_plan(fc_unet* u, Plan* pl, Builder& b, int H, int W) {
         s.op = full ? S_ATTN : S_LINATTN; s.in0 = x.off; s.out = out.off; s.C0 = x.C; s.Hi = x.H; s.Wi = x.W;
         s.scratch = alloc(2 * n * x.C + 3 * n * 32 + (full ? n * n : 32 * 32) + n * 32);
         s.gamma = u->R(p + ".fn.norm.weight"); s.beta = u->R(p + ".fn.norm.bias");
+        s.lc = ilog2(x.C); s.ln = ilog2(n);
         s.w = u->P(p + ".fn.fn.to_qkv.weight");
         if (full) { s.w2 = u->P(p + ".fn.fn.to_out.weight"); s.b2 = u->R(p + ".fn.fn.to_out.bias"); }
         else {
@@ -512,14 +534,16 @@ static int build_sample_plan(fc_unet* u, Plan* pl, Builder& b, int H, int W) {
     T v = tensor(ch, H, W);
     flops += conv(x, nullptr, v, "final_conv", 1, 0, 1, 0, 0, -1, 0);
     // every tensor at most four elements per thread, attention at most 64 channels / 64 keys (unet_sample.hip's register and staging budgets)
+    // (powers of two throughout: the kernel indexes by shifts and masks)
+    const int cap = 4 * SAMPLE_THREADS;
     for (const SStep& s : prog) {
-        if (s.op == S_CONV && s.Ho * s.Wo * s.Cout > 1024) return 1;
-        if (s.op == S_NORM && s.Hi * s.Wi * s.C0 > 1024) return 1;
-        if ((s.op == S_ATTN || s.op == S_LINATTN) && (s.C0 > 64 || (s.C0 & 3))) return 1;
+        if (s.op == S_CONV && (s.Ho * s.Wo * s.Cout > cap || !is_pow2(s.Cout) || s.Cout < 4 || s.Cout > SAMPLE_THREADS || s.nchunk > 8 || s.C0 > 128 || s.C1 > 128)) return 1;
+        if (s.op == S_NORM && (s.Hi * s.Wi * s.C0 > cap || !is_pow2(s.C0) || s.C0 > 64 || !is_pow2(s.C0 / s.G) || s.G > 8)) return 1;
+        if ((s.op == S_ATTN || s.op == S_LINATTN) && (s.C0 > 64 || s.C0 < 4 || !is_pow2(s.C0) || !is_pow2(s.Hi * s.Wi) || s.Hi * s.Wi * s.C0 > cap)) return 1;
         if (s.op == S_ATTN && s.Hi * s.Wi > 64) return 1;
-        if (s.op == S_CONV && (s.Cout & 3)) return 1;
     }
     top = peak;                                           // behind every temporary (they were released, not forgotten)
+    const int zero_off = alloc(128);
     const int wbuf_off = alloc(2 * 4096), prog_off = alloc((int)(prog.size() * sizeof(SStep) / 4) + 4);
     const size_t lds = (size_t)peak * sizeof(float);
     if (lds > 150 * 1024) return 1;                       // the sample does not fit a CU: ordinary plan
@@ -531,7 +555,7 @@ static int build_sample_plan(fc_unet* u, Plan* pl, Builder& b, int H, int W) {
     FC_HIP(hipMemset(done, 0, 4 * sizeof(unsigned)));
     SampleArgs a;
     a.prog = dev; a.nsteps = (int)prog.size(); a.S = u->S; a.ss = pl->ss; a.ch = ch; a.HW = H * W;
-    a.x_off = xin.off; a.mask_off = mask.off; a.v_off = v.off; a.done = done; a.wbuf_off = wbuf_off; a.prog_off = prog_off;
+    a.x_off = xin.off; a.mask_off = mask.off; a.v_off = v.off; a.done = done; a.wbuf_off = wbuf_off; a.prog_off = prog_off; a.zero_off = zero_off;
     const bool mask_cond = c.mask_cond != 0;
     b.scope = "unet (one workgroup per sample)";
     b.push([a, lds, mask_cond](const FwdCtx& cx, hipStream_t s) {

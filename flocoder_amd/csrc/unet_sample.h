@@ -4,6 +4,8 @@
 
 namespace fc {
 
+constexpr int SAMPLE_THREADS = 256;       // threads of a sample's workgroup
+
 enum SampleOp { S_CONV = 0, S_NORM = 1, S_BILINEAR = 2, S_LINATTN = 3, S_ATTN = 4, S_COPY = 5 };
 
 struct SStep {
@@ -18,6 +20,13 @@ struct SStep {
     int act = 0;              // SiLU on the result (before `res`)
     int G = 1, ss_off = -1;   // GroupNorm groups; column of the block's FiLM scale in the sample's conditioning row (shift at + C), or -1
     float eps = 1e-5f;
+    // convolution: the weight rows it reads, in chunks of <= 4096 floats (only the taps some output pixel can reach; the host's list)
+    int nchunk = 0;
+    int crow[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // first row (tap * Cin + ci) of chunk k
+    int cn[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // rows in chunk k
+    int lco = 0;              // log2(Cout) (convolution)
+    int lc = 0, lcpg = 0;     // log2(C0), log2(channels per GroupNorm group) (norm, attention)
+    int ln = 0;               // log2(pixels) (attention)
     const float* w = nullptr;      // conv: packed [tap][Cin][Cout]; attention: to_qkv [C][384]
     const float* bias = nullptr;
     const float* gamma = nullptr;  // norm weight / bias (attention: fn.norm)
@@ -42,6 +51,7 @@ struct SampleArgs {
     float* out = nullptr;          // NCHW [B][ch][HW]
     int ch = 0, HW = 0;
     int x_off = 0, mask_off = 0, v_off = 0;    // LDS float offsets: input, mask, velocity (all NHWC)
+    int zero_off = 0;                          // LDS float offset of 128 zeros (what a tap outside the image reads)
     int wbuf_off = 0, prog_off = 0;            // LDS float offsets: the weight staging buffers (2 x 4096 floats), the program's copy
     EulerTail euler;               // integrator: Euler update instead of `out`, counters moved by the last workgroup
     unsigned* done = nullptr;      // arrival counter of that hand-over (zero between launches)

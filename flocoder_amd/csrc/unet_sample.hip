@@ -5,9 +5,15 @@
 // in flight overlap at that size (measured, tools/bench_inpaint.py).  Every activation of a sample is a few KB there, so a workgroup keeps
 // the sample's whole forward in its LDS and walks a PROGRAM of steps (unet.py:289-372 unrolled by the host: convolutions, GroupNorm +
 // FiLM + SiLU, the linear / full attention modules, bilinear mask resizes), one workgroup barrier between steps instead of a launch
-// boundary; weights stream from L2 (the same packed copies the ordinary kernels read), the FiLM rows from the conditioning table.  The
-// arithmetic is plain fp32 FMA on the vector pipe: the layers are far too small for matrix tiles (8..64 channels, 64..1 pixels).
-// Same results as the ordinary plan to summation order (tests/test_gpu_unet.py compares both with the oracle).
+// boundary; weights stream from L2 (the same packed copies the ordinary kernels read) through LDS, the FiLM rows come from the conditioning
+// table.  The arithmetic is plain fp32 FMA on the vector pipe: the layers are far too small for matrix tiles (8..64 channels, 64..1 pixels).
+// Same results as the ordinary plan to summation order (tests/test_gpu_unet.py compares both with the goldens and the oracle).
+//
+// What decides its speed (profiles/r04_sample_kernel_stamps*.txt): a step lives a few microseconds, so (1) nothing in it may wait for its
+// own weights -- the first chunk of the NEXT weight-reading step is requested (global -> registers) before the current step computes, later
+// chunks of a step travel while the previous one is multiplied; (2) the multiply-add loops keep four independent accumulators per thread
+// that share one weight value (a thread's outputs are the same channel of four pixels), with the loop over input channels unrolled, and
+// the reductions use shifts and lane masks, never an integer division (all extents are powers of two; the host checks).
 #include <cstdlib>
 #include <string>
 
@@ -17,156 +23,194 @@
 namespace fc {
 
 namespace {
-constexpr int NT = 256;
+constexpr int NT = SAMPLE_THREADS;
 constexpr int WCH = 4096;                 // floats per weight chunk (two buffers)
 constexpr int NO = 4;                     // elements per thread at most (the host checks C * H * W <= NO * NT for every tensor)
 
 __device__ __forceinline__ float silu(float z) { return z / (1.0f + __expf(-z)); }
 
-// sum of `v` over the workgroup; `red` = 8 floats of LDS.  Every thread gets the result.
+// sum of `v` over the workgroup; `red` = NT / 64 floats of LDS.  Every thread gets the result.
 __device__ __forceinline__ float block_sum(float v, float* red) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) s += red[w];
+    return s;
 }
 
-// y = [act]( (x - mean_g) * rstd_g * gamma + beta  [* (scale + 1) + shift] ) [+ res]     GroupNorm over (channels of a group) x pixels
-__device__ void op_norm(const SStep& s, float* L, const float* ss, float* red) {
-    const int tid = threadIdx.x, C = s.C0, HW = s.Hi * s.Wi, G = s.G, cpg = C / G, n = HW * C;
+// ---- weights on their way: global -> registers (requested early) -> LDS (when the step starts) ---------------------------------------
+// The registers are NAMED members, not an array: as an array that lives across the step loop the compiler kept them in scratch memory and
+// waited for every "prefetch" on the spot (ISA of the first version: flat_load, s_waitcnt vmcnt(0), scratch_store).  The weight pointers are
+// read from the LDS copy of the program, so their address space is unknown to the compiler: re-tagged as global, the loads are
+// global_load (counted on vmcnt alone, in order) instead of flat_load (which also holds up every LDS wait).
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) f4v* gf4p;
+__device__ __forceinline__ gf4p gptr(const float* p) { return (gf4p)(size_t)p; }
+typedef const __attribute__((address_space(1))) float* gfp;
+__device__ __forceinline__ gfp gsc(const float* p) { return (gfp)(size_t)p; }      // a scalar parameter vector in global memory
+struct Pre { f4v r0, r1, r2, r3, r4, r5, r6, r7; };
+constexpr int NCV = WCH / 4 / NT;         // float4's per thread of a convolution chunk
+constexpr int NWQ = 6144 / 4 / NT, NWO = 2048 / 4 / NT;      // ... of an attention head's wq / wo
+static_assert(NCV <= 4 && NWQ == 6 && NWO == 2, "the named registers below are laid out for 256 threads");
+#define FC_LD4(dst, cond, ptr) do { f4v z_ = {0.f, 0.f, 0.f, 0.f}; dst = z_; if (cond) dst = *(ptr); } while (0)
+__device__ __forceinline__ void issue_conv_chunk(const SStep& s, int k, Pre& r) {
+    gf4p src = gptr(s.w + (size_t)s.crow[k] * s.Cout);
+    const int n4 = s.cn[k] * s.Cout / 4, t = threadIdx.x;
+    FC_LD4(r.r0, t < n4, src + t); FC_LD4(r.r1, t + NT < n4, src + t + NT); FC_LD4(r.r2, t + 2 * NT < n4, src + t + 2 * NT); FC_LD4(r.r3, t + 3 * NT < n4, src + t + 3 * NT);
+}
+__device__ __forceinline__ void stash_conv_chunk(const SStep& s, int k, const Pre& r, float* wbuf) {
+    const int n4 = s.cn[k] * s.Cout / 4, t = threadIdx.x;
+    f4v* dst = reinterpret_cast<f4v*>(wbuf + (k & 1) * WCH);
+    if (t < n4) dst[t] = r.r0;
+    if (t + NT < n4) dst[t + NT] = r.r1;
+    if (t + 2 * NT < n4) dst[t + 2 * NT] = r.r2;
+    if (t + 3 * NT < n4) dst[t + 3 * NT] = r.r3;
+}
+// one head of an attention module: wq [C][96] = the head's q | k | v columns of to_qkv ([C][384] in memory), wo [32][C] = its rows of to_out
+__device__ __forceinline__ gf4p wq_src(const SStep& s, int h, int e) {
+    const int c = e / 24, q = e - c * 24, which = q >> 3, d4 = q & 7;
+    return gptr(s.w + (size_t)c * 384 + which * 128 + h * 32 + 4 * d4);
+}
+__device__ __forceinline__ void issue_head(const SStep& s, int h, Pre& r) {
+    const int C = s.C0, nq4 = C * 24, no4 = 8 * C, t = threadIdx.x;
+    FC_LD4(r.r0, t < nq4, wq_src(s, h, t)); FC_LD4(r.r1, t + NT < nq4, wq_src(s, h, t + NT)); FC_LD4(r.r2, t + 2 * NT < nq4, wq_src(s, h, t + 2 * NT));
+    FC_LD4(r.r3, t + 3 * NT < nq4, wq_src(s, h, t + 3 * NT)); FC_LD4(r.r4, t + 4 * NT < nq4, wq_src(s, h, t + 4 * NT)); FC_LD4(r.r5, t + 5 * NT < nq4, wq_src(s, h, t + 5 * NT));
+    gf4p wo = gptr(s.w2 + (size_t)(h * 32) * C);
+    FC_LD4(r.r6, t < no4, wo + t); FC_LD4(r.r7, t + NT < no4, wo + t + NT);
+}
+__device__ __forceinline__ void stash_head(const SStep& s, const Pre& r, float* wbuf) {
+    const int C = s.C0, nq4 = C * 24, no4 = 8 * C, t = threadIdx.x;
+    f4v* wq = reinterpret_cast<f4v*>(wbuf);
+    f4v* wo = reinterpret_cast<f4v*>(wbuf + 6144);
+    if (t < nq4) wq[t] = r.r0;
+    if (t + NT < nq4) wq[t + NT] = r.r1;
+    if (t + 2 * NT < nq4) wq[t + 2 * NT] = r.r2;
+    if (t + 3 * NT < nq4) wq[t + 3 * NT] = r.r3;
+    if (t + 4 * NT < nq4) wq[t + 4 * NT] = r.r4;
+    if (t + 5 * NT < nq4) wq[t + 5 * NT] = r.r5;
+    if (t < no4) wo[t] = r.r6;
+    if (t + NT < no4) wo[t + NT] = r.r7;
+}
+__device__ __forceinline__ bool reads_weights(const SStep& s) { return s.op == S_CONV || s.op == S_LINATTN || s.op == S_ATTN; }
+__device__ __forceinline__ void issue_first(const SStep& s, Pre& r) { if (s.op == S_CONV) issue_conv_chunk(s, 0, r); else issue_head(s, 0, r); }
+__device__ __forceinline__ void stash_first(const SStep& s, const Pre& r, float* wbuf) { if (s.op == S_CONV) stash_conv_chunk(s, 0, r, wbuf); else stash_head(s, r, wbuf); }
+
+// y = [act]( (x - mean_g) * rstd_g * gamma + beta  [* (scale + 1) + shift] ) [+ res]     GroupNorm over (channels of a group) x pixels.
+// A thread's elements e = tid + j NT are the SAME channel c = tid & (C - 1) of different pixels (C <= 64 divides NT), so they lie in one
+// group: a group's sum is reduced over exactly those lane bits that do not select the group (the bits below log2(channels per group) and
+// the bits from log2(C) up), then over the waves through LDS.
+__device__ __forceinline__ void op_norm(const SStep& s, float* L, const float* ss, float* red) {
+    const int tid = threadIdx.x, lane = tid & 63, C = s.C0, n = s.Hi * s.Wi * C, lc = s.lc, lcpg = s.lcpg;
     const float* x = L + s.in0;
     float* y = L + s.out;
-    // this thread's affine parameters first: their round trip to L2 passes behind the two reductions below
-    float pg[NO], pb[NO], psc[NO], psh[NO];
+    const int c = tid & (C - 1), g = c >> lcpg;
+    const float pg = gsc(s.gamma)[c], pb = gsc(s.beta)[c];
+    float psc = 0.f, psh = 0.f;
+    if (s.ss_off >= 0) { psc = gsc(ss)[s.ss_off + c]; psh = gsc(ss)[s.ss_off + C + c]; }
+    float v[NO], a = 0.f;
 #pragma unroll
-    for (int j = 0; j < NO; ++j) {
-        const int e = tid + j * NT, c = e % C;
-        pg[j] = 1.f; pb[j] = 0.f; psc[j] = 0.f; psh[j] = 0.f;
-        if (e < n) {
-            pg[j] = s.gamma[c]; pb[j] = s.beta[c];
-            if (s.ss_off >= 0) { psc[j] = ss[s.ss_off + c]; psh[j] = ss[s.ss_off + C + c]; }
-        }
-    }
-    float mean[8], rstd[8];
-    const float cnt = (float)(cpg * HW);
-    for (int g = 0; g < G; ++g) {
-        float a = 0.f;
-        for (int e = tid; e < n; e += NT) { const int c = e % C; if (c / cpg == g) a += x[e]; }
-        mean[g] = block_sum(a, red) / cnt;
-    }
-    for (int g = 0; g < G; ++g) {
-        float a = 0.f;
-        for (int e = tid; e < n; e += NT) { const int c = e % C; if (c / cpg == g) { const float d = x[e] - mean[g]; a += d * d; } }
-        rstd[g] = 1.0f / sqrtf(block_sum(a, red) / cnt + s.eps);
-    }
+    for (int j = 0; j < NO; ++j) { const int e = tid + j * NT; v[j] = e < n ? x[e] : 0.f; a += v[j]; }
+    const float cnt = (float)((n >> lc) << lcpg);          // pixels x channels per group
+    const int rmask = (((1 << lcpg) - 1) | ~((1 << lc) - 1)) & 63;     // the lane bits a group's sum runs over
+    auto group_sum = [&](float t) {
+#pragma unroll
+        for (int b = 0; b < 6; ++b) if ((rmask >> b) & 1) t += __shfl_xor(t, 1 << b);
+        __syncthreads();
+        if ((lane & rmask) == 0) red[(tid >> 6) * 8 + g] = t;       // one lane per (wave, group)
+        __syncthreads();
+        float r = 0.f;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) r += red[w * 8 + g];
+        return r;
+    };
+    const float mean = group_sum(a) / cnt;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NO; ++j) { const int e = tid + j * NT; if (e < n) { const float d = v[j] - mean; q += d * d; } }
+    const float rstd = 1.0f / sqrtf(group_sum(q) / cnt + s.eps);
     const float* res = s.res >= 0 ? L + s.res : nullptr;
 #pragma unroll
     for (int j = 0; j < NO; ++j) {
         const int e = tid + j * NT;
         if (e >= n) continue;
-        const int c = e % C, g = c / cpg;
-        float m = mean[0], r = rstd[0];
-#pragma unroll
-        for (int k = 1; k < 8; ++k) if (k < G && g == k) { m = mean[k]; r = rstd[k]; }
-        float v = (x[e] - m) * r * pg[j] + pb[j];
-        if (s.ss_off >= 0) v = v * (psc[j] + 1.0f) + psh[j];
-        if (s.act) v = silu(v);
-        if (res) v += res[e];
-        y[e] = v;
+        float t = (v[j] - mean) * rstd * pg + pb;
+        if (s.ss_off >= 0) t = t * (psc + 1.0f) + psh;
+        if (s.act) t = silu(t);
+        if (res) t += res[e];
+        y[e] = t;
     }
 }
 
-// Convolution over one or two (concatenated) NHWC sources in LDS.  The weights (packed [tap][Cin][Cout] in global memory, L2-resident) pass
-// through LDS in chunks of whole rows: read straight from global inside the multiply-add loop every product waited for its own load (the
-// first version: 1.18 ms per evaluation, slower than the 115 launches it replaced).  The next chunk travels global -> registers while the
-// current one is multiplied out of LDS; only the taps some output pixel can reach are staged (at 1x1 resolution: the centre tap).
-__device__ void op_conv(const SStep& s, float* L, float* wbuf, int2* chunks, int* nchunks_s) {
-    const int tid = threadIdx.x, C0 = s.C0, C1 = s.C1, Cin = C0 + C1, Cout = s.Cout, KS = s.KS;
+// Convolution over one or two (concatenated) NHWC sources in LDS; weights packed [tap][Cin][Cout], staged through LDS in the host's chunk
+// list (whole weight rows of the taps some output pixel can reach).  Chunk 0 is in wbuf[0] when this is called.
+__device__ __forceinline__ void op_conv(const SStep& s, float* L, float* wbuf, const float* zl) {
+    const int tid = threadIdx.x, C0 = s.C0, C1 = s.C1, Cin = C0 + C1, Cout = s.Cout, KS = s.KS, lco = s.lco;
     const float* a0 = L + s.in0;
-    const float* a1 = C1 ? L + s.in1 : nullptr;
-    const int Hin = s.Hi << s.ups, Win = s.Wi << s.ups, total = s.Ho * s.Wo * Cout;
-    if (tid == 0) {   // the chunk list: per reachable kernel row ky the contiguous weight rows of its reachable kx, cut into chunks of <= WCH floats
-        const int RW = WCH / Cout;
-        int kx_lo = KS, kx_hi = -1, n = 0;
-        for (int kx = 0; kx < KS; ++kx) if ((s.Wo - 1) * s.stride - s.pad + kx >= 0 && -s.pad + kx < Win) { if (kx < kx_lo) kx_lo = kx; kx_hi = kx; }
-        for (int ky = 0; ky < KS && kx_hi >= kx_lo; ++ky) {
-            if (!((s.Ho - 1) * s.stride - s.pad + ky >= 0 && -s.pad + ky < Hin)) continue;
-            const int r0 = (ky * KS + kx_lo) * Cin, r1 = (ky * KS + kx_hi + 1) * Cin;
-            for (int r = r0; r < r1 && n < 64; r += RW) chunks[n++] = make_int2(r, r1 - r < RW ? r1 - r : RW);
-        }
-        *nchunks_s = n;
-    }
-    int co[NO], oy[NO], ox[NO];
+    const float* a1 = C1 ? L + s.in1 : zl;
+    const int Hin = s.Hi << s.ups, Win = s.Wi << s.ups, npix = s.Ho * s.Wo;
+    const int co = tid & (Cout - 1), pstep = NT >> lco;
+    const float bias = s.bias ? gsc(s.bias)[co] : 0.f;
+    const int nj = (npix + pstep - 1) / pstep;             // output passes in use (uniform)
+    int oy[NO], ox[NO];
     float acc[NO];
 #pragma unroll
     for (int j = 0; j < NO; ++j) {
-        const int o = tid + j * NT;
-        co[j] = 0; oy[j] = -1; ox[j] = 0; acc[j] = 0.f;
-        if (o < total) {
-            co[j] = o % Cout;
-            const int pix = o / Cout;
-            oy[j] = pix / s.Wo; ox[j] = pix - oy[j] * s.Wo;
-            acc[j] = s.bias ? s.bias[co[j]] : 0.f;
-        }
+        const int pix = (tid >> lco) + j * pstep;
+        oy[j] = pix < npix ? pix / s.Wo : -1000;
+        ox[j] = pix - (pix / s.Wo) * s.Wo;
+        acc[j] = 0.f;
     }
-    __syncthreads();
-    const int nch = *nchunks_s;
-    float4 pre[WCH / 4 / NT];
-    auto fetch = [&](int k) {
-        const int2 c = chunks[k];
-        const float4* src = reinterpret_cast<const float4*>(s.w + (size_t)c.x * Cout);
-        const int n4 = c.y * Cout / 4;
-#pragma unroll
-        for (int i = 0; i < WCH / 4 / NT; ++i) { const int e = tid + i * NT; pre[i] = e < n4 ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f); }
-    };
-    auto stash = [&](int k) {
-        const int n4 = chunks[k].y * Cout / 4;
-        float4* dst = reinterpret_cast<float4*>(wbuf + (k & 1) * WCH);
-#pragma unroll
-        for (int i = 0; i < WCH / 4 / NT; ++i) { const int e = tid + i * NT; if (e < n4) dst[e] = pre[i]; }
-    };
-    if (nch > 0) { fetch(0); stash(0); }
-    __syncthreads();
+    Pre cur;
+    const int nch = s.nchunk;
     for (int k = 0; k < nch; ++k) {
-        if (k + 1 < nch) fetch(k + 1);
-        const int2 c = chunks[k];
+        if (k + 1 < nch) issue_conv_chunk(s, k + 1, cur);
         const float* wb = wbuf + (k & 1) * WCH;
-        for (int row = c.x; row < c.x + c.y;) {           // segments of one tap: channels [ci0, ci0 + seg)
+        const int r0 = s.crow[k], r1 = r0 + s.cn[k];
+        for (int row = r0; row < r1;) {                    // segments of one tap: channels [ci0, ci0 + seg)
             const int tap = row / Cin, ci0 = row - tap * Cin, ky = tap / KS, kx = tap - ky * KS;
-            const int seg = (Cin - ci0 < c.x + c.y - row) ? Cin - ci0 : c.x + c.y - row;
-            const float* wr = wb + (size_t)(row - c.x) * Cout;
+            const int seg = (Cin - ci0 < r1 - row) ? Cin - ci0 : r1 - row;
+            const float* w = wb + (size_t)(row - r0) * Cout + co;
+            const float* p0[NO];
+            const float* p1[NO];
 #pragma unroll
             for (int j = 0; j < NO; ++j) {
-                if (oy[j] < 0) continue;
                 const int iy = oy[j] * s.stride - s.pad + ky, ix = ox[j] * s.stride - s.pad + kx;
-                if (iy < 0 || iy >= Hin || ix < 0 || ix >= Win) continue;
-                const int sp = (iy >> s.ups) * s.Wi + (ix >> s.ups);
-                const float* w = wr + co[j];
-                float a = acc[j];
-                int ci = ci0;
-                const int e0 = ci0 + seg < C0 ? ci0 + seg : C0;     // part of the segment inside the first source
-                const float* p0 = a0 + sp * C0;
-                for (; ci < e0; ++ci) a += p0[ci] * w[(size_t)(ci - ci0) * Cout];
-                if (ci < ci0 + seg) {
-                    const float* p1 = a1 + sp * C1 - C0;
-                    for (; ci < ci0 + seg; ++ci) a += p1[ci] * w[(size_t)(ci - ci0) * Cout];
-                }
-                acc[j] = a;
+                const bool ok = iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
+                const int sp = ok ? (iy >> s.ups) * s.Wi + (ix >> s.ups) : 0;
+                p0[j] = ok ? a0 + sp * C0 : zl;
+                p1[j] = (ok && C1) ? a1 + sp * C1 - C0 : zl - C0;
+            }
+            const int e0 = ci0 + seg < C0 ? ci0 + seg : C0;      // the part of the segment inside the first source
+            int ci = ci0;
+#pragma unroll 4
+            for (; ci < e0; ++ci) {
+                const float wv = w[(ci - ci0) * Cout];
+#pragma unroll
+                for (int j = 0; j < NO; ++j) if (j < nj) acc[j] += p0[j][ci] * wv;
+            }
+#pragma unroll 4
+            for (; ci < ci0 + seg; ++ci) {
+                const float wv = w[(ci - ci0) * Cout];
+#pragma unroll
+                for (int j = 0; j < NO; ++j) if (j < nj) acc[j] += p1[j][ci] * wv;
             }
             row += seg;
         }
-        if (k + 1 < nch) stash(k + 1);
+        if (k + 1 < nch) stash_conv_chunk(s, k + 1, cur, wbuf);
         __syncthreads();
     }
     const float* res = s.res >= 0 ? L + s.res : nullptr;
     float* y = L + s.out;
 #pragma unroll
     for (int j = 0; j < NO; ++j) {
-        const int o = tid + j * NT;
-        if (o < total) {
-            float v = acc[j];
+        const int pix = (tid >> lco) + j * pstep;
+        if (pix < npix) {
+            const int o = pix * Cout + co;
+            float v = acc[j] + bias;
             if (s.act) v = silu(v);
             if (res) v += res[o];
             y[o] = v;
@@ -175,7 +219,7 @@ __device__ void op_conv(const SStep& s, float* L, float* wbuf, int2* chunks, int
 }
 
 // F.interpolate(mode='bilinear', align_corners=False) of an NHWC tensor in LDS (elementwise.hip bilinear_kernel, same arithmetic)
-__device__ void op_bilinear(const SStep& s, float* L) {
+__device__ __forceinline__ void op_bilinear(const SStep& s, float* L) {
     const int C = s.C0, Hs = s.Hi, Ws = s.Wi, Hd = s.Ho, Wd = s.Wo, total = Hd * Wd * C;
     const float sy = (float)Hs / (float)Hd, sx = (float)Ws / (float)Wd;
     const float* src = L + s.in0;
@@ -195,20 +239,22 @@ __device__ void op_bilinear(const SStep& s, float* L) {
 
 // GroupNorm(1) statistics of an [n][C] tensor in LDS (mean, rstd); every thread gets them
 __device__ __forceinline__ void gn1_stats(const float* x, int n, float eps, float* red, float* mean, float* rstd) {
-    float a = 0.f;
-    for (int e = threadIdx.x; e < n; e += NT) a += x[e];
+    float v[NO], a = 0.f;
+#pragma unroll
+    for (int j = 0; j < NO; ++j) { const int e = threadIdx.x + j * NT; v[j] = e < n ? x[e] : 0.f; a += v[j]; }
     const float m = block_sum(a, red) / (float)n;
     float q = 0.f;
-    for (int e = threadIdx.x; e < n; e += NT) { const float d = x[e] - m; q += d * d; }
+#pragma unroll
+    for (int j = 0; j < NO; ++j) { const int e = threadIdx.x + j * NT; if (e < n) { const float d = v[j] - m; q += d * d; } }
     *mean = m;
     *rstd = 1.0f / sqrtf(block_sum(q, red) / (float)n + eps);
 }
 
 // Residual(PreNorm(LinearAttention)) (unet.py:125-161) / Residual(PreNorm(Attention)) (unet.py:99-122) on an [n][C] tensor in LDS.
-// scratch: xn [n][C] | y [n][C] | q, k, v [n][32] each | ctx [32][32] or sim [n][n] | o [n][32]
-__device__ void op_attention(const SStep& s, float* L, float* red, float* wbuf, bool full) {
-    const int tid = threadIdx.x, C = s.C0, n = s.Hi * s.Wi, nC = n * C;
-    constexpr int DH = 32, HID = 128, C3 = 384;
+// scratch: xn [n][C] | y [n][C] | q, k, v [n][32] each | ctx [32][32] or sim [n][n] | o [n][32].  Head 0's weights are in wbuf when called.
+__device__ __forceinline__ void op_attention(const SStep& s, float* L, float* red, float* wbuf, bool full) {
+    const int tid = threadIdx.x, C = s.C0, lc = s.lc, n = s.Hi * s.Wi, ln = s.ln, nC = n * C;
+    constexpr int DH = 32;
     const float* x = L + s.in0;
     float* xn = L + s.scratch;
     float* y = xn + nC;
@@ -217,103 +263,106 @@ __device__ void op_attention(const SStep& s, float* L, float* red, float* wbuf, 
     float* v = k + n * DH;
     float* cx = v + n * DH;                              // ctx [32][32], or sim [n][n]
     float* o = cx + (full ? n * n : DH * DH);
+    const float* wq = wbuf;
+    const float* wo = wbuf + 6144;
+    const int cc = tid & (C - 1);
+    const float pg = gsc(s.gamma)[cc], pb = gsc(s.beta)[cc], pbo = gsc(s.b2)[cc];
     float mean, rstd;
     gn1_stats(x, nC, s.eps, red, &mean, &rstd);
-    for (int e = tid; e < nC; e += NT) {
-        const int c = e % C;
-        xn[e] = (x[e] - mean) * rstd * s.gamma[c] + s.beta[c];
-        y[e] = s.b2[c];                                   // to_out bias; the heads' shares are added below
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+        const int e = tid + j * NT;
+        if (e < nC) { xn[e] = (x[e] - mean) * rstd * pg + pb; y[e] = pbo; }       // y starts as the to_out bias; the heads' shares are added below
     }
     __syncthreads();
     const float scale = 0.17677669529663687f;            // dim_head^-0.5
-    // this head's weights through LDS (the host checks C <= 64): wq [C][96] = the head's q | k | v columns of to_qkv, wo [32][C] = its rows of to_out;
-    // head h + 1's travel global -> registers while head h is computed
-    float* wq = wbuf;
-    float* wo = wbuf + 6144;
-    constexpr int NWQ = 6144 / 4 / NT, NWO = 2048 / 4 / NT;      // float4's per thread
-    float4 pq[NWQ], po[NWO];
-    const int nq4 = C * 24, no4 = 8 * C;                  // float4's in wq (C rows x 96) and wo (32 rows x C)
-    auto fetch = [&](int h) {
-#pragma unroll
-        for (int i = 0; i < NWQ; ++i) {
-            const int e = tid + i * NT, c = e / 24, r = e - c * 24, which = r >> 3, d4 = r & 7;
-            pq[i] = e < nq4 ? *reinterpret_cast<const float4*>(s.w + (size_t)c * C3 + which * HID + h * DH + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < NWO; ++i) {
-            const int e = tid + i * NT;
-            po[i] = e < no4 ? *reinterpret_cast<const float4*>(s.w2 + (size_t)(h * DH) * C + 4 * e) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto stash = [&]() {
-#pragma unroll
-        for (int i = 0; i < NWQ; ++i) { const int e = tid + i * NT; if (e < nq4) reinterpret_cast<float4*>(wq)[e] = pq[i]; }
-#pragma unroll
-        for (int i = 0; i < NWO; ++i) { const int e = tid + i * NT; if (e < no4) reinterpret_cast<float4*>(wo)[e] = po[i]; }
-    };
-    fetch(0);
+    const int d = tid & 31, p8 = tid >> 5, PP = NT >> 5;  // (channel of the head, first position) of this thread in the [n][32] loops
+    Pre nxt;
     for (int h = 0; h < 4; ++h) {
-        stash();                                          // (the previous head's last reader passed the barrier that closes its loop body)
-        __syncthreads();
-        if (h + 1 < 4) fetch(h + 1);
-        // q | k | v of this head: [n][32] each
-        for (int i = tid; i < 3 * n * DH; i += NT) {
-            const int which = i / (n * DH), r = i - which * (n * DH), pix = r / DH, d = r - pix * DH;
+        if (h > 0) { stash_head(s, nxt, wbuf); __syncthreads(); }
+        if (h + 1 < 4) issue_head(s, h + 1, nxt);
+        // q | k | v of this head: [n][32] each; four positions per thread share a weight value
+        for (int which = 0; which < 3; ++which) {
+            float* dst = q + which * n * DH;
             const float* w = wq + which * DH + d;
-            const float* xp = xn + pix * C;
-            float acc = 0.f;
+            for (int p0 = p8; p0 < n; p0 += 4 * PP) {
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                const float* xp[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xp[j] = xn + ((p0 + j * PP) < n ? (p0 + j * PP) : p0) * C;
 #pragma unroll 4
-            for (int c = 0; c < C; ++c) acc += xp[c] * w[c * 96];
-            q[i] = acc;                                   // q, k, v are contiguous
+                for (int c = 0; c < C; ++c) {
+                    const float wv = w[c * 96];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] += xp[j][c] * wv;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (p0 + j * PP < n) dst[(p0 + j * PP) * DH + d] = acc[j];
+            }
         }
         __syncthreads();
         if (!full) {
-            // k: softmax over the positions (per channel d); thread (d, part): 8 threads per column
-            {
-                const int d = tid >> 3, part = tid & 7;
+            if (tid < 256) {   // k: softmax over the positions (per channel); 8 threads per column
+                const int dd = tid >> 3, part = tid & 7;
                 float m = -INFINITY;
-                for (int p = part; p < n; p += 8) m = fmaxf(m, k[p * DH + d]);
+                for (int p = part; p < n; p += 8) m = fmaxf(m, k[p * DH + dd]);
                 m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
                 float sum = 0.f;
-                for (int p = part; p < n; p += 8) { const float e = __expf(k[p * DH + d] - m); k[p * DH + d] = e; sum += e; }
+                for (int p = part; p < n; p += 8) { const float e = __expf(k[p * DH + dd] - m); k[p * DH + dd] = e; sum += e; }
                 sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
                 const float inv = 1.0f / sum;
-                for (int p = part; p < n; p += 8) k[p * DH + d] *= inv;
+                for (int p = part; p < n; p += 8) k[p * DH + dd] *= inv;
             }
-            // q: softmax over the head's 32 channels (per position), * scale; thread (pix, part): 4 threads per position
-            for (int p0 = 0; p0 < n; p0 += 64) {
+            // q: softmax over the head's 32 channels (per position), * scale; 4 threads per position
+            for (int p0 = 0; p0 < n; p0 += NT / 4) {
                 const int pix = p0 + (tid >> 2), part = tid & 3;
                 const bool on = pix < n;
-                float m = -INFINITY;
-                if (on) for (int d = part; d < DH; d += 4) m = fmaxf(m, q[pix * DH + d]);
+                float t[8], m = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { t[i] = on ? q[pix * DH + part + 4 * i] : 0.f; m = fmaxf(m, t[i]); }
                 m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2));
                 float sum = 0.f;
-                if (on) for (int d = part; d < DH; d += 4) { const float e = __expf(q[pix * DH + d] - m); q[pix * DH + d] = e; sum += e; }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { t[i] = __expf(t[i] - m); sum += t[i]; }
                 sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
                 const float f = scale / sum;
-                if (on) for (int d = part; d < DH; d += 4) q[pix * DH + d] *= f;
+                if (on) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) q[pix * DH + part + 4 * i] = t[i] * f;
+                }
             }
             __syncthreads();
-            for (int i = tid; i < DH * DH; i += NT) {     // ctx[d][e] = sum_n k[n][d] v[n][e]
-                const int d = i >> 5, e = i & 31;
-                float acc = 0.f;
-                for (int p = 0; p < n; ++p) acc += k[p * DH + d] * v[p * DH + e];
-                cx[i] = acc;
+            {   // ctx[dd][e] = sum_n k[n][dd] v[n][e]: thread (e = d, rows dd = p8 + PP j)
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int p = 0; p < n; ++p) {
+                    const float vv = v[p * DH + d];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] += k[p * DH + ((p8 + j * PP) & 31)] * vv;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (p8 + j * PP < DH) cx[(p8 + j * PP) * DH + d] = acc[j];
             }
             __syncthreads();
-            for (int i = tid; i < n * DH; i += NT) {      // o[n][e] = sum_d q[n][d] ctx[d][e]
-                const int pix = i >> 5, e = i & 31;
-                float acc = 0.f;
+            for (int p0 = p8; p0 < n; p0 += 4 * PP) {     // o[pix][e] = sum_dd q[pix][dd] ctx[dd][e]
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                const float* qp[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qp[j] = q + ((p0 + j * PP) < n ? (p0 + j * PP) : p0) * DH;
 #pragma unroll 8
-                for (int d = 0; d < DH; ++d) acc += q[pix * DH + d] * cx[d * DH + e];
-                o[i] = acc;
+                for (int dd = 0; dd < DH; ++dd) {
+                    const float cv = cx[dd * DH + d];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] += qp[j][dd] * cv;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (p0 + j * PP < n) o[(p0 + j * PP) * DH + d] = acc[j];
             }
         } else {
-            for (int i = tid; i < n * n; i += NT) {       // sim[i][j] = (q_i * scale) . k_j
-                const int a = i / n, b = i - a * n;
+            for (int i = tid; i < n * n; i += NT) {       // sim[a][b] = (q_a * scale) . k_b
+                const int a = i >> ln, b = i & (n - 1);
                 float acc = 0.f;
 #pragma unroll 8
-                for (int d = 0; d < DH; ++d) acc += (q[a * DH + d] * scale) * k[b * DH + d];
+                for (int dd = 0; dd < DH; ++dd) acc += (q[a * DH + dd] * scale) * k[b * DH + dd];
                 cx[i] = acc;
             }
             __syncthreads();
@@ -326,46 +375,59 @@ __device__ void op_attention(const SStep& s, float* L, float* red, float* wbuf, 
                 for (int b = 0; b < n; ++b) cx[a * n + b] *= inv;
             }
             __syncthreads();
-            for (int i = tid; i < n * DH; i += NT) {      // o[i][d] = sum_j attn[i][j] v[j][d]
-                const int a = i >> 5, d = i & 31;
+            for (int i = tid; i < n * DH; i += NT) {      // o[a][dd] = sum_b attn[a][b] v[b][dd]
+                const int a = i >> 5, dd = i & 31;
                 float acc = 0.f;
-                for (int b = 0; b < n; ++b) acc += cx[a * n + b] * v[b * DH + d];
+                for (int b = 0; b < n; ++b) acc += cx[a * n + b] * v[b * DH + dd];
                 o[i] = acc;
             }
         }
         __syncthreads();
-        for (int e = tid; e < nC; e += NT) {              // y[n][c] += sum_e o[n][e] Wout[32 h + e][c]
-            const int pix = e / C, c = e - pix * C;
-            const float* w = wo + c;
-            float acc = 0.f;
+        {   // y[pix][c] += sum_e o[pix][e] Wout[32 h + e][c]: thread (c = cc, positions (tid >> lc) + j (NT >> lc))
+            const int pc = tid >> lc, PC = NT >> lc;
+            for (int p0 = pc; p0 < n; p0 += 4 * PC) {
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                const float* op[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) op[j] = o + ((p0 + j * PC) < n ? (p0 + j * PC) : p0) * DH;
 #pragma unroll 8
-            for (int d = 0; d < DH; ++d) acc += o[pix * DH + d] * w[d * C];
-            y[e] += acc;
+                for (int e = 0; e < DH; ++e) {
+                    const float wv = wo[e * C + cc];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] += op[j][e] * wv;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (p0 + j * PC < n) y[(p0 + j * PC) * C + cc] += acc[j];
+            }
         }
         __syncthreads();
     }
     float* out = L + s.out;
     if (!full) {                                          // to_out.1: GroupNorm(1), then the residual
+        const float g2 = gsc(s.g2)[cc], b2 = gsc(s.be2)[cc];
         gn1_stats(y, nC, s.eps, red, &mean, &rstd);
-        for (int e = tid; e < nC; e += NT) { const int c = e % C; out[e] = ((y[e] - mean) * rstd * s.g2[c] + s.be2[c]) + x[e]; }
+#pragma unroll
+        for (int j = 0; j < NO; ++j) { const int e = tid + j * NT; if (e < nC) out[e] = ((y[e] - mean) * rstd * g2 + b2) + x[e]; }
     } else {
-        for (int e = tid; e < nC; e += NT) out[e] = y[e] + x[e];
+#pragma unroll
+        for (int j = 0; j < NO; ++j) { const int e = tid + j * NT; if (e < nC) out[e] = y[e] + x[e]; }
     }
 }
 
 __global__ void __launch_bounds__(NT) unet_sample_kernel(const SampleArgs a) {
     extern __shared__ __attribute__((aligned(16))) float L[];
-    __shared__ float red[8];
-    __shared__ int last, nchunks;
-    __shared__ int2 chunks[64];
+    __shared__ float red[64];
+    __shared__ int last;
     const int b = blockIdx.x, tid = threadIdx.x, HW = a.HW, ch = a.ch;
     float* wbuf = L + a.wbuf_off;                         // 2 x WCH floats: weights on their way to the multiply-add loops
+    const float* zl = L + a.zero_off;                     // 128 zeros: what a tap outside the image reads
     SStep* prog = reinterpret_cast<SStep*>(L + a.prog_off);     // the program itself: a step descriptor read from global memory was a cold round trip per step
     {
         const int nw = a.nsteps * (int)(sizeof(SStep) / 4);
         const unsigned* src = reinterpret_cast<const unsigned*>(a.prog);
         unsigned* dst = reinterpret_cast<unsigned*>(prog);
         for (int i = tid; i < nw; i += NT) dst[i] = src[i];
+        for (int i = tid; i < 128; i += NT) L[a.zero_off + i] = 0.f;
     }
     const int eval = a.evalc ? *a.evalc : 0;
     const float* ss = a.ss_all ? a.ss_all + ((size_t)eval * a.rows + b) * a.S : a.ss + (size_t)b * a.S;
@@ -380,6 +442,13 @@ __global__ void __launch_bounds__(NT) unet_sample_kernel(const SampleArgs a) {
         }
     }
     __syncthreads();
+    // guard: 0 always | 1 only with a mask | 2 only when mask_fusion_conv runs | 3 only without a mask | 4 mask but no fusion | 5 no fusion
+    auto runs = [&](const SStep& s) {
+        const int g = s.guard;
+        return g == 0 || (g == 1 && has_mask) || (g == 2 && a.mask_fuse) || (g == 3 && !has_mask) || (g == 4 && has_mask && !a.mask_fuse) || (g == 5 && !a.mask_fuse);
+    };
+    Pre pre;
+    int have = -1;                                        // the step whose first weights sit in `pre`
     for (int i = 0; i < a.nsteps; ++i) {
         const SStep& s = prog[i];
         if (a.stamps && b == 0 && tid == 0) {
@@ -387,13 +456,21 @@ __global__ void __launch_bounds__(NT) unet_sample_kernel(const SampleArgs a) {
             a.stamps[2 * i + 1] = (unsigned long long)s.op | ((unsigned long long)s.KS << 4) | ((unsigned long long)s.Cout << 8) | ((unsigned long long)(s.C0 + s.C1) << 20) |
                                   ((unsigned long long)s.Hi << 32) | ((unsigned long long)s.guard << 40);
         }
-        // guard: 0 always | 1 only with a mask | 2 only when mask_fusion_conv runs | 3 only without a mask | 4 mask but no fusion | 5 no fusion
-        const int g = s.guard;
-        const bool on = g == 0 || (g == 1 && has_mask) || (g == 2 && a.mask_fuse) || (g == 3 && !has_mask) || (g == 4 && has_mask && !a.mask_fuse) ||
-                        (g == 5 && !a.mask_fuse);
-        if (!on) continue;                                // (uniform over the workgroup)
+        if (!runs(s)) continue;                           // (uniform over the workgroup)
+        const bool needs = reads_weights(s);
+        if (needs) {
+            if (have != i) issue_first(s, pre);           // nobody asked ahead (the first such step)
+            stash_first(s, pre, wbuf);
+            have = -1;
+        }
+        {   // `pre` is free: the first weights of the NEXT step that reads any start travelling now, a whole step ahead of their use
+            int nx = i + 1;
+            while (nx < a.nsteps && !(runs(prog[nx]) && reads_weights(prog[nx]))) ++nx;
+            if (nx < a.nsteps) { issue_first(prog[nx], pre); have = nx; }
+        }
+        if (needs) __syncthreads();
         switch (s.op) {
-            case S_CONV: op_conv(s, L, wbuf, chunks, &nchunks); break;
+            case S_CONV: op_conv(s, L, wbuf, zl); break;
             case S_NORM: op_norm(s, L, ss, red); break;
             case S_BILINEAR: op_bilinear(s, L); break;
             case S_LINATTN: op_attention(s, L, red, wbuf, false); break;
@@ -442,7 +519,7 @@ __global__ void __launch_bounds__(NT) unet_sample_kernel(const SampleArgs a) {
 int unet_sample_init() {
     static bool done = false;
     if (done) return FC_OK;
-    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(unet_sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));   // (the kernel's static LDS: ~0.6 KB)
+    FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(unet_sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));   // (the kernel's static LDS: ~0.3 KB)
     done = true;
     return FC_OK;
 }
