@@ -385,9 +385,8 @@ static void free_plan(fc_unet* u) {
 // Used for inference plans of models whose whole per-sample state fits a CU's LDS (the dim-8 inpainting flow at 4x8x8: BASELINE config 5).
 // Returns FC_OK and leaves ONE launch in the plan, or 1 when the model does not qualify (the caller then builds the ordinary plan).
 static int build_sample_plan(fc_unet* u, Plan* pl, Builder& b, int H, int W) {
-    // OFF unless FLOCODER_AMD_SAMPLE_KERNEL=1 (round 4: built, parity-green, and SLOWER than the plan it was meant to replace -- 1373 us per
-    // evaluation at the dim-8 / 4x8x8 shape against 842 us for the 115 launches: with four waves on a CU nothing covers a step's dependent
-    // round trips to L2 for its weights, and 120 steps of 5-50 us each add up; profiles/r04_sample_kernel_stamps.txt)
+    // OFF unless FLOCODER_AMD_SAMPLE_KERNEL=1 (round 4: built, parity-green, and no faster than the plan it was meant to replace -- 876-892 us per
+    // evaluation at the dim-8 / 4x8x8 shape against 842 us for the 115 launches after five versions; profiles/r04_sample_kernel_stamps.txt)
     static const bool off = [] { const char* e = std::getenv("FLOCODER_AMD_SAMPLE_KERNEL"); return !(e && std::string(e) == "1"); }();
     const fc_unet_config& c = u->cfg;
     const int L = c.n_levels, dim = c.dim, ch = c.channels, G = c.groups, heads = u->heads;

@@ -146,19 +146,21 @@ __device__ __forceinline__ void op_norm(const SStep& s, float* L, const float* s
 }
 
 // Convolution over one or two (concatenated) NHWC sources in LDS; weights packed [tap][Cin][Cout], staged through LDS in the host's chunk
-// list (whole weight rows of the taps some output pixel can reach).  Chunk 0 is in wbuf[0] when this is called.
-__device__ __forceinline__ void op_conv(const SStep& s, float* L, float* wbuf, const float* zl) {
+// list (whole weight rows of the taps some output pixel can reach).  Chunk 0 is in wbuf[0] when this is called.  NJ = output passes a
+// thread makes (its outputs are channel co of NJ pixels): a compile-time count, so the multiply-add loop is branch-free -- one weight
+// read and NJ activation reads feed NJ independent accumulators, four channels per trip with their loads in flight together.
+template <int NJ>
+__device__ __forceinline__ void conv_body(const SStep& s, float* L, float* wbuf, const float* zl) {
     const int tid = threadIdx.x, C0 = s.C0, C1 = s.C1, Cin = C0 + C1, Cout = s.Cout, KS = s.KS, lco = s.lco;
     const float* a0 = L + s.in0;
     const float* a1 = C1 ? L + s.in1 : zl;
     const int Hin = s.Hi << s.ups, Win = s.Wi << s.ups, npix = s.Ho * s.Wo;
     const int co = tid & (Cout - 1), pstep = NT >> lco;
     const float bias = s.bias ? gsc(s.bias)[co] : 0.f;
-    const int nj = (npix + pstep - 1) / pstep;             // output passes in use (uniform)
-    int oy[NO], ox[NO];
-    float acc[NO];
+    int oy[NJ], ox[NJ];
+    float acc[NJ];
 #pragma unroll
-    for (int j = 0; j < NO; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int pix = (tid >> lco) + j * pstep;
         oy[j] = pix < npix ? pix / s.Wo : -1000;
         ox[j] = pix - (pix / s.Wo) * s.Wo;
@@ -174,29 +176,45 @@ __device__ __forceinline__ void op_conv(const SStep& s, float* L, float* wbuf, c
             const int tap = row / Cin, ci0 = row - tap * Cin, ky = tap / KS, kx = tap - ky * KS;
             const int seg = (Cin - ci0 < r1 - row) ? Cin - ci0 : r1 - row;
             const float* w = wb + (size_t)(row - r0) * Cout + co;
-            const float* p0[NO];
-            const float* p1[NO];
+            // the segment's two parts: channels of the first source, then of the second (either may be empty)
+            const int n0 = ci0 < C0 ? ((ci0 + seg < C0 ? ci0 + seg : C0) - ci0) : 0, n1 = seg - n0;
+            const float* p0[NJ];
+            const float* p1[NJ];
 #pragma unroll
-            for (int j = 0; j < NO; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int iy = oy[j] * s.stride - s.pad + ky, ix = ox[j] * s.stride - s.pad + kx;
                 const bool ok = iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
                 const int sp = ok ? (iy >> s.ups) * s.Wi + (ix >> s.ups) : 0;
-                p0[j] = ok ? a0 + sp * C0 : zl;
-                p1[j] = (ok && C1) ? a1 + sp * C1 - C0 : zl - C0;
+                p0[j] = ok ? a0 + sp * C0 + ci0 : zl;
+                p1[j] = (ok && C1) ? a1 + sp * C1 + (ci0 + n0 - C0) : zl;
             }
-            const int e0 = ci0 + seg < C0 ? ci0 + seg : C0;      // the part of the segment inside the first source
-            int ci = ci0;
-#pragma unroll 4
-            for (; ci < e0; ++ci) {
-                const float wv = w[(ci - ci0) * Cout];
+            int i = 0;
+            for (; i + 4 <= n0; i += 4) {
+                const float w0 = w[i * Cout], w1 = w[(i + 1) * Cout], w2 = w[(i + 2) * Cout], w3 = w[(i + 3) * Cout];
 #pragma unroll
-                for (int j = 0; j < NO; ++j) if (j < nj) acc[j] += p0[j][ci] * wv;
+                for (int j = 0; j < NJ; ++j) {
+                    const float x0 = p0[j][i], x1 = p0[j][i + 1], x2 = p0[j][i + 2], x3 = p0[j][i + 3];
+                    acc[j] += x0 * w0; acc[j] += x1 * w1; acc[j] += x2 * w2; acc[j] += x3 * w3;
+                }
             }
-#pragma unroll 4
-            for (; ci < ci0 + seg; ++ci) {
-                const float wv = w[(ci - ci0) * Cout];
+            for (; i < n0; ++i) {
+                const float w0 = w[i * Cout];
 #pragma unroll
-                for (int j = 0; j < NO; ++j) if (j < nj) acc[j] += p1[j][ci] * wv;
+                for (int j = 0; j < NJ; ++j) acc[j] += p0[j][i] * w0;
+            }
+            const float* w2p = w + n0 * Cout;
+            for (i = 0; i + 4 <= n1; i += 4) {
+                const float w0 = w2p[i * Cout], w1 = w2p[(i + 1) * Cout], w2 = w2p[(i + 2) * Cout], w3 = w2p[(i + 3) * Cout];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const float x0 = p1[j][i], x1 = p1[j][i + 1], x2 = p1[j][i + 2], x3 = p1[j][i + 3];
+                    acc[j] += x0 * w0; acc[j] += x1 * w1; acc[j] += x2 * w2; acc[j] += x3 * w3;
+                }
+            }
+            for (; i < n1; ++i) {
+                const float w0 = w2p[i * Cout];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[j] += p1[j][i] * w0;
             }
             row += seg;
         }
@@ -206,7 +224,7 @@ __device__ __forceinline__ void op_conv(const SStep& s, float* L, float* wbuf, c
     const float* res = s.res >= 0 ? L + s.res : nullptr;
     float* y = L + s.out;
 #pragma unroll
-    for (int j = 0; j < NO; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int pix = (tid >> lco) + j * pstep;
         if (pix < npix) {
             const int o = pix * Cout + co;
@@ -216,6 +234,12 @@ __device__ __forceinline__ void op_conv(const SStep& s, float* L, float* wbuf, c
             y[o] = v;
         }
     }
+}
+__device__ __forceinline__ void op_conv(const SStep& s, float* L, float* wbuf, const float* zl) {
+    const int pstep = NT >> s.lco, nj = (s.Ho * s.Wo + pstep - 1) / pstep;        // uniform over the workgroup
+    if (nj <= 1) conv_body<1>(s, L, wbuf, zl);
+    else if (nj == 2) conv_body<2>(s, L, wbuf, zl);
+    else conv_body<4>(s, L, wbuf, zl);
 }
 
 // F.interpolate(mode='bilinear', align_corners=False) of an NHWC tensor in LDS (elementwise.hip bilinear_kernel, same arithmetic)
