@@ -397,9 +397,25 @@ static int build_sample_plan(fc_unet* u, Plan* pl, Builder& b, int H, int W) {
     int top = 0, peak = 0;
     double flops = 0.0;
     auto alloc = [&](int floats) { const int o = top; top += (floats + 3) & ~3; if (top > peak) peak = top; return o; };
-    auto tensor = [&](int C, int h, int w) { T t; t.C = C; t.H = h; t.W = w; t.off = alloc(C * h * w); return t; };
-    auto conv = [&](const T& x, const T* x1, const T& out, const std::string& name, int KS, int pad, int stride, int ups, int act, int res, int guard, bool bias = true) {
+    // block outputs whose last reader has been emitted serve later tensors of the same size (every tensor a step reads or writes is alive
+    // for the whole step, so a buffer may be handed out again only AFTER the step that last read it has been pushed)
+    std::multimap<int, int> pool;
+    auto tensor = [&](int C, int h, int w) {
+        T t; t.C = C; t.H = h; t.W = w;
+        auto it = pool.find(C * h * w);
+        if (it != pool.end()) { t.off = it->second; pool.erase(it); }
+        else t.off = alloc(C * h * w);
+        return t;
+    };
+    auto release = [&](const T& t) { if (t.off >= 0) pool.emplace(t.C * t.H * t.W, t.off); };
+    struct NormSpec { std::string name; int groups = 0, ss_off = -1; };       // a GroupNorm folded into the convolution's epilogue (groups > 0)
+    auto conv = [&](const T& x, const T* x1, const T& out, const std::string& name, int KS, int pad, int stride, int ups, int act, int res, int guard, bool bias = true,
+                    const NormSpec* nm = nullptr) {
         SStep s;
+        if (nm && nm->groups > 0) {
+            s.fnorm = 1; s.G = nm->groups; s.ss_off = nm->ss_off; s.lcpg = ilog2(out.C / nm->groups);
+            s.gamma = u->R(nm->name + ".weight"); s.beta = u->R(nm->name + ".bias");
+        }
         s.op = S_CONV; s.guard = guard; s.in0 = x.off; s.C0 = x.C; s.in1 = x1 ? x1->off : -1; s.C1 = x1 ? x1->C : 0;
         s.out = out.off; s.Cout = out.C; s.Hi = x.H; s.Wi = x.W; s.Ho = out.H; s.Wo = out.W; s.KS = KS; s.pad = pad; s.stride = stride; s.ups = ups;
         s.act = act; s.res = res; s.w = u->P(name + ".weight"); s.bias = bias ? u->R(name + ".bias") : nullptr;
@@ -441,17 +457,17 @@ static int build_sample_plan(fc_unet* u, Plan* pl, Builder& b, int H, int W) {
     auto resblock = [&](const std::string& p, const T& x, const T* skip, int cout) {
         T out = tensor(cout, x.H, x.W);
         const int mark = top, cin = x.C + (skip ? skip->C : 0);
-        T h1 = tensor(cout, x.H, x.W), a1 = tensor(cout, x.H, x.W), h2 = tensor(cout, x.H, x.W);
-        flops += conv(x, skip, h1, p + ".block1.proj", 3, 1, 1, 0, 0, -1, 0);
-        norm(h1, a1, p + ".block1.norm", G, u->ss_off.at(p), 1, -1);
-        flops += conv(a1, nullptr, h2, p + ".block2.proj", 3, 1, 1, 0, 0, -1, 0);
+        // Block = convolution with GroupNorm (+ FiLM) + SiLU in its epilogue (unet.py:57-73); block2 adds the residual there too
+        T a1; a1.C = cout; a1.H = x.H; a1.W = x.W; a1.off = alloc(cout * x.H * x.W);      // (temporaries: stack-allocated above `mark`, never pooled)
+        NormSpec n1{p + ".block1.norm", G, u->ss_off.at(p)}, n2{p + ".block2.norm", G, -1};
+        flops += conv(x, skip, a1, p + ".block1.proj", 3, 1, 1, 0, 1, -1, 0, true, &n1);
         int res = x.off;
         if (cin != cout) {
-            T rb = tensor(cout, x.H, x.W);
+            T rb; rb.C = cout; rb.H = x.H; rb.W = x.W; rb.off = alloc(cout * x.H * x.W);
             flops += conv(x, skip, rb, p + ".res_conv", 1, 0, 1, 0, 0, -1, 0);
             res = rb.off;
         }
-        norm(h2, out, p + ".block2.norm", G, -1, 1, res);
+        flops += conv(a1, nullptr, out, p + ".block2.proj", 3, 1, 1, 0, 1, res, 0, true, &n2);
         top = mark;
         return out;
     };
@@ -460,7 +476,11 @@ static int build_sample_plan(fc_unet* u, Plan* pl, Builder& b, int H, int W) {
         const int mark = top, n = x.H * x.W, hid = heads * 32;
         SStep s;
         s.op = full ? S_ATTN : S_LINATTN; s.in0 = x.off; s.out = out.off; s.C0 = x.C; s.Hi = x.H; s.Wi = x.W;
-        s.scratch = alloc(2 * n * x.C + 3 * n * 32 + (full ? n * n : 32 * 32) + n * 32);
+        if (n == 1) { s.op = S_ATTN1; s.full = full ? 1 : 0; }       // one position: the closed form (unet_sample.hip op_attention1)
+        else if (!full && n <= 64 && x.C <= 16) s.op = S_LINATTN_W;   // a wave per head (all four heads' weights fit the staging buffer: C * 512 floats)
+        s.scratch = alloc(n == 1 ? 2 * x.C + 128 + SAMPLE_THREADS
+                          : s.op == S_LINATTN_W ? 5 * n * x.C + 4 * (n + std::max(n, 32)) * 32
+                          : 2 * n * x.C + 3 * n * 32 + (full ? n * n : 32 * 32) + n * 32);
         s.gamma = u->R(p + ".fn.norm.weight"); s.beta = u->R(p + ".fn.norm.bias");
         s.lc = ilog2(x.C); s.ln = ilog2(n);
         s.w = u->P(p + ".fn.fn.to_qkv.weight");
@@ -481,18 +501,20 @@ static int build_sample_plan(fc_unet* u, Plan* pl, Builder& b, int H, int W) {
     if (c.mask_cond) {                                   // unet.py:298-305: replaces x when a mask is given that is not all ones
         x0 = tensor(dim, H, W);
         const int mark = top;
-        T f1 = tensor(2 * dim, H, W), f2 = tensor(2 * dim, H, W);
+        T f1, f2;
+        f1.C = f2.C = 2 * dim; f1.H = f2.H = H; f1.W = f2.W = W; f1.off = alloc(2 * dim * H * W); f2.off = alloc(2 * dim * H * W);
         conv(xi, &mask, f1, "mask_fusion_conv.0", 5, 2, 1, 0, 1, -1, 2);
         conv(f1, nullptr, f2, "mask_fusion_conv.2", 3, 1, 1, 0, 1, -1, 2);
         conv(f2, nullptr, x0, "mask_fusion_conv.4", 3, 1, 1, 0, 0, -1, 2);
         copy(xi, x0, 5);
         flops += 2.0 * H * W * (25.0 * (dim + ch) * 2 * dim + 9.0 * 2 * dim * 2 * dim + 9.0 * 2 * dim * dim);
         top = mark;
+        release(xi);
     }
     auto inject = [&](const std::string& name, const T& x) {       // x + SiLU(conv3x3(cat[x, bilinear(mask)])), unet.py:336-340,360-364
         T out = tensor(x.C, x.H, x.W);
         const int mark = top;
-        T mr = tensor(ch, x.H, x.W);
+        T mr; mr.C = ch; mr.H = x.H; mr.W = x.W; mr.off = alloc(ch * x.H * x.W);
         SStep s;
         s.op = S_BILINEAR; s.guard = 1; s.in0 = mask.off; s.out = mr.off; s.C0 = ch; s.Hi = H; s.Wi = W; s.Ho = x.H; s.Wo = x.W;
         prog.push_back(s);
@@ -503,33 +525,38 @@ static int build_sample_plan(fc_unet* u, Plan* pl, Builder& b, int H, int W) {
     };
     std::vector<T> skips;
     T x = x0;
+    // `step(y = f(x))`: the new tensor is taken BEFORE the old one is released (they are alive together in the step), the old one after
+    auto next = [&](T& cur, const T& nw, bool keep_old) { if (!keep_old) release(cur); cur = nw; };
     for (int i = 0; i < L; ++i) {
         const std::string p = "downs." + std::to_string(i);
-        x = resblock(p + ".0", x, nullptr, cs[i]);
+        next(x, resblock(p + ".0", x, nullptr, cs[i]), i == 0);                 // (level 0's input is x0: final_res_block reads it)
         skips.push_back(x);
-        x = resblock(p + ".1", x, nullptr, cs[i]);
-        x = attention(p + ".2", x, false);
+        next(x, resblock(p + ".1", x, nullptr, cs[i]), true);                   // the input is a skip
+        next(x, attention(p + ".2", x, false), false);
         skips.push_back(x);
-        if (c.mask_cond && i < 2) x = inject("down_mask_fusions." + std::to_string(i) + ".0", x);
-        if (i == L - 1) { T o = tensor(cs[i + 1], x.H, x.W); flops += conv(x, nullptr, o, p + ".3", 3, 1, 1, 0, 0, -1, 0); x = o; }
-        else { T o = tensor(cs[i + 1], x.H / 2, x.W / 2); flops += conv(x, nullptr, o, p + ".3.1", 2, 0, 2, 0, 0, -1, 0); x = o; }
+        if (c.mask_cond && i < 2) next(x, inject("down_mask_fusions." + std::to_string(i) + ".0", x), true);     // the input is a skip
+        const bool x_is_skip = !(c.mask_cond && i < 2);
+        if (i == L - 1) { T o = tensor(cs[i + 1], x.H, x.W); flops += conv(x, nullptr, o, p + ".3", 3, 1, 1, 0, 0, -1, 0); next(x, o, x_is_skip); }
+        else { T o = tensor(cs[i + 1], x.H / 2, x.W / 2); flops += conv(x, nullptr, o, p + ".3.1", 2, 0, 2, 0, 0, -1, 0); next(x, o, x_is_skip); }
     }
-    x = resblock("mid_block1", x, nullptr, cs[L]);
-    x = attention("mid_attn", x, true);
-    x = resblock("mid_block2", x, nullptr, cs[L]);
+    next(x, resblock("mid_block1", x, nullptr, cs[L]), false);
+    next(x, attention("mid_attn", x, true), false);
+    next(x, resblock("mid_block2", x, nullptr, cs[L]), false);
     for (int i = 0; i < L; ++i) {
         const std::string p = "ups." + std::to_string(i);
         const int din = cs[L - 1 - i], dout = cs[L - i];
         T s1 = skips.back(); skips.pop_back();
-        x = resblock(p + ".0", x, &s1, dout);
+        next(x, resblock(p + ".0", x, &s1, dout), false);
+        release(s1);
         T s2 = skips.back(); skips.pop_back();
-        x = resblock(p + ".1", x, &s2, dout);
-        x = attention(p + ".2", x, false);
-        if (c.mask_cond && i < 2) x = inject("up_mask_fusions." + std::to_string(i) + ".0", x);
-        if (i == L - 1) { T o = tensor(din, x.H, x.W); flops += conv(x, nullptr, o, p + ".3", 3, 1, 1, 0, 0, -1, 0); x = o; }
-        else { T o = tensor(din, x.H * 2, x.W * 2); flops += conv(x, nullptr, o, p + ".3.1", 3, 1, 1, 1, 0, -1, 0); x = o; }
+        next(x, resblock(p + ".1", x, &s2, dout), false);
+        release(s2);
+        next(x, attention(p + ".2", x, false), false);
+        if (c.mask_cond && i < 2) next(x, inject("up_mask_fusions." + std::to_string(i) + ".0", x), false);
+        if (i == L - 1) { T o = tensor(din, x.H, x.W); flops += conv(x, nullptr, o, p + ".3", 3, 1, 1, 0, 0, -1, 0); next(x, o, false); }
+        else { T o = tensor(din, x.H * 2, x.W * 2); flops += conv(x, nullptr, o, p + ".3.1", 3, 1, 1, 1, 0, -1, 0); next(x, o, false); }
     }
-    x = resblock("final_res_block", x, &x0, dim);
+    next(x, resblock("final_res_block", x, &x0, dim), false);
     T v = tensor(ch, H, W);
     flops += conv(x, nullptr, v, "final_conv", 1, 0, 1, 0, 0, -1, 0);
     // every tensor at most four elements per thread, attention at most 64 channels / 64 keys (unet_sample.hip's register and staging budgets)
@@ -538,6 +565,9 @@ static int build_sample_plan(fc_unet* u, Plan* pl, Builder& b, int H, int W) {
     for (const SStep& s : prog) {
         if (s.op == S_CONV && (s.Ho * s.Wo * s.Cout > cap || !is_pow2(s.Cout) || s.Cout < 4 || s.Cout > SAMPLE_THREADS || s.nchunk > 8 || s.C0 > 128 || s.C1 > 128)) return 1;
         if (s.op == S_NORM && (s.Hi * s.Wi * s.C0 > cap || !is_pow2(s.C0) || s.C0 > 64 || !is_pow2(s.C0 / s.G) || s.G > 8)) return 1;
+        if (s.op == S_CONV && s.fnorm && (s.Cout > 64 || !is_pow2(s.Cout / s.G) || s.G > 8)) return 1;
+        if (s.op == S_LINATTN_W && (s.C0 > 16 || s.C0 < 4 || !is_pow2(s.C0) || !is_pow2(s.Hi * s.Wi) || s.Hi * s.Wi > 64)) return 1;
+        if (s.op == S_ATTN1 && (s.C0 > 64 || s.C0 < 8 || !is_pow2(s.C0))) return 1;
         if ((s.op == S_ATTN || s.op == S_LINATTN) && (s.C0 > 64 || s.C0 < 4 || !is_pow2(s.C0) || !is_pow2(s.Hi * s.Wi) || s.Hi * s.Wi * s.C0 > cap)) return 1;
         if (s.op == S_ATTN && s.Hi * s.Wi > 64) return 1;
     }
@@ -545,7 +575,8 @@ static int build_sample_plan(fc_unet* u, Plan* pl, Builder& b, int H, int W) {
     const int zero_off = alloc(128);
     const int wbuf_off = alloc(2 * 4096), prog_off = alloc((int)(prog.size() * sizeof(SStep) / 4) + 4);
     const size_t lds = (size_t)peak * sizeof(float);
-    if (lds > 150 * 1024) return 1;                       // the sample does not fit a CU: ordinary plan
+    if (std::getenv("FLOCODER_AMD_SAMPLE_KERNEL_DEBUG")) fprintf(stderr, "[unet_sample] %zu steps, %zu bytes of LDS per sample\n", prog.size(), lds);
+    if (lds > 158 * 1024) return 1;                       // the sample does not fit a CU: ordinary plan
     FC_TRY(unet_sample_init());
     SStep* dev = reinterpret_cast<SStep*>(b.dmalloc((prog.size() * sizeof(SStep) + 3) / 4 + 4));
     unsigned* done = reinterpret_cast<unsigned*>(b.dmalloc(4));

@@ -6,7 +6,7 @@ namespace fc {
 
 constexpr int SAMPLE_THREADS = 256;       // threads of a sample's workgroup
 
-enum SampleOp { S_CONV = 0, S_NORM = 1, S_BILINEAR = 2, S_LINATTN = 3, S_ATTN = 4, S_COPY = 5 };
+enum SampleOp { S_CONV = 0, S_NORM = 1, S_BILINEAR = 2, S_LINATTN = 3, S_ATTN = 4, S_COPY = 5, S_ATTN1 = 6, S_LINATTN_W = 7 };   // S_ATTN1: either attention on ONE position; S_LINATTN_W: LinearAttention, a wave per head
 
 struct SStep {
     int op = 0;
@@ -25,6 +25,8 @@ struct SStep {
     int crow[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // first row (tap * Cin + ci) of chunk k
     int cn[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // rows in chunk k
     int lco = 0;              // log2(Cout) (convolution)
+    int fnorm = 0;            // convolution: 1 = GroupNorm (G, gamma, beta, ss_off, eps) + SiLU (`act`) + `res` applied to the result in the epilogue
+    int full = 0;             // S_ATTN1: 1 = Attention (no to_out norm), 0 = LinearAttention
     int lc = 0, lcpg = 0;     // log2(C0), log2(channels per GroupNorm group) (norm, attention)
     int ln = 0;               // log2(pixels) (attention)
     const float* w = nullptr;      // conv: packed [tap][Cin][Cout]; attention: to_qkv [C][384]

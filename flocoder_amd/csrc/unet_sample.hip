@@ -95,9 +95,12 @@ __device__ __forceinline__ void stash_head(const SStep& s, const Pre& r, float* 
     if (t < no4) wo[t] = r.r6;
     if (t + NT < no4) wo[t + NT] = r.r7;
 }
-__device__ __forceinline__ bool reads_weights(const SStep& s) { return s.op == S_CONV || s.op == S_LINATTN || s.op == S_ATTN; }
-__device__ __forceinline__ void issue_first(const SStep& s, Pre& r) { if (s.op == S_CONV) issue_conv_chunk(s, 0, r); else issue_head(s, 0, r); }
-__device__ __forceinline__ void stash_first(const SStep& s, const Pre& r, float* wbuf) { if (s.op == S_CONV) stash_conv_chunk(s, 0, r, wbuf); else stash_head(s, r, wbuf); }
+__device__ __forceinline__ bool reads_weights(const SStep& s) { return s.op == S_CONV || s.op == S_LINATTN || s.op == S_ATTN || s.op == S_ATTN1 || s.op == S_LINATTN_W; }
+__device__ __forceinline__ void issue_wv(const SStep& s, Pre& r);
+__device__ __forceinline__ void issue_allheads(const SStep& s, Pre& r);
+__device__ __forceinline__ void stash_flat8(const Pre& r, int n4, float* wbuf);
+__device__ __forceinline__ void issue_first(const SStep& s, Pre& r) { if (s.op == S_CONV) issue_conv_chunk(s, 0, r); else if (s.op == S_ATTN1) issue_wv(s, r); else if (s.op == S_LINATTN_W) issue_allheads(s, r); else issue_head(s, 0, r); }
+__device__ __forceinline__ void stash_first(const SStep& s, const Pre& r, float* wbuf) { if (s.op == S_CONV) stash_conv_chunk(s, 0, r, wbuf); else if (s.op == S_ATTN1) stash_flat8(r, s.C0 * 32, wbuf); else if (s.op == S_LINATTN_W) stash_flat8(r, s.C0 * 128, wbuf); else stash_head(s, r, wbuf); }
 
 // y = [act]( (x - mean_g) * rstd_g * gamma + beta  [* (scale + 1) + shift] ) [+ res]     GroupNorm over (channels of a group) x pixels.
 // A thread's elements e = tid + j NT are the SAME channel c = tid & (C - 1) of different pixels (C <= 64 divides NT), so they lie in one
@@ -150,7 +153,7 @@ __device__ __forceinline__ void op_norm(const SStep& s, float* L, const float* s
 // thread makes (its outputs are channel co of NJ pixels): a compile-time count, so the multiply-add loop is branch-free -- one weight
 // read and NJ activation reads feed NJ independent accumulators, four channels per trip with their loads in flight together.
 template <int NJ>
-__device__ __forceinline__ void conv_body(const SStep& s, float* L, float* wbuf, const float* zl) {
+__device__ __forceinline__ void conv_body(const SStep& s, float* L, float* wbuf, const float* zl, const float* ss, float* red) {
     const int tid = threadIdx.x, C0 = s.C0, C1 = s.C1, Cin = C0 + C1, Cout = s.Cout, KS = s.KS, lco = s.lco;
     const float* a0 = L + s.in0;
     const float* a1 = C1 ? L + s.in1 : zl;
@@ -223,6 +226,49 @@ __device__ __forceinline__ void conv_body(const SStep& s, float* L, float* wbuf,
     }
     const float* res = s.res >= 0 ? L + s.res : nullptr;
     float* y = L + s.out;
+    if (s.fnorm) {
+        // GroupNorm (+ FiLM) of the result right here: this thread's outputs are channel `co` of NJ pixels, i.e. ONE group; the group's sums
+        // run over the lane bits that do not select it (op_norm's reduction, on registers), then over the waves.  A step and a trip of
+        // the tensor through LDS less per Block half.
+        const int lane = tid & 63, lcpg = s.lcpg, g = co >> lcpg;
+        const float pg = gsc(s.gamma)[co], pb = gsc(s.beta)[co];
+        float psc = 0.f, psh = 0.f;
+        if (s.ss_off >= 0) { psc = gsc(ss)[s.ss_off + co]; psh = gsc(ss)[s.ss_off + Cout + co]; }
+        float v[NJ], a = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { const bool on = (tid >> lco) + j * pstep < npix; v[j] = on ? acc[j] + bias : 0.f; a += v[j]; }
+        const float cnt = (float)(npix << lcpg);
+        const int rmask = (((1 << lcpg) - 1) | ~((1 << lco) - 1)) & 63;
+        auto group_sum = [&](float t) {
+#pragma unroll
+            for (int b2 = 0; b2 < 6; ++b2) if ((rmask >> b2) & 1) t += __shfl_xor(t, 1 << b2);
+            __syncthreads();
+            if ((lane & rmask) == 0) red[(tid >> 6) * 8 + g] = t;
+            __syncthreads();
+            float r = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < NT / 64; ++w2) r += red[w2 * 8 + g];
+            return r;
+        };
+        const float mean = group_sum(a) / cnt;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) if ((tid >> lco) + j * pstep < npix) { const float d = v[j] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(group_sum(q) / cnt + s.eps);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int pix = (tid >> lco) + j * pstep;
+            if (pix < npix) {
+                const int o = pix * Cout + co;
+                float t = (v[j] - mean) * rstd * pg + pb;
+                if (s.ss_off >= 0) t = t * (psc + 1.0f) + psh;
+                if (s.act) t = silu(t);
+                if (res) t += res[o];
+                y[o] = t;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int pix = (tid >> lco) + j * pstep;
@@ -235,11 +281,11 @@ __device__ __forceinline__ void conv_body(const SStep& s, float* L, float* wbuf,
         }
     }
 }
-__device__ __forceinline__ void op_conv(const SStep& s, float* L, float* wbuf, const float* zl) {
+__device__ __forceinline__ void op_conv(const SStep& s, float* L, float* wbuf, const float* zl, const float* ss, float* red) {
     const int pstep = NT >> s.lco, nj = (s.Ho * s.Wo + pstep - 1) / pstep;        // uniform over the workgroup
-    if (nj <= 1) conv_body<1>(s, L, wbuf, zl);
-    else if (nj == 2) conv_body<2>(s, L, wbuf, zl);
-    else conv_body<4>(s, L, wbuf, zl);
+    if (nj <= 1) conv_body<1>(s, L, wbuf, zl, ss, red);
+    else if (nj == 2) conv_body<2>(s, L, wbuf, zl, ss, red);
+    else conv_body<4>(s, L, wbuf, zl, ss, red);
 }
 
 // F.interpolate(mode='bilinear', align_corners=False) of an NHWC tensor in LDS (elementwise.hip bilinear_kernel, same arithmetic)
@@ -438,6 +484,231 @@ __device__ __forceinline__ void op_attention(const SStep& s, float* L, float* re
     }
 }
 
+// Either attention module on ONE position (the 1x1 level): the softmaxes collapse -- LinearAttention: k's softmax over a single position is
+// 1, so the context is v itself and out = (sum_d softmax_d(q) * scale) v = scale * v; Attention: one key, attn = 1, out = v -- and the module is
+// two matrix-vector products: v = GN1(x) . Wv (all four heads: the last 128 columns of to_qkv), y = b + f v . Wout, then to_out.1's
+// GroupNorm(1) (LinearAttention only) and the residual.  The general kernel spent ~30 us here on 4 heads x 7 barrier-separated phases.
+// wbuf holds Wv ([C][128], requested a step ahead) on entry; Wout ([128][C]) is staged here.
+__device__ __forceinline__ void issue_wv(const SStep& s, Pre& r) {        // row c, columns 256..383 of to_qkv: 32 float4's per row
+    const int n4 = s.C0 * 32, t = threadIdx.x;
+#define FC_WV(k) gptr(s.w + (size_t)((t + (k) * NT) >> 5) * 384 + 256 + 4 * ((t + (k) * NT) & 31))
+    FC_LD4(r.r0, t < n4, FC_WV(0)); FC_LD4(r.r1, t + NT < n4, FC_WV(1)); FC_LD4(r.r2, t + 2 * NT < n4, FC_WV(2)); FC_LD4(r.r3, t + 3 * NT < n4, FC_WV(3));
+    FC_LD4(r.r4, t + 4 * NT < n4, FC_WV(4)); FC_LD4(r.r5, t + 5 * NT < n4, FC_WV(5)); FC_LD4(r.r6, t + 6 * NT < n4, FC_WV(6)); FC_LD4(r.r7, t + 7 * NT < n4, FC_WV(7));
+#undef FC_WV
+}
+__device__ __forceinline__ void issue_flat8(const float* src, int n4, Pre& r) {   // up to 8 float4's per thread of a contiguous block
+    gf4p p = gptr(src);
+    const int t = threadIdx.x;
+    FC_LD4(r.r0, t < n4, p + t); FC_LD4(r.r1, t + NT < n4, p + t + NT); FC_LD4(r.r2, t + 2 * NT < n4, p + t + 2 * NT); FC_LD4(r.r3, t + 3 * NT < n4, p + t + 3 * NT);
+    FC_LD4(r.r4, t + 4 * NT < n4, p + t + 4 * NT); FC_LD4(r.r5, t + 5 * NT < n4, p + t + 5 * NT); FC_LD4(r.r6, t + 6 * NT < n4, p + t + 6 * NT); FC_LD4(r.r7, t + 7 * NT < n4, p + t + 7 * NT);
+}
+__device__ __forceinline__ void stash_flat8(const Pre& r, int n4, float* wbuf) {
+    f4v* d = reinterpret_cast<f4v*>(wbuf);
+    const int t = threadIdx.x;
+    if (t < n4) d[t] = r.r0;
+    if (t + NT < n4) d[t + NT] = r.r1;
+    if (t + 2 * NT < n4) d[t + 2 * NT] = r.r2;
+    if (t + 3 * NT < n4) d[t + 3 * NT] = r.r3;
+    if (t + 4 * NT < n4) d[t + 4 * NT] = r.r4;
+    if (t + 5 * NT < n4) d[t + 5 * NT] = r.r5;
+    if (t + 6 * NT < n4) d[t + 6 * NT] = r.r6;
+    if (t + 7 * NT < n4) d[t + 7 * NT] = r.r7;
+}
+__device__ __forceinline__ void issue_allheads(const SStep& s, Pre& r) {   // to_qkv [C][384] then to_out.0 [128][C], as one run of C * 128 float4's (C <= 16)
+    const int nq4 = s.C0 * 96, n4 = s.C0 * 128, t = threadIdx.x;
+    gf4p q = gptr(s.w), o = gptr(s.w2);
+#define FC_AH(k) ((t + (k) * NT) < nq4 ? q + (t + (k) * NT) : o + ((t + (k) * NT) - nq4))
+    FC_LD4(r.r0, t < n4, FC_AH(0)); FC_LD4(r.r1, t + NT < n4, FC_AH(1)); FC_LD4(r.r2, t + 2 * NT < n4, FC_AH(2)); FC_LD4(r.r3, t + 3 * NT < n4, FC_AH(3));
+    FC_LD4(r.r4, t + 4 * NT < n4, FC_AH(4)); FC_LD4(r.r5, t + 5 * NT < n4, FC_AH(5)); FC_LD4(r.r6, t + 6 * NT < n4, FC_AH(6)); FC_LD4(r.r7, t + 7 * NT < n4, FC_AH(7));
+#undef FC_AH
+}
+__device__ __forceinline__ void op_attention1(const SStep& s, float* L, float* red, float* wbuf) {
+    const int tid = threadIdx.x, C = s.C0;
+    const float* x = L + s.in0;
+    float* xn = L + s.scratch;          // [C]
+    float* vv = xn + C;                 // [128]
+    float* y = vv + 128;                // [C]
+    Pre wo;
+    issue_flat8(s.w2, 32 * C, wo);      // Wout [128][C]: in flight while v is computed
+    const int cc = tid & (C - 1);
+    const float pg = gsc(s.gamma)[cc], pb = gsc(s.beta)[cc], pbo = gsc(s.b2)[cc];
+    float g2 = 1.f, b2 = 0.f;
+    if (!s.full) { g2 = gsc(s.g2)[cc]; b2 = gsc(s.be2)[cc]; }
+    float mean, rstd;
+    gn1_stats(x, C, s.eps, red, &mean, &rstd);
+    if (tid < C) xn[tid] = (x[tid] - mean) * rstd * pg + pb;
+    __syncthreads();
+    {   // v[j] = sum_c xn[c] Wv[c][j]: thread (j = tid & 127, half of the channels), halves met by one LDS add
+        const int j = tid & 127, part = tid >> 7, ch = C >> 1;
+        const float* w = wbuf + j;
+        float acc = 0.f;
+#pragma unroll 4
+        for (int c = part * ch; c < (part + 1) * ch; ++c) acc += xn[c] * w[c * 128];
+        if (part == 1) vv[j] = acc;
+        __syncthreads();
+        if (part == 0) vv[j] += acc;
+    }
+    __syncthreads();
+    stash_flat8(wo, 32 * C, wbuf);      // every reader of Wv has passed the barrier above
+    __syncthreads();
+    {   // y[c] = b[c] + f sum_j v[j] Wout[j][c]: thread (c = tid & (C - 1), slice of the 128 rows)
+        const int parts = NT >> s.lc, part = tid >> s.lc, per = 128 / parts;
+        const float* w = wbuf + cc;
+        float acc = 0.f;
+#pragma unroll 4
+        for (int j = part * per; j < (part + 1) * per; ++j) acc += vv[j] * w[j * C];
+        float* tmp = L + s.scratch + 2 * C + 128;      // [parts][C]
+        tmp[part * C + cc] = acc;
+        __syncthreads();
+        if (tid < C) {
+            float t = 0.f;
+            for (int p2 = 0; p2 < parts; ++p2) t += tmp[p2 * C + tid];
+            y[tid] = pbo + (s.full ? 1.0f : 0.17677669529663687f) * t;
+        }
+    }
+    __syncthreads();
+    float* out = L + s.out;
+    if (!s.full) {
+        gn1_stats(y, C, s.eps, red, &mean, &rstd);
+        if (tid < C) out[tid] = ((y[tid] - mean) * rstd * g2 + b2) + x[tid];
+    } else if (tid < C) out[tid] = y[tid] + x[tid];
+}
+
+// LinearAttention with a WAVE PER HEAD (C <= 16: all four heads' weights fit the staging buffer).  In the general form the four heads run one
+// after the other, each as seven phases of the whole workgroup with a barrier between them -- ~30 us per module however little there is to
+// compute.  The heads never meet before to_out, so here wave h does head h on its own: k and v, k's softmax, the context; then q (into k's
+// place), its softmax, the output (into v's place) and the head's share of to_out.0 -- all in a wave-private part of the scratch, ordered by
+// the wave's own in-order LDS traffic (no workgroup barrier).  The shares meet once, at the end, in a fixed order.  wbuf holds all four
+// heads' weights on entry: to_qkv [C][384] then to_out.0 [128][C] (requested a step ahead).
+// scratch: xn [n][C] | yh [4][n][C] | per head: a [n][32] (k, then q) | b [n][32] (v, then o) | ctx [32][32]
+__device__ __forceinline__ void op_linattn_w(const SStep& s, float* L, float* red, float* wbuf) {
+    const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6, C = s.C0, lc = s.lc, n = s.Hi * s.Wi, nC = n * C;
+    constexpr int DH = 32;
+    const float* x = L + s.in0;
+    float* xn = L + s.scratch;
+    float* yh = xn + nC;
+    // per head: a[n][32] (k, then q, then the head's output IN PLACE) | b[max(n, 32)][32] (v, then the 32 x 32 context where v was)
+    const int nb = n > DH ? n : DH;
+    float* ha = yh + 4 * nC + h * ((n + nb) * DH);
+    float* hb = ha + n * DH;
+    float* ctx = hb;
+    const float* wq = wbuf;                               // [C][384]
+    const float* wo = wbuf + C * 384;                     // [128][C]
+    const int cc = tid & (C - 1);
+    const float pg = gsc(s.gamma)[cc], pb = gsc(s.beta)[cc], pbo = gsc(s.b2)[cc], g2 = gsc(s.g2)[cc], b2 = gsc(s.be2)[cc];
+    float mean, rstd;
+    gn1_stats(x, nC, s.eps, red, &mean, &rstd);
+#pragma unroll
+    for (int j = 0; j < NO; ++j) { const int e = tid + j * NT; if (e < nC) xn[e] = (x[e] - mean) * rstd * pg + pb; }
+    __syncthreads();
+    const int d = lane & 31, hf = lane >> 5;              // channel of the head, half of the wave
+    // a projection of this head: lane (d, hf) does positions hf, hf + 2, ...; four of them share a weight value
+    auto project = [&](int which, float* dst) {
+        const float* w = wq + which * 128 + h * DH + d;
+        for (int p0 = hf; p0 < n; p0 += 8) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            const float* xp[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xp[j] = xn + (p0 + 2 * j < n ? p0 + 2 * j : p0) * C;
+#pragma unroll 4
+            for (int c = 0; c < C; ++c) {
+                const float wv = w[c * 384];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] += xp[j][c] * wv;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (p0 + 2 * j < n) dst[(p0 + 2 * j) * DH + d] = acc[j];
+        }
+    };
+    project(1, ha);                                       // k
+    project(2, hb);                                       // v
+    __builtin_amdgcn_wave_barrier();
+    {   // k: softmax over the positions, column d; the two halves of the wave split the positions
+        float m = -INFINITY;
+        for (int p = hf; p < n; p += 2) m = fmaxf(m, ha[p * DH + d]);
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float sum = 0.f;
+        for (int p = hf; p < n; p += 2) { const float e = __expf(ha[p * DH + d] - m); ha[p * DH + d] = e; sum += e; }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        for (int p = hf; p < n; p += 2) ha[p * DH + d] *= inv;
+    }
+    __builtin_amdgcn_wave_barrier();
+    {   // ctx[dd][e] = sum_p k[p][dd] v[p][e]: lane (e = d, rows dd = 16 hf .. 16 hf + 15)
+        float acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int p = 0; p < n; ++p) {
+            const float vv = hb[p * DH + d];
+            const float* kp = ha + p * DH + 16 * hf;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] += kp[i] * vv;
+        }
+        __builtin_amdgcn_wave_barrier();                   // every lane's reads of v are done (one wave per head, in lockstep): the context takes its place
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ctx[(16 * hf + i) * DH + d] = acc[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    project(0, ha);                                       // q, where k was
+    __builtin_amdgcn_wave_barrier();
+    // q: softmax over the 32 channels of a position (a half-wave per position), * scale
+    for (int p = hf; p < n + hf; p += 2) {
+        const bool on = p < n;
+        const float v = on ? ha[p * DH + d] : 0.f;
+        float m = v;
+        m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4)); m = fmaxf(m, __shfl_xor(m, 8)); m = fmaxf(m, __shfl_xor(m, 16));
+        const float e = __expf(v - m);
+        float sum = e;
+        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8); sum += __shfl_xor(sum, 16);
+        if (on) ha[p * DH + d] = e * (0.17677669529663687f / sum);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // o[p][e] = sum_dd q[p][dd] ctx[dd][e], written over q's row p: the 32 lanes that read a row are the ones that write it, after their last read
+    for (int p0 = hf; p0 < n; p0 += 8) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* qp[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) qp[j] = ha + (p0 + 2 * j < n ? p0 + 2 * j : p0) * DH;
+#pragma unroll 8
+        for (int dd = 0; dd < DH; ++dd) {
+            const float cv = ctx[dd * DH + d];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += qp[j][dd] * cv;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (p0 + 2 * j < n) ha[(p0 + 2 * j) * DH + d] = acc[j];
+    }
+    __builtin_amdgcn_wave_barrier();
+    {   // this head's share of to_out.0: yh[h][p][c] = sum_e o[p][e] Wout[32 h + e][c]: lane -> (c = lane & (C - 1), positions (lane >> lc) + k (64 >> lc))
+        const int c = lane & (C - 1), pl = lane >> lc, PL = 64 >> lc;
+        const float* w = wo + (size_t)(h * DH) * C + c;
+        for (int p = pl; p < n; p += PL) {
+            float acc = 0.f;
+#pragma unroll 8
+            for (int e = 0; e < DH; ++e) acc += ha[p * DH + e] * w[e * C];
+            yh[(h * n + p) * C + c] = acc;
+        }
+    }
+    __syncthreads();
+    // y = bias + the four shares (fixed order), then to_out.1's GroupNorm(1) and the residual
+    float yv[NO], a1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+        const int e = tid + j * NT;
+        yv[j] = 0.f;
+        if (e < nC) { yv[j] = pbo + ((yh[e] + yh[nC + e]) + (yh[2 * nC + e] + yh[3 * nC + e])); a1 += yv[j]; }
+    }
+    const float m2 = block_sum(a1, red) / (float)nC;
+    float q2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NO; ++j) { const int e = tid + j * NT; if (e < nC) { const float dlt = yv[j] - m2; q2 += dlt * dlt; } }
+    const float r2 = 1.0f / sqrtf(block_sum(q2, red) / (float)nC + s.eps);
+    float* out = L + s.out;
+#pragma unroll
+    for (int j = 0; j < NO; ++j) { const int e = tid + j * NT; if (e < nC) out[e] = ((yv[j] - m2) * r2 * g2 + b2) + x[e]; }
+}
+
 __global__ void __launch_bounds__(NT) unet_sample_kernel(const SampleArgs a) {
     extern __shared__ __attribute__((aligned(16))) float L[];
     __shared__ float red[64];
@@ -494,11 +765,13 @@ __global__ void __launch_bounds__(NT) unet_sample_kernel(const SampleArgs a) {
         }
         if (needs) __syncthreads();
         switch (s.op) {
-            case S_CONV: op_conv(s, L, wbuf, zl); break;
+            case S_CONV: op_conv(s, L, wbuf, zl, ss, red); break;
             case S_NORM: op_norm(s, L, ss, red); break;
             case S_BILINEAR: op_bilinear(s, L); break;
             case S_LINATTN: op_attention(s, L, red, wbuf, false); break;
             case S_ATTN: op_attention(s, L, red, wbuf, true); break;
+            case S_ATTN1: op_attention1(s, L, red, wbuf); break;
+            case S_LINATTN_W: op_linattn_w(s, L, red, wbuf); break;
             case S_COPY: for (int e = tid; e < s.Cout; e += NT) L[s.out + e] = L[s.in0 + e]; break;
         }
         __syncthreads();

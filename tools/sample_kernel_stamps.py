@@ -27,7 +27,7 @@ with torch.no_grad():
     torch.cuda.synchronize()
     B.check(B.lib().fc_debug_set_conv_stamps(None))
 v = buf.cpu().tolist()
-names = {0: "conv", 1: "norm", 2: "bilinear", 3: "linattn", 4: "attn", 5: "copy", 255: "end"}
+names = {0: "conv", 1: "norm", 2: "bilinear", 3: "linattn", 4: "attn", 5: "copy", 6: "attn1", 7: "linattn_w", 255: "end"}
 rows, i = [], 0
 while v[2 * i + 1] != 255 and i < 2000:
     code = v[2 * i + 1]
