@@ -384,10 +384,14 @@ static void free_plan(fc_unet* u) {
 // ---- one workgroup per sample (unet_sample.hip): the forward as a program over LDS-resident activations -------------------------------
 // Used for inference plans of models whose whole per-sample state fits a CU's LDS (the dim-8 inpainting flow at 4x8x8: BASELINE config 5).
 // Returns FC_OK and leaves ONE launch in the plan, or 1 when the model does not qualify (the caller then builds the ordinary plan).
-static int build_sample_plan(fc_unet* u, Plan* pl, Builder& b, int H, int W) {
-    // OFF unless FLOCODER_AMD_SAMPLE_KERNEL=1 (round 4: built, parity-green, and no faster than the plan it was meant to replace -- 876-892 us per
-    // evaluation at the dim-8 / 4x8x8 shape against 842 us for the 115 launches after five versions; profiles/r04_sample_kernel_stamps.txt)
-    static const bool off = [] { const char* e = std::getenv("FLOCODER_AMD_SAMPLE_KERNEL"); return !(e && std::string(e) == "1"); }();
+static int build_sample_plan(fc_unet* u, Plan* pl, Builder& b, int maxB, int H, int W) {
+    // ON for the models that qualify unless FLOCODER_AMD_SAMPLE_KERNEL=0 (round 4, config 5's dim-8 / 4x8x8 flow: 538 us per evaluation
+    // against 842 us for the 115 launches of the ordinary plan; profiles/r04_sample_kernel_stamps.txt).  A sample
+    // is ONE workgroup, so the kernel's time is that of one sample as long as every sample has a CU of its own: beyond that the ordinary
+    // plan (whose launches grow wider, not longer) wins again -- batches larger than the CU count keep it.
+    static const bool off = [] { const char* e = std::getenv("FLOCODER_AMD_SAMPLE_KERNEL"); return e && std::string(e) == "0"; }();
+    static const int cus = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0; return n; }();
+    if (maxB > cus) return 1;
     const fc_unet_config& c = u->cfg;
     const int L = c.n_levels, dim = c.dim, ch = c.channels, G = c.groups, heads = u->heads;
     if (off || u->keep_all || G > 8 || heads != 4 || u->nchains > 1) return 1;
@@ -421,7 +425,7 @@ static int build_sample_plan(fc_unet* u, Plan* pl, Builder& b, int H, int W) {
         s.act = act; s.res = res; s.w = u->P(name + ".weight"); s.bias = bias ? u->R(name + ".bias") : nullptr;
         s.lco = ilog2(out.C);
         {   // the weight rows some output pixel can reach, merged where contiguous, cut into chunks of <= 4096 floats
-            const int Cin = s.C0 + s.C1, Hin = x.H << ups, Win = x.W << ups, RW = 4096 / out.C;
+            const int Cin = s.C0 + s.C1, Hin = x.H << ups, Win = x.W << ups, RW0 = 4096 / out.C;
             int kx_lo = KS, kx_hi = -1;
             for (int kx = 0; kx < KS; ++kx) if ((out.W - 1) * stride - pad + kx >= 0 && -pad + kx < Win) { if (kx < kx_lo) kx_lo = kx; kx_hi = kx; }
             std::vector<std::pair<int, int>> ranges;
@@ -431,6 +435,8 @@ static int build_sample_plan(fc_unet* u, Plan* pl, Builder& b, int H, int W) {
                 if (!ranges.empty() && ranges.back().second == r0) ranges.back().second = r1;
                 else ranges.push_back({r0, r1});
             }
+            // (whole taps per chunk where a tap's rows fit one; whole channel quads otherwise)
+            const int RW = RW0 >= Cin ? (RW0 / Cin) * Cin : (RW0 & ~3);
             int nck = 0;
             for (auto& rg : ranges)
                 for (int r = rg.first; r < rg.second; r += RW) {
@@ -438,16 +444,20 @@ static int build_sample_plan(fc_unet* u, Plan* pl, Builder& b, int H, int W) {
                     ++nck;
                 }
             s.nchunk = nck;                              // > 8: the model does not qualify (checked below)
+            // lanes per output quad: as many as fill the workgroup, at most the channel quads of a tap
+            const int quads = out.H * out.W * out.C / 4, CQ = Cin / 4;
+            while (s.lks < 6 && (quads << (s.lks + 1)) <= SAMPLE_THREADS && (2 << s.lks) <= CQ) ++s.lks;
+            // the unrolled multiply-add: ONE chunk of one tap or of all nine taps of a 3x3 kernel, the lanes of a quad dividing a tap's channel
+            // quads evenly, at most four each
+            const int ntaps = nck == 1 ? s.cn[0] / Cin : 0;
+            if (nck == 1 && s.cn[0] == ntaps * Cin && (ntaps == 1 || (ntaps == 9 && KS == 3 && s.crow[0] == 0))) {
+                int lf = 0;
+                while (lf < 6 && (quads << (lf + 1)) <= SAMPLE_THREADS && CQ % (2 << lf) == 0) ++lf;
+                if (CQ >> lf <= 4) { s.lks = lf; s.nqi = CQ >> lf; s.fast = ntaps; }
+            }
         }
         prog.push_back(s);
         return 2.0 * out.H * out.W * KS * KS * (double)(s.C0 + s.C1) * out.C;
-    };
-    auto norm = [&](const T& x, const T& out, const std::string& name, int groups, int ss_off, int act, int res) {
-        SStep s;
-        s.op = S_NORM; s.in0 = x.off; s.out = out.off; s.C0 = x.C; s.Hi = x.H; s.Wi = x.W; s.G = groups; s.ss_off = ss_off; s.act = act; s.res = res;
-        s.gamma = u->R(name + ".weight"); s.beta = u->R(name + ".bias");
-        s.lc = ilog2(x.C); s.lcpg = ilog2(x.C / groups);
-        prog.push_back(s);
     };
     auto copy = [&](const T& x, const T& out, int guard) {
         SStep s;
@@ -563,7 +573,7 @@ static int build_sample_plan(fc_unet* u, Plan* pl, Builder& b, int H, int W) {
     // (powers of two throughout: the kernel indexes by shifts and masks)
     const int cap = 4 * SAMPLE_THREADS;
     for (const SStep& s : prog) {
-        if (s.op == S_CONV && (s.Ho * s.Wo * s.Cout > cap || !is_pow2(s.Cout) || s.Cout < 4 || s.Cout > SAMPLE_THREADS || s.nchunk > 8 || s.C0 > 128 || s.C1 > 128)) return 1;
+        if (s.op == S_CONV && (s.Ho * s.Wo * s.Cout > cap || !is_pow2(s.Cout) || s.Cout < 4 || s.Cout > SAMPLE_THREADS || s.nchunk > 8 || (s.C0 & 3) || (s.C1 & 3) || s.C0 + s.C1 > 128)) return 1;     // (channel quads; the zero line is 128 floats)
         if (s.op == S_NORM && (s.Hi * s.Wi * s.C0 > cap || !is_pow2(s.C0) || s.C0 > 64 || !is_pow2(s.C0 / s.G) || s.G > 8)) return 1;
         if (s.op == S_CONV && s.fnorm && (s.Cout > 64 || !is_pow2(s.Cout / s.G) || s.G > 8)) return 1;
         if (s.op == S_LINATTN_W && (s.C0 > 16 || s.C0 < 4 || !is_pow2(s.C0) || !is_pow2(s.Hi * s.Wi) || s.Hi * s.Wi > 64)) return 1;
@@ -640,7 +650,7 @@ static int build_plan(fc_unet* u, Plan* pl, int maxB, int H, int W) {
     }
 
     {   // small models: the whole forward of a sample in one workgroup (unet_sample.hip); 1 = does not qualify
-        const int r = build_sample_plan(u, pl, b, H, W);
+        const int r = build_sample_plan(u, pl, b, maxB, H, W);
         if (r != 1) {
             if (r != FC_OK) return r;
             pl->join_at = (int)pl->ops.size();

@@ -25,6 +25,8 @@ struct SStep {
     int crow[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // first row (tap * Cin + ci) of chunk k
     int cn[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // rows in chunk k
     int lco = 0;              // log2(Cout) (convolution)
+    int lks = 0;              // convolution: log2 of the lanes that share one output quad (each takes every (1 << lks)-th channel quad of a tap)
+    int fast = 0, nqi = 0;    // convolution: fast = taps of the ONE chunk (1 or 9) when the unrolled multiply-add applies, nqi = channel quads per lane per tap
     int fnorm = 0;            // convolution: 1 = GroupNorm (G, gamma, beta, ss_off, eps) + SiLU (`act`) + `res` applied to the result in the epilogue
     int full = 0;             // S_ATTN1: 1 = Attention (no to_out norm), 0 = LinearAttention
     int lc = 0, lcpg = 0;     // log2(C0), log2(channels per GroupNorm group) (norm, attention)

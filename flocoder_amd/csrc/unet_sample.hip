@@ -149,91 +149,149 @@ __device__ __forceinline__ void op_norm(const SStep& s, float* L, const float* s
 }
 
 // Convolution over one or two (concatenated) NHWC sources in LDS; weights packed [tap][Cin][Cout], staged through LDS in the host's chunk
-// list (whole weight rows of the taps some output pixel can reach).  Chunk 0 is in wbuf[0] when this is called.  NJ = output passes a
-// thread makes (its outputs are channel co of NJ pixels): a compile-time count, so the multiply-add loop is branch-free -- one weight
-// read and NJ activation reads feed NJ independent accumulators, four channels per trip with their loads in flight together.
-template <int NJ>
-__device__ __forceinline__ void conv_body(const SStep& s, float* L, float* wbuf, const float* zl, const float* ss, float* red) {
-    const int tid = threadIdx.x, C0 = s.C0, C1 = s.C1, Cin = C0 + C1, Cout = s.Cout, KS = s.KS, lco = s.lco;
+// list (whole taps some output pixel can reach).  Chunk 0 is in wbuf[0] when this is called.
+//
+// The multiply-add phase: a thread owns FOUR output channels of one pixel (a quad: one 16-byte weight read per input channel, one 16-byte
+// activation read per four input channels -> five LDS reads per sixteen multiply-adds, four independent accumulators), and (1 << lks)
+// neighbouring lanes share a quad, each taking every (1 << lks)-th channel quad of a tap, their partial sums added by lane shuffles:
+// the layers have 128..1024 outputs and 72..432 products per output, so without the split most of the workgroup idles behind a serial
+// chain of LDS latencies (the first version: one output per thread pass, 8 reads per 4 multiply-adds, 7..16 us per convolution).
+// The raw sums go to the result tensor; the epilogue (bias, GroupNorm + FiLM, SiLU, residual) re-reads them in the channel-major thread
+// layout the group reduction wants.
+__device__ __forceinline__ void conv_mac(const SStep& s, const SStep& sl, float* L, float* wbuf, const float* zl) {
+    const int tid = threadIdx.x, C0 = s.C0, C1 = s.C1, Cin = C0 + C1, Cout = s.Cout, KS = s.KS;
+    const int CQ0 = C0 >> 2, lks = s.lks, KSPL = 1 << lks, lnq = s.lco - 2;
+    const int ks = tid & (KSPL - 1), ot = tid >> lks, q = ot & ((1 << lnq) - 1), pix = ot >> lnq;
     const float* a0 = L + s.in0;
     const float* a1 = C1 ? L + s.in1 : zl;
     const int Hin = s.Hi << s.ups, Win = s.Wi << s.ups, npix = s.Ho * s.Wo;
-    const int co = tid & (Cout - 1), pstep = NT >> lco;
-    const float bias = s.bias ? gsc(s.bias)[co] : 0.f;
-    int oy[NJ], ox[NJ];
-    float acc[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int pix = (tid >> lco) + j * pstep;
-        oy[j] = pix < npix ? pix / s.Wo : -1000;
-        ox[j] = pix - (pix / s.Wo) * s.Wo;
-        acc[j] = 0.f;
-    }
+    const bool live = pix < npix;
+    const int oy = live ? pix / s.Wo : 0, ox = live ? pix - oy * s.Wo : 0;
+    const int by = oy * s.stride - s.pad, bx = ox * s.stride - s.pad;
+    f4v acc = {0.f, 0.f, 0.f, 0.f};
     Pre cur;
     const int nch = s.nchunk;
     for (int k = 0; k < nch; ++k) {
-        if (k + 1 < nch) issue_conv_chunk(s, k + 1, cur);
-        const float* wb = wbuf + (k & 1) * WCH;
-        const int r0 = s.crow[k], r1 = r0 + s.cn[k];
-        for (int row = r0; row < r1;) {                    // segments of one tap: channels [ci0, ci0 + seg)
-            const int tap = row / Cin, ci0 = row - tap * Cin, ky = tap / KS, kx = tap - ky * KS;
+        if (k + 1 < nch) issue_conv_chunk(sl, k + 1, cur);
+        const float* wb = wbuf + (k & 1) * WCH + 4 * q;
+        const int r0 = sl.crow[k], r1 = r0 + sl.cn[k];
+        const int tap0 = r0 / Cin;                                         // (uniform; once per chunk)
+        int ci0 = r0 - tap0 * Cin, ky = tap0 / KS, kx = tap0 - ky * KS;
+        for (int row = r0; row < r1;) {                                    // segments of one tap: channels [ci0, ci0 + seg), whole quads
             const int seg = (Cin - ci0 < r1 - row) ? Cin - ci0 : r1 - row;
-            const float* w = wb + (size_t)(row - r0) * Cout + co;
-            // the segment's two parts: channels of the first source, then of the second (either may be empty)
-            const int n0 = ci0 < C0 ? ((ci0 + seg < C0 ? ci0 + seg : C0) - ci0) : 0, n1 = seg - n0;
-            const float* p0[NJ];
-            const float* p1[NJ];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int iy = oy[j] * s.stride - s.pad + ky, ix = ox[j] * s.stride - s.pad + kx;
-                const bool ok = iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
-                const int sp = ok ? (iy >> s.ups) * s.Wi + (ix >> s.ups) : 0;
-                p0[j] = ok ? a0 + sp * C0 + ci0 : zl;
-                p1[j] = (ok && C1) ? a1 + sp * C1 + (ci0 + n0 - C0) : zl;
+            const int iy = by + ky, ix = bx + kx;
+            const bool ok = live && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
+            const int sp = ok ? (iy >> s.ups) * s.Wi + (ix >> s.ups) : 0;
+            const float* p0 = ok ? a0 + sp * C0 : zl;                      // (out of the picture: the zero line, no branch in the loop)
+            const float* p1 = (ok && C1) ? a1 + sp * C1 - C0 : zl;
+            const float* w = wb + (size_t)(row - r0 - ci0) * Cout;         // row (tap * Cin + c) of the weights sits at w + c * Cout
+            const int cqe = (ci0 + seg) >> 2;
+#pragma unroll 2
+            for (int cq = (ci0 >> 2) + ks; cq < cqe; cq += KSPL) {
+                const float* xp = (cq < CQ0 ? p0 : p1) + 4 * cq;
+                const f4v x = *reinterpret_cast<const f4v*>(xp);
+                const float* wr = w + (size_t)(4 * cq) * Cout;
+                const f4v w0 = *reinterpret_cast<const f4v*>(wr), w1 = *reinterpret_cast<const f4v*>(wr + Cout);
+                const f4v w2 = *reinterpret_cast<const f4v*>(wr + 2 * Cout), w3 = *reinterpret_cast<const f4v*>(wr + 3 * Cout);
+                acc += x.x * w0; acc += x.y * w1; acc += x.z * w2; acc += x.w * w3;
             }
-            int i = 0;
-            for (; i + 4 <= n0; i += 4) {
-                const float w0 = w[i * Cout], w1 = w[(i + 1) * Cout], w2 = w[(i + 2) * Cout], w3 = w[(i + 3) * Cout];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const float x0 = p0[j][i], x1 = p0[j][i + 1], x2 = p0[j][i + 2], x3 = p0[j][i + 3];
-                    acc[j] += x0 * w0; acc[j] += x1 * w1; acc[j] += x2 * w2; acc[j] += x3 * w3;
-                }
-            }
-            for (; i < n0; ++i) {
-                const float w0 = w[i * Cout];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[j] += p0[j][i] * w0;
-            }
-            const float* w2p = w + n0 * Cout;
-            for (i = 0; i + 4 <= n1; i += 4) {
-                const float w0 = w2p[i * Cout], w1 = w2p[(i + 1) * Cout], w2 = w2p[(i + 2) * Cout], w3 = w2p[(i + 3) * Cout];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const float x0 = p1[j][i], x1 = p1[j][i + 1], x2 = p1[j][i + 2], x3 = p1[j][i + 3];
-                    acc[j] += x0 * w0; acc[j] += x1 * w1; acc[j] += x2 * w2; acc[j] += x3 * w3;
-                }
-            }
-            for (; i < n1; ++i) {
-                const float w0 = w2p[i * Cout];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[j] += p1[j][i] * w0;
-            }
-            row += seg;
+            row += seg; ci0 += seg;
+            if (ci0 == Cin) { ci0 = 0; if (++kx == KS) { kx = 0; ++ky; } }
         }
-        if (k + 1 < nch) stash_conv_chunk(s, k + 1, cur, wbuf);
+        if (k + 1 < nch) stash_conv_chunk(sl, k + 1, cur, wbuf);
         __syncthreads();
     }
+    for (int b = 0; b < lks; ++b) {
+        acc.x += __shfl_xor(acc.x, 1 << b); acc.y += __shfl_xor(acc.y, 1 << b); acc.z += __shfl_xor(acc.z, 1 << b); acc.w += __shfl_xor(acc.w, 1 << b);
+    }
+    if (live && ks == 0) *reinterpret_cast<f4v*>(L + s.out + pix * Cout + 4 * q) = acc;
+    __syncthreads();
+}
+
+// The same multiply-add phase for the common case -- ONE chunk holding NTAPS whole taps (all nine of a 3x3 kernel, or the single tap a 1x1
+// kernel has / a 1x1 image can reach) and exactly NQI channel quads per lane per tap -- with both loops unrolled: the general loop above
+// walks the taps one after the other, each a pointer set-up, five LDS reads and a wait (~0.3 us per tap, 2..3 us per convolution, most of
+// the step); unrolled, the address arithmetic of all taps is independent straight-line code and their reads are in flight together.
+template <int NTAPS, int NQI>
+__device__ __forceinline__ void conv_mac_fast(const SStep& s, float* L, float* wbuf, const float* zl) {
+    const int tid = threadIdx.x, C0 = s.C0, C1 = s.C1, Cin = C0 + C1, Cout = s.Cout, KS = s.KS;
+    const int CQ0 = C0 >> 2, lks = s.lks, KSPL = 1 << lks, lnq = s.lco - 2;
+    const int ks = tid & (KSPL - 1), ot = tid >> lks, q = ot & ((1 << lnq) - 1), pix = ot >> lnq;
+    const float* a0 = L + s.in0;
+    const float* a1 = C1 ? L + s.in1 : zl;
+    const int Hin = s.Hi << s.ups, Win = s.Wi << s.ups, npix = s.Ho * s.Wo;
+    const bool live = pix < npix;
+    const int oy = live ? pix / s.Wo : 0, ox = live ? pix - oy * s.Wo : 0;
+    const int by = oy * s.stride - s.pad, bx = ox * s.stride - s.pad;
+    const int tap0 = s.crow[0] / Cin, ky0 = tap0 / KS, kx0 = tap0 - ky0 * KS;      // (NTAPS == 9: zero)
+    const float* wb = wbuf + 4 * q;
+    f4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) {
+        const int ky = NTAPS == 1 ? ky0 : t / 3, kx = NTAPS == 1 ? kx0 : t % 3;
+        const int iy = by + ky, ix = bx + kx;
+        const bool ok = live && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
+        const int sp = ok ? (iy >> s.ups) * s.Wi + (ix >> s.ups) : 0;
+        const float* p0 = ok ? a0 + sp * C0 : zl;
+        const float* p1 = (ok && C1) ? a1 + sp * C1 - C0 : zl;
+        const float* w = wb + (size_t)(t * Cin) * Cout;
+#pragma unroll
+        for (int j = 0; j < NQI; ++j) {
+            const int cq = ks + j * KSPL;
+            const float* xp = (cq < CQ0 ? p0 : p1) + 4 * cq;
+            const f4v x = *reinterpret_cast<const f4v*>(xp);
+            const float* wr = w + (size_t)(4 * cq) * Cout;
+            const f4v w0 = *reinterpret_cast<const f4v*>(wr), w1 = *reinterpret_cast<const f4v*>(wr + Cout);
+            const f4v w2 = *reinterpret_cast<const f4v*>(wr + 2 * Cout), w3 = *reinterpret_cast<const f4v*>(wr + 3 * Cout);
+            acc += x.x * w0; acc += x.y * w1; acc += x.z * w2; acc += x.w * w3;
+        }
+    }
+    __syncthreads();                                       // (the general loop's end-of-chunk barrier: every wave is past its weight reads)
+    for (int b = 0; b < lks; ++b) {
+        acc.x += __shfl_xor(acc.x, 1 << b); acc.y += __shfl_xor(acc.y, 1 << b); acc.z += __shfl_xor(acc.z, 1 << b); acc.w += __shfl_xor(acc.w, 1 << b);
+    }
+    if (live && ks == 0) *reinterpret_cast<f4v*>(L + s.out + pix * Cout + 4 * q) = acc;
+    __syncthreads();
+}
+template <int NTAPS>
+__device__ __forceinline__ void conv_mac_fast_n(const SStep& s, float* L, float* wbuf, const float* zl) {
+    switch (s.nqi) {
+        case 1: conv_mac_fast<NTAPS, 1>(s, L, wbuf, zl); break;
+        case 2: conv_mac_fast<NTAPS, 2>(s, L, wbuf, zl); break;
+        case 3: conv_mac_fast<NTAPS, 3>(s, L, wbuf, zl); break;
+        default: conv_mac_fast<NTAPS, 4>(s, L, wbuf, zl); break;
+    }
+}
+
+// The epilogue's per-channel parameters (global memory): requested BEFORE the multiply-add phase, used after it.
+struct ConvParams { float bias, pg, pb, psc, psh; };
+__device__ __forceinline__ ConvParams conv_params(const SStep& s, const float* ss) {
+    const int co = threadIdx.x & (s.Cout - 1);
+    ConvParams p = {0.f, 1.f, 0.f, 0.f, 0.f};
+    if (s.bias) p.bias = gsc(s.bias)[co];
+    if (s.fnorm) {
+        p.pg = gsc(s.gamma)[co]; p.pb = gsc(s.beta)[co];
+        if (s.ss_off >= 0) { p.psc = gsc(ss)[s.ss_off + co]; p.psh = gsc(ss)[s.ss_off + s.Cout + co]; }
+    }
+    return p;
+}
+
+// NJ = elements of the result per thread (channel co = tid & (Cout - 1) of NJ pixels, i.e. ONE GroupNorm group): a compile-time count.
+template <int NJ>
+__device__ __forceinline__ void conv_epilogue(const SStep& s, float* L, const ConvParams& cp, float* red) {
+    const int tid = threadIdx.x, Cout = s.Cout, lco = s.lco, npix = s.Ho * s.Wo;
+    const int co = tid & (Cout - 1), pstep = NT >> lco;
+    const float bias = cp.bias;
     const float* res = s.res >= 0 ? L + s.res : nullptr;
     float* y = L + s.out;
+    float acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { const int pix = (tid >> lco) + j * pstep; acc[j] = pix < npix ? y[pix * Cout + co] : 0.f; }
     if (s.fnorm) {
-        // GroupNorm (+ FiLM) of the result right here: this thread's outputs are channel `co` of NJ pixels, i.e. ONE group; the group's sums
-        // run over the lane bits that do not select it (op_norm's reduction, on registers), then over the waves.  A step and a trip of
-        // the tensor through LDS less per Block half.
+        // GroupNorm (+ FiLM) of the result right here: the group's sums run over the lane bits that do not select it (op_norm's reduction,
+        // on registers), then over the waves.  A step less per Block half.
         const int lane = tid & 63, lcpg = s.lcpg, g = co >> lcpg;
-        const float pg = gsc(s.gamma)[co], pb = gsc(s.beta)[co];
-        float psc = 0.f, psh = 0.f;
-        if (s.ss_off >= 0) { psc = gsc(ss)[s.ss_off + co]; psh = gsc(ss)[s.ss_off + Cout + co]; }
+        const float pg = cp.pg, pb = cp.pb, psc = cp.psc, psh = cp.psh;
         float v[NJ], a = 0.f;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) { const bool on = (tid >> lco) + j * pstep < npix; v[j] = on ? acc[j] + bias : 0.f; a += v[j]; }
@@ -281,11 +339,12 @@ __device__ __forceinline__ void conv_body(const SStep& s, float* L, float* wbuf,
         }
     }
 }
-__device__ __forceinline__ void op_conv(const SStep& s, float* L, float* wbuf, const float* zl, const float* ss, float* red) {
+
+__device__ __forceinline__ void op_conv_epilogue(const SStep& s, float* L, const ConvParams& cp, float* red) {
     const int pstep = NT >> s.lco, nj = (s.Ho * s.Wo + pstep - 1) / pstep;        // uniform over the workgroup
-    if (nj <= 1) conv_body<1>(s, L, wbuf, zl, ss, red);
-    else if (nj == 2) conv_body<2>(s, L, wbuf, zl, ss, red);
-    else conv_body<4>(s, L, wbuf, zl, ss, red);
+    if (nj <= 1) conv_epilogue<1>(s, L, cp, red);
+    else if (nj == 2) conv_epilogue<2>(s, L, cp, red);
+    else conv_epilogue<4>(s, L, cp, red);
 }
 
 // F.interpolate(mode='bilinear', align_corners=False) of an NHWC tensor in LDS (elementwise.hip bilinear_kernel, same arithmetic)
@@ -742,16 +801,22 @@ __global__ void __launch_bounds__(NT) unet_sample_kernel(const SampleArgs a) {
         const int g = s.guard;
         return g == 0 || (g == 1 && has_mask) || (g == 2 && a.mask_fuse) || (g == 3 && !has_mask) || (g == 4 && has_mask && !a.mask_fuse) || (g == 5 && !a.mask_fuse);
     };
+    unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, tA = 0, tB = 0;       // diagnostics: convolution steps split into stage | multiply-add | epilogue
+    const bool clk = a.stamps && b == 0;
     Pre pre;
     int have = -1;                                        // the step whose first weights sit in `pre`
     for (int i = 0; i < a.nsteps; ++i) {
-        const SStep& s = prog[i];
+        const SStep& sl = prog[i];
+        // the step's scalars in REGISTERS (a copy the LDS stores of the step cannot alias: read through the LDS reference, every field was
+        // re-read after every store and barrier, a chain of LDS latencies per step); the chunk list stays behind `sl` (indexed at run time)
+        const SStep s = sl;
         if (a.stamps && b == 0 && tid == 0) {
             a.stamps[2 * i] = __builtin_amdgcn_s_memrealtime();
             a.stamps[2 * i + 1] = (unsigned long long)s.op | ((unsigned long long)s.KS << 4) | ((unsigned long long)s.Cout << 8) | ((unsigned long long)(s.C0 + s.C1) << 20) |
                                   ((unsigned long long)s.Hi << 32) | ((unsigned long long)s.guard << 40);
         }
         if (!runs(s)) continue;                           // (uniform over the workgroup)
+        if (clk) tA = __builtin_amdgcn_s_memrealtime();
         const bool needs = reads_weights(s);
         if (needs) {
             if (have != i) issue_first(s, pre);           // nobody asked ahead (the first such step)
@@ -764,8 +829,18 @@ __global__ void __launch_bounds__(NT) unet_sample_kernel(const SampleArgs a) {
             if (nx < a.nsteps) { issue_first(prog[nx], pre); have = nx; }
         }
         if (needs) __syncthreads();
+        if (clk && s.op == S_CONV) { tB = __builtin_amdgcn_s_memrealtime(); ph0 += tB - tA; }
         switch (s.op) {
-            case S_CONV: op_conv(s, L, wbuf, zl, ss, red); break;
+            case S_CONV: {
+                const ConvParams cp = conv_params(s, ss);
+                if (s.fast == 9) conv_mac_fast_n<9>(s, L, wbuf, zl);
+                else if (s.fast == 1) conv_mac_fast_n<1>(s, L, wbuf, zl);
+                else conv_mac(s, sl, L, wbuf, zl);
+                if (clk) { tA = __builtin_amdgcn_s_memrealtime(); ph1 += tA - tB; }
+                op_conv_epilogue(s, L, cp, red);
+                if (clk) { tB = __builtin_amdgcn_s_memrealtime(); ph2 += tB - tA; }
+                break;
+            }
             case S_NORM: op_norm(s, L, ss, red); break;
             case S_BILINEAR: op_bilinear(s, L); break;
             case S_LINATTN: op_attention(s, L, red, wbuf, false); break;
@@ -776,7 +851,10 @@ __global__ void __launch_bounds__(NT) unet_sample_kernel(const SampleArgs a) {
         }
         __syncthreads();
     }
-    if (a.stamps && b == 0 && tid == 0) { a.stamps[2 * a.nsteps] = __builtin_amdgcn_s_memrealtime(); a.stamps[2 * a.nsteps + 1] = 255; }
+    if (a.stamps && b == 0 && tid == 0) {
+        a.stamps[2 * a.nsteps] = __builtin_amdgcn_s_memrealtime(); a.stamps[2 * a.nsteps + 1] = 255;
+        a.stamps[2 * a.nsteps + 2] = ph0; a.stamps[2 * a.nsteps + 3] = ph1; a.stamps[2 * a.nsteps + 4] = ph2;
+    }
     // the velocity: NHWC in LDS -> NCHW in global memory, or the legacy Euler update y += v * dt (final_conv's tail, elementwise.hip)
     {
         const float* vsrc = L + a.v_off;

@@ -299,13 +299,26 @@ def test_folded_upsampling_equals_the_conv_over_the_upsampled_window(tmp_path):
     assert fl == fl0 and abs(ex0 - fl0) < 1e-3 * fl0 and ex < 0.95 * ex0
 
 
-def test_one_workgroup_per_sample_kernel_matches_the_goldens():
-    """csrc/unet_sample.hip (the whole forward of a sample in one workgroup, for models whose activations fit a CU's LDS; opt-in,
-    FLOCODER_AMD_SAMPLE_KERNEL=1 -- slower than the ordinary plan today): the mask-conditioned dim-8 model's forward goldens,
-    the mask-conditioned sampler against the oracle and the batch-size / determinism test once more on that kernel, in a child process
-    (the switch is read once per process)."""
+def test_one_workgroup_per_sample_kernel_is_the_default_where_it_fits_and_both_plans_match_the_goldens():
+    """csrc/unet_sample.hip (the whole forward of a sample in one workgroup, for models whose activations fit a CU's LDS and batches of at
+    most one sample per CU): the mask-conditioned dim-8 model runs on it by default (the plan is ONE U-Net launch),
+    a batch larger than the CU count keeps the ordinary plan, and with FLOCODER_AMD_SAMPLE_KERNEL=0 the ordinary plan gives the goldens,
+    the mask-conditioned sampler and the oracle the same answers (a child process: the switch is read once per process)."""
     import subprocess
-    env = dict(os.environ, FLOCODER_AMD_SAMPLE_KERNEL="1")
+    g = load_golden("g3_unet_d8mask")
+    model, _ = make_model(g["shapes"], 3, dim=8, channels=4, n_classes=0, mask_cond=True)
+    x = synth_input("g3.x.d8mask", (2, 4, 8, 8), 3).to(DEV)
+    t = torch.from_numpy(g["t"]).to(DEV)
+    with torch.no_grad():
+        small = model(x, t, None)
+        n_small = model.launches_per_forward
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        reps = cus // 2 + 1                                                   # 2 * reps samples > the CU count
+        big = model(x.repeat(reps, 1, 1, 1), t.repeat(reps), None)
+        n_big = model.launches_per_forward
+    assert n_small <= 4 < n_big, (n_small, n_big)                             # conditioning + ONE U-Net launch, against the ~115 of the ordinary plan
+    assert rel_l2(big[:2].cpu(), small.cpu()) < 2e-6                          # the two plans agree (summation order apart)
+    env = dict(os.environ, FLOCODER_AMD_SAMPLE_KERNEL="0")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
                         "-k", "d8mask or mask_cond_sampling"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""

@@ -34,7 +34,9 @@ while v[2 * i + 1] != 255 and i < 2000:
     rows.append((names[code & 15], (code >> 4) & 15, (code >> 8) & 4095, (code >> 20) & 4095, (code >> 32) & 255, (code >> 40) & 15, (v[2 * i + 2] - v[2 * i]) / 100.0))
     i += 1
 tot = sum(r[-1] for r in rows)
+ph = [v[2 * i + 2 + k] / 100.0 for k in range(3)]
 print(f"{len(rows)} steps, {tot:.1f} us in the step loop of workgroup 0 (B={Bn})")
+print(f"  convolution steps: {ph[0]:.1f} us staging the first weights + the barrier, {ph[1]:.1f} us multiply-add, {ph[2]:.1f} us epilogue")
 by = defaultdict(lambda: [0, 0.0])
 for r in rows:
     by[(r[0], r[1])][0] += 1; by[(r[0], r[1])][1] += r[-1]
