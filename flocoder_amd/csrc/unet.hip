@@ -487,7 +487,7 @@ static int build_sample_plan(fc_unet* u, Plan* pl, Builder& b, int maxB, int H, 
         SStep s;
         s.op = full ? S_ATTN : S_LINATTN; s.in0 = x.off; s.out = out.off; s.C0 = x.C; s.Hi = x.H; s.Wi = x.W;
         if (n == 1) { s.op = S_ATTN1; s.full = full ? 1 : 0; }       // one position: the closed form (unet_sample.hip op_attention1)
-        else if (!full && n <= 64 && x.C <= 16) s.op = S_LINATTN_W;   // a wave per head (all four heads' weights fit the staging buffer: C * 512 floats)
+        else if (!full && n <= 64 && (x.C == 8 || x.C == 16)) s.op = S_LINATTN_W;   // a wave per head (all four heads' weights fit the staging buffer: C * 512 floats)
         s.scratch = alloc(n == 1 ? 2 * x.C + 128 + SAMPLE_THREADS
                           : s.op == S_LINATTN_W ? 5 * n * x.C + 4 * (n + std::max(n, 32)) * 32
                           : 2 * n * x.C + 3 * n * 32 + (full ? n * n : 32 * 32) + n * 32);
@@ -576,7 +576,7 @@ static int build_sample_plan(fc_unet* u, Plan* pl, Builder& b, int maxB, int H, 
         if (s.op == S_CONV && (s.Ho * s.Wo * s.Cout > cap || !is_pow2(s.Cout) || s.Cout < 4 || s.Cout > SAMPLE_THREADS || s.nchunk > 8 || (s.C0 & 3) || (s.C1 & 3) || s.C0 + s.C1 > 128)) return 1;     // (channel quads; the zero line is 128 floats)
         if (s.op == S_NORM && (s.Hi * s.Wi * s.C0 > cap || !is_pow2(s.C0) || s.C0 > 64 || !is_pow2(s.C0 / s.G) || s.G > 8)) return 1;
         if (s.op == S_CONV && s.fnorm && (s.Cout > 64 || !is_pow2(s.Cout / s.G) || s.G > 8)) return 1;
-        if (s.op == S_LINATTN_W && (s.C0 > 16 || s.C0 < 4 || !is_pow2(s.C0) || !is_pow2(s.Hi * s.Wi) || s.Hi * s.Wi > 64)) return 1;
+        if (s.op == S_LINATTN_W && ((s.C0 != 8 && s.C0 != 16) || !is_pow2(s.Hi * s.Wi) || s.Hi * s.Wi > 64)) return 1;
         if (s.op == S_ATTN1 && (s.C0 > 64 || s.C0 < 8 || !is_pow2(s.C0))) return 1;
         if ((s.op == S_ATTN || s.op == S_LINATTN) && (s.C0 > 64 || s.C0 < 4 || !is_pow2(s.C0) || !is_pow2(s.Hi * s.Wi) || s.Hi * s.Wi * s.C0 > cap)) return 1;
         if (s.op == S_ATTN && s.Hi * s.Wi > 64) return 1;

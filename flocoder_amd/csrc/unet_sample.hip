@@ -633,24 +633,24 @@ __device__ __forceinline__ void op_attention1(const SStep& s, float* L, float* r
     } else if (tid < C) out[tid] = y[tid] + x[tid];
 }
 
-// LinearAttention with a WAVE PER HEAD (C <= 16: all four heads' weights fit the staging buffer).  In the general form the four heads run one
-// after the other, each as seven phases of the whole workgroup with a barrier between them -- ~30 us per module however little there is to
-// compute.  The heads never meet before to_out, so here wave h does head h on its own: k and v, k's softmax, the context; then q (into k's
-// place), its softmax, the output (into v's place) and the head's share of to_out.0 -- all in a wave-private part of the scratch, ordered by
-// the wave's own in-order LDS traffic (no workgroup barrier).  The shares meet once, at the end, in a fixed order.  wbuf holds all four
-// heads' weights on entry: to_qkv [C][384] then to_out.0 [128][C] (requested a step ahead).
-// scratch: xn [n][C] | yh [4][n][C] | per head: a [n][32] (k, then q) | b [n][32] (v, then o) | ctx [32][32]
+// LinearAttention (unet.py:151-176) of a small module, ONE WAVE PER HEAD, all four heads at once: every phase of a head is a short serial
+// chain (n <= 64 positions, 32 channels), so four of them side by side is the parallelism there is.  All four heads' weights sit in the
+// staging buffer (to_qkv [C][384] then to_out.0 [128][C]: C * 512 floats, C <= 16).  Per head: a[n][32] (k, then q, then the head's output
+// IN PLACE) | b[max(n, 32)][32] (v, then the 32 x 32 context where v was).
+// Every LDS access of the phases is a 16-byte one and the operands that do not change with the position live in registers: a lane owns
+// four channels of every eighth position, so a projection reads its C weight quads ONCE and then C/4 quads of x per position; the context
+// is a 4 x 4 block per lane (one quad of k and one of v per position); the output keeps its 32 context rows, the head's share of to_out
+// its 32 weight rows in registers.  (The first version read scalars: ~5000 LDS instructions per wave at n = 64, 50 us; this one ~450.)
+template <int C>
 __device__ __forceinline__ void op_linattn_w(const SStep& s, float* L, float* red, float* wbuf) {
-    const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6, C = s.C0, lc = s.lc, n = s.Hi * s.Wi, nC = n * C;
-    constexpr int DH = 32;
+    const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6, n = s.Hi * s.Wi, nC = n * C;
+    constexpr int DH = 32, CQ = C / 4;
     const float* x = L + s.in0;
     float* xn = L + s.scratch;
     float* yh = xn + nC;
-    // per head: a[n][32] (k, then q, then the head's output IN PLACE) | b[max(n, 32)][32] (v, then the 32 x 32 context where v was)
     const int nb = n > DH ? n : DH;
     float* ha = yh + 4 * nC + h * ((n + nb) * DH);
     float* hb = ha + n * DH;
-    float* ctx = hb;
     const float* wq = wbuf;                               // [C][384]
     const float* wo = wbuf + C * 384;                     // [128][C]
     const int cc = tid & (C - 1);
@@ -660,93 +660,92 @@ __device__ __forceinline__ void op_linattn_w(const SStep& s, float* L, float* re
 #pragma unroll
     for (int j = 0; j < NO; ++j) { const int e = tid + j * NT; if (e < nC) xn[e] = (x[e] - mean) * rstd * pg + pb; }
     __syncthreads();
-    const int d = lane & 31, hf = lane >> 5;              // channel of the head, half of the wave
-    // a projection of this head: lane (d, hf) does positions hf, hf + 2, ...; four of them share a weight value
-    auto project = [&](int which, float* dst) {
-        const float* w = wq + which * 128 + h * DH + d;
-        for (int p0 = hf; p0 < n; p0 += 8) {
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            const float* xp[4];
+    const int l8 = lane & 7, g8 = lane >> 3;              // a lane: quad l8 (channels 4 l8 .. 4 l8 + 3) of positions g8, g8 + 8, ...
+    // a projection of this head (which: 0 q, 1 k, 2 v); q gets its softmax over the 32 channels (the eight lanes of a position) and the scale
+    auto project = [&](int which, float* dst, bool qsoft) {
+        f4v w[C];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xp[j] = xn + (p0 + 2 * j < n ? p0 + 2 * j : p0) * C;
-#pragma unroll 4
-            for (int c = 0; c < C; ++c) {
-                const float wv = w[c * 384];
+        for (int c = 0; c < C; ++c) w[c] = *reinterpret_cast<const f4v*>(wq + c * 384 + which * 128 + h * DH + 4 * l8);
+        for (int p = g8; p < n; p += 8) {
+            f4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] += xp[j][c] * wv;
+            for (int cq = 0; cq < CQ; ++cq) {
+                const f4v xv = *reinterpret_cast<const f4v*>(xn + p * C + 4 * cq);
+                acc += xv.x * w[4 * cq]; acc += xv.y * w[4 * cq + 1]; acc += xv.z * w[4 * cq + 2]; acc += xv.w * w[4 * cq + 3];
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if (p0 + 2 * j < n) dst[(p0 + 2 * j) * DH + d] = acc[j];
+            if (qsoft) {
+                float m = fmaxf(fmaxf(acc.x, acc.y), fmaxf(acc.z, acc.w));
+                m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
+                acc.x = __expf(acc.x - m); acc.y = __expf(acc.y - m); acc.z = __expf(acc.z - m); acc.w = __expf(acc.w - m);
+                float sum = (acc.x + acc.y) + (acc.z + acc.w);
+                sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+                acc *= 0.17677669529663687f / sum;
+            }
+            *reinterpret_cast<f4v*>(dst + p * DH + 4 * l8) = acc;
         }
     };
-    project(1, ha);                                       // k
-    project(2, hb);                                       // v
+    project(1, ha, false);                                // k
+    project(2, hb, false);                                // v
     __builtin_amdgcn_wave_barrier();
-    {   // k: softmax over the positions, column d; the two halves of the wave split the positions
-        float m = -INFINITY;
-        for (int p = hf; p < n; p += 2) m = fmaxf(m, ha[p * DH + d]);
+    {   // k: softmax over the positions, column d; the two halves of the wave split the positions, a lane's values stay in registers
+        const int d = lane & 31, hf = lane >> 5;
+        float kv[32], m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { const int p = hf + 2 * j; kv[j] = p < n ? ha[p * DH + d] : -INFINITY; m = fmaxf(m, kv[j]); }
         m = fmaxf(m, __shfl_xor(m, 32));
         float sum = 0.f;
-        for (int p = hf; p < n; p += 2) { const float e = __expf(ha[p * DH + d] - m); ha[p * DH + d] = e; sum += e; }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { kv[j] = (hf + 2 * j < n) ? __expf(kv[j] - m) : 0.f; sum += kv[j]; }
         sum += __shfl_xor(sum, 32);
         const float inv = 1.0f / sum;
-        for (int p = hf; p < n; p += 2) ha[p * DH + d] *= inv;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { const int p = hf + 2 * j; if (p < n) ha[p * DH + d] = kv[j] * inv; }
     }
     __builtin_amdgcn_wave_barrier();
-    {   // ctx[dd][e] = sum_p k[p][dd] v[p][e]: lane (e = d, rows dd = 16 hf .. 16 hf + 15)
-        float acc[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    {   // ctx[dd][e] = sum_p k[p][dd] v[p][e]: a 4 x 4 block per lane (rows 4 g8 .., columns 4 l8 ..)
+        f4v c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+#pragma unroll 4
         for (int p = 0; p < n; ++p) {
-            const float vv = hb[p * DH + d];
-            const float* kp = ha + p * DH + 16 * hf;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] += kp[i] * vv;
+            const f4v kk = *reinterpret_cast<const f4v*>(ha + p * DH + 4 * g8);
+            const f4v vv = *reinterpret_cast<const f4v*>(hb + p * DH + 4 * l8);
+            c0 += kk.x * vv; c1 += kk.y * vv; c2 += kk.z * vv; c3 += kk.w * vv;
         }
         __builtin_amdgcn_wave_barrier();                   // every lane's reads of v are done (one wave per head, in lockstep): the context takes its place
-#pragma unroll
-        for (int i = 0; i < 16; ++i) ctx[(16 * hf + i) * DH + d] = acc[i];
+        float* cb = hb + (4 * g8) * DH + 4 * l8;
+        *reinterpret_cast<f4v*>(cb) = c0; *reinterpret_cast<f4v*>(cb + DH) = c1; *reinterpret_cast<f4v*>(cb + 2 * DH) = c2; *reinterpret_cast<f4v*>(cb + 3 * DH) = c3;
     }
     __builtin_amdgcn_wave_barrier();
-    project(0, ha);                                       // q, where k was
+    project(0, ha, true);                                 // q (softmax over the channels, * scale), where k was
     __builtin_amdgcn_wave_barrier();
-    // q: softmax over the 32 channels of a position (a half-wave per position), * scale
-    for (int p = hf; p < n + hf; p += 2) {
-        const bool on = p < n;
-        const float v = on ? ha[p * DH + d] : 0.f;
-        float m = v;
-        m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4)); m = fmaxf(m, __shfl_xor(m, 8)); m = fmaxf(m, __shfl_xor(m, 16));
-        const float e = __expf(v - m);
-        float sum = e;
-        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8); sum += __shfl_xor(sum, 16);
-        if (on) ha[p * DH + d] = e * (0.17677669529663687f / sum);
-    }
-    __builtin_amdgcn_wave_barrier();
-    // o[p][e] = sum_dd q[p][dd] ctx[dd][e], written over q's row p: the 32 lanes that read a row are the ones that write it, after their last read
-    for (int p0 = hf; p0 < n; p0 += 8) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        const float* qp[4];
+    {   // o[p][e] = sum_dd q[p][dd] ctx[dd][e], written over q's row p: the eight lanes that read a row are the ones that write it, after their last read
+        f4v cr[DH];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) qp[j] = ha + (p0 + 2 * j < n ? p0 + 2 * j : p0) * DH;
-#pragma unroll 8
-        for (int dd = 0; dd < DH; ++dd) {
-            const float cv = ctx[dd * DH + d];
+        for (int dd = 0; dd < DH; ++dd) cr[dd] = *reinterpret_cast<const f4v*>(hb + dd * DH + 4 * l8);
+        for (int p = g8; p < n; p += 8) {
+            f4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] += qp[j][dd] * cv;
+            for (int j = 0; j < 8; ++j) {
+                const f4v qv = *reinterpret_cast<const f4v*>(ha + p * DH + 4 * j);
+                acc += qv.x * cr[4 * j]; acc += qv.y * cr[4 * j + 1]; acc += qv.z * cr[4 * j + 2]; acc += qv.w * cr[4 * j + 3];
+            }
+            __builtin_amdgcn_wave_barrier();
+            *reinterpret_cast<f4v*>(ha + p * DH + 4 * l8) = acc;
         }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (p0 + 2 * j < n) ha[(p0 + 2 * j) * DH + d] = acc[j];
     }
     __builtin_amdgcn_wave_barrier();
-    {   // this head's share of to_out.0: yh[h][p][c] = sum_e o[p][e] Wout[32 h + e][c]: lane -> (c = lane & (C - 1), positions (lane >> lc) + k (64 >> lc))
-        const int c = lane & (C - 1), pl = lane >> lc, PL = 64 >> lc;
-        const float* w = wo + (size_t)(h * DH) * C + c;
+    {   // this head's share of to_out.0: yh[h][p][c] = sum_e o[p][e] Wout[32 h + e][c]: lane -> (channel quad, positions pl, pl + 64 / CQ, ...)
+        const int cq = lane & (CQ - 1), pl = lane / CQ, PL = 64 / CQ;
+        f4v wr[DH];
+#pragma unroll
+        for (int e = 0; e < DH; ++e) wr[e] = *reinterpret_cast<const f4v*>(wo + (size_t)(h * DH + e) * C + 4 * cq);
         for (int p = pl; p < n; p += PL) {
-            float acc = 0.f;
-#pragma unroll 8
-            for (int e = 0; e < DH; ++e) acc += ha[p * DH + e] * w[e * C];
-            yh[(h * n + p) * C + c] = acc;
+            f4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f4v ov = *reinterpret_cast<const f4v*>(ha + p * DH + 4 * j);
+                acc += ov.x * wr[4 * j]; acc += ov.y * wr[4 * j + 1]; acc += ov.z * wr[4 * j + 2]; acc += ov.w * wr[4 * j + 3];
+            }
+            *reinterpret_cast<f4v*>(yh + (size_t)(h * n + p) * C + 4 * cq) = acc;
         }
     }
     __syncthreads();
@@ -846,7 +845,7 @@ __global__ void __launch_bounds__(NT) unet_sample_kernel(const SampleArgs a) {
             case S_LINATTN: op_attention(s, L, red, wbuf, false); break;
             case S_ATTN: op_attention(s, L, red, wbuf, true); break;
             case S_ATTN1: op_attention1(s, L, red, wbuf); break;
-            case S_LINATTN_W: op_linattn_w(s, L, red, wbuf); break;
+            case S_LINATTN_W: if (s.C0 == 8) op_linattn_w<8>(s, L, red, wbuf); else op_linattn_w<16>(s, L, red, wbuf); break;
             case S_COPY: for (int e = tid; e < s.Cout; e += NT) L[s.out + e] = L[s.in0 + e]; break;
         }
         __syncthreads();
