@@ -487,9 +487,10 @@ static int build_sample_plan(fc_unet* u, Plan* pl, Builder& b, int maxB, int H, 
         SStep s;
         s.op = full ? S_ATTN : S_LINATTN; s.in0 = x.off; s.out = out.off; s.C0 = x.C; s.Hi = x.H; s.Wi = x.W;
         if (n == 1) { s.op = S_ATTN1; s.full = full ? 1 : 0; }       // one position: the closed form (unet_sample.hip op_attention1)
-        else if (!full && n <= 64 && (x.C == 8 || x.C == 16)) s.op = S_LINATTN_W;   // a wave per head (all four heads' weights fit the staging buffer: C * 512 floats)
+        else if (!full && n <= 64 && (x.C == 8 || x.C == 16)) s.op = S_LINATTN_W;
+        else if (!full && n <= 16 && x.C == 32) s.op = S_LINATTN_G;      // the same with its weights read from L2 (they do not fit the staging buffer)   // a wave per head (all four heads' weights fit the staging buffer: C * 512 floats)
         s.scratch = alloc(n == 1 ? 2 * x.C + 128 + SAMPLE_THREADS
-                          : s.op == S_LINATTN_W ? 5 * n * x.C + 4 * (n + std::max(n, 32)) * 32
+                          : (s.op == S_LINATTN_W || s.op == S_LINATTN_G) ? 5 * n * x.C + 4 * (n + std::max(n, 32)) * 32
                           : 2 * n * x.C + 3 * n * 32 + (full ? n * n : 32 * 32) + n * 32);
         s.gamma = u->R(p + ".fn.norm.weight"); s.beta = u->R(p + ".fn.norm.bias");
         s.lc = ilog2(x.C); s.ln = ilog2(n);
@@ -577,6 +578,7 @@ static int build_sample_plan(fc_unet* u, Plan* pl, Builder& b, int maxB, int H, 
         if (s.op == S_NORM && (s.Hi * s.Wi * s.C0 > cap || !is_pow2(s.C0) || s.C0 > 64 || !is_pow2(s.C0 / s.G) || s.G > 8)) return 1;
         if (s.op == S_CONV && s.fnorm && (s.Cout > 64 || !is_pow2(s.Cout / s.G) || s.G > 8)) return 1;
         if (s.op == S_LINATTN_W && ((s.C0 != 8 && s.C0 != 16) || !is_pow2(s.Hi * s.Wi) || s.Hi * s.Wi > 64)) return 1;
+        if (s.op == S_LINATTN_G && (s.C0 != 32 || !is_pow2(s.Hi * s.Wi) || s.Hi * s.Wi > 16)) return 1;
         if (s.op == S_ATTN1 && (s.C0 > 64 || s.C0 < 8 || !is_pow2(s.C0))) return 1;
         if ((s.op == S_ATTN || s.op == S_LINATTN) && (s.C0 > 64 || s.C0 < 4 || !is_pow2(s.C0) || !is_pow2(s.Hi * s.Wi) || s.Hi * s.Wi * s.C0 > cap)) return 1;
         if (s.op == S_ATTN && s.Hi * s.Wi > 64) return 1;

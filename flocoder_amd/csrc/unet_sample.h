@@ -6,7 +6,7 @@ namespace fc {
 
 constexpr int SAMPLE_THREADS = 256;       // threads of a sample's workgroup
 
-enum SampleOp { S_CONV = 0, S_NORM = 1, S_BILINEAR = 2, S_LINATTN = 3, S_ATTN = 4, S_COPY = 5, S_ATTN1 = 6, S_LINATTN_W = 7 };   // S_ATTN1: either attention on ONE position; S_LINATTN_W: LinearAttention, a wave per head
+enum SampleOp { S_CONV = 0, S_NORM = 1, S_BILINEAR = 2, S_LINATTN = 3, S_ATTN = 4, S_COPY = 5, S_ATTN1 = 6, S_LINATTN_W = 7, S_LINATTN_G = 8 };   // S_ATTN1: either attention on ONE position; S_LINATTN_W: LinearAttention, a wave per head
 
 struct SStep {
     int op = 0;

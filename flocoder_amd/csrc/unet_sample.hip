@@ -9,11 +9,15 @@
 // table.  The arithmetic is plain fp32 FMA on the vector pipe: the layers are far too small for matrix tiles (8..64 channels, 64..1 pixels).
 // Same results as the ordinary plan to summation order (tests/test_gpu_unet.py compares both with the goldens and the oracle).
 //
-// What decides its speed (profiles/r04_sample_kernel_stamps*.txt): a step lives a few microseconds, so (1) nothing in it may wait for its
-// own weights -- the first chunk of the NEXT weight-reading step is requested (global -> registers) before the current step computes, later
-// chunks of a step travel while the previous one is multiplied; (2) the multiply-add loops keep four independent accumulators per thread
-// that share one weight value (a thread's outputs are the same channel of four pixels), with the loop over input channels unrolled, and
-// the reductions use shifts and lane masks, never an integer division (all extents are powers of two; the host checks).
+// What decides its speed (profiles/r04_sample_kernel_stamps.txt; the history is in DESIGN.md section 7): four waves on a CU hide nothing, so a
+// step costs its LDS round trips and barriers in full (~3 us before any arithmetic).  Hence (1) nothing waits for its own weights -- the
+// first chunk of the NEXT weight-reading step is requested (global -> registers) before the current step computes, later chunks of a step
+// travel while the previous one is multiplied; (2) every hot LDS access is a 16-byte one and operands that do not change inside a loop sit
+// in registers (a convolution thread owns four output channels of a pixel, an attention lane four channels of every eighth position);
+// (3) idle lanes are given a share of the reduction (the channel quads of a tap are split over neighbouring lanes and summed by shuffles);
+// (4) GroupNorm lives in the convolution's epilogue and the heads of a small attention run one per wave, because each removed step or
+// barrier is worth more than the arithmetic it carries; the reductions use shifts and lane masks, never an integer division in a loop
+// (all extents are powers of two; the host checks).
 #include <cstdlib>
 #include <string>
 
@@ -641,7 +645,9 @@ __device__ __forceinline__ void op_attention1(const SStep& s, float* L, float* r
 // four channels of every eighth position, so a projection reads its C weight quads ONCE and then C/4 quads of x per position; the context
 // is a 4 x 4 block per lane (one quad of k and one of v per position); the output keeps its 32 context rows, the head's share of to_out
 // its 32 weight rows in registers.  (The first version read scalars: ~5000 LDS instructions per wave at n = 64, 50 us; this one ~450.)
-template <int C>
+// GW: the weights are read from global memory (L2) straight into those registers instead of the staging buffer -- C = 32 at n <= 16, where
+// the four heads' weights (64 KB) do not fit it and the general form below takes 40 us for 4 positions.
+template <int C, bool GW>
 __device__ __forceinline__ void op_linattn_w(const SStep& s, float* L, float* red, float* wbuf) {
     const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6, n = s.Hi * s.Wi, nC = n * C;
     constexpr int DH = 32, CQ = C / 4;
@@ -651,8 +657,8 @@ __device__ __forceinline__ void op_linattn_w(const SStep& s, float* L, float* re
     const int nb = n > DH ? n : DH;
     float* ha = yh + 4 * nC + h * ((n + nb) * DH);
     float* hb = ha + n * DH;
-    const float* wq = wbuf;                               // [C][384]
-    const float* wo = wbuf + C * 384;                     // [128][C]
+    auto ldq = [&](int off) -> f4v { if constexpr (GW) return *gptr(s.w + off); else return *reinterpret_cast<const f4v*>(wbuf + off); };              // to_qkv [C][384]
+    auto ldo = [&](int off) -> f4v { if constexpr (GW) return *gptr(s.w2 + off); else return *reinterpret_cast<const f4v*>(wbuf + C * 384 + off); };   // to_out.0 [128][C]
     const int cc = tid & (C - 1);
     const float pg = gsc(s.gamma)[cc], pb = gsc(s.beta)[cc], pbo = gsc(s.b2)[cc], g2 = gsc(s.g2)[cc], b2 = gsc(s.be2)[cc];
     float mean, rstd;
@@ -665,7 +671,7 @@ __device__ __forceinline__ void op_linattn_w(const SStep& s, float* L, float* re
     auto project = [&](int which, float* dst, bool qsoft) {
         f4v w[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) w[c] = *reinterpret_cast<const f4v*>(wq + c * 384 + which * 128 + h * DH + 4 * l8);
+        for (int c = 0; c < C; ++c) w[c] = ldq(c * 384 + which * 128 + h * DH + 4 * l8);
         for (int p = g8; p < n; p += 8) {
             f4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -737,7 +743,7 @@ __device__ __forceinline__ void op_linattn_w(const SStep& s, float* L, float* re
         const int cq = lane & (CQ - 1), pl = lane / CQ, PL = 64 / CQ;
         f4v wr[DH];
 #pragma unroll
-        for (int e = 0; e < DH; ++e) wr[e] = *reinterpret_cast<const f4v*>(wo + (size_t)(h * DH + e) * C + 4 * cq);
+        for (int e = 0; e < DH; ++e) wr[e] = ldo((h * DH + e) * C + 4 * cq);
         for (int p = pl; p < n; p += PL) {
             f4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -828,16 +834,16 @@ __global__ void __launch_bounds__(NT) unet_sample_kernel(const SampleArgs a) {
             if (nx < a.nsteps) { issue_first(prog[nx], pre); have = nx; }
         }
         if (needs) __syncthreads();
-        if (clk && s.op == S_CONV) { tB = __builtin_amdgcn_s_memrealtime(); ph0 += tB - tA; }
+        if (clk && s.op == S_CONV) { tB = __builtin_amdgcn_s_memrealtime(); ph0 += tB - tA; if (tid == 0) a.stamps[2 * a.nsteps + 8 + 3 * i] = tB - tA; }
         switch (s.op) {
             case S_CONV: {
                 const ConvParams cp = conv_params(s, ss);
                 if (s.fast == 9) conv_mac_fast_n<9>(s, L, wbuf, zl);
                 else if (s.fast == 1) conv_mac_fast_n<1>(s, L, wbuf, zl);
                 else conv_mac(s, sl, L, wbuf, zl);
-                if (clk) { tA = __builtin_amdgcn_s_memrealtime(); ph1 += tA - tB; }
+                if (clk) { tA = __builtin_amdgcn_s_memrealtime(); ph1 += tA - tB; if (tid == 0) a.stamps[2 * a.nsteps + 9 + 3 * i] = tA - tB; }
                 op_conv_epilogue(s, L, cp, red);
-                if (clk) { tB = __builtin_amdgcn_s_memrealtime(); ph2 += tB - tA; }
+                if (clk) { tB = __builtin_amdgcn_s_memrealtime(); ph2 += tB - tA; if (tid == 0) a.stamps[2 * a.nsteps + 10 + 3 * i] = tB - tA; }
                 break;
             }
             case S_NORM: op_norm(s, L, ss, red); break;
@@ -845,7 +851,8 @@ __global__ void __launch_bounds__(NT) unet_sample_kernel(const SampleArgs a) {
             case S_LINATTN: op_attention(s, L, red, wbuf, false); break;
             case S_ATTN: op_attention(s, L, red, wbuf, true); break;
             case S_ATTN1: op_attention1(s, L, red, wbuf); break;
-            case S_LINATTN_W: if (s.C0 == 8) op_linattn_w<8>(s, L, red, wbuf); else op_linattn_w<16>(s, L, red, wbuf); break;
+            case S_LINATTN_W: if (s.C0 == 8) op_linattn_w<8, false>(s, L, red, wbuf); else op_linattn_w<16, false>(s, L, red, wbuf); break;
+            case S_LINATTN_G: op_linattn_w<32, true>(s, L, red, wbuf); break;
             case S_COPY: for (int e = tid; e < s.Cout; e += NT) L[s.out + e] = L[s.in0 + e]; break;
         }
         __syncthreads();

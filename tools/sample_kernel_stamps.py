@@ -27,7 +27,7 @@ with torch.no_grad():
     torch.cuda.synchronize()
     B.check(B.lib().fc_debug_set_conv_stamps(None))
 v = buf.cpu().tolist()
-names = {0: "conv", 1: "norm", 2: "bilinear", 3: "linattn", 4: "attn", 5: "copy", 6: "attn1", 7: "linattn_w", 255: "end"}
+names = {0: "conv", 1: "norm", 2: "bilinear", 3: "linattn", 4: "attn", 5: "copy", 6: "attn1", 7: "linattn_w", 8: "linattn_g", 255: "end"}
 rows, i = [], 0
 while v[2 * i + 1] != 255 and i < 2000:
     code = v[2 * i + 1]
@@ -42,5 +42,9 @@ for r in rows:
     by[(r[0], r[1])][0] += 1; by[(r[0], r[1])][1] += r[-1]
 for k, (n, us) in sorted(by.items(), key=lambda kv: -kv[1][1]):
     print(f"  {k[0]:9s} KS={k[1]}  x{n:3d}  {us:8.1f} us  ({us / n:6.2f} each)")
-for r in rows:
-    print(f"{r[0]:9s} KS={r[1]} Cout={r[2]:3d} Cin={r[3]:3d} H={r[4]:2d} guard={r[5]}  {r[6]:7.2f} us")
+ns = len(rows)
+for k, r in enumerate(rows):
+    split = ""
+    if r[0] == "conv":
+        split = "   stage %.2f  multiply-add %.2f  epilogue %.2f" % tuple(v[2 * ns + 8 + 3 * k + j] / 100.0 for j in range(3))
+    print(f"{r[0]:9s} KS={r[1]} Cout={r[2]:3d} Cin={r[3]:3d} H={r[4]:2d} guard={r[5]}  {r[6]:7.2f} us{split}")
