@@ -60,6 +60,7 @@ SIGNATURES = {
     "fc_unet_meeting_launches": (_i, [_vp]),
     "fc_unet_check": (_i, [_vp, _vp, _i]),
     "fc_debug_unet_break_meeting": (_i, [_vp]),
+    "fc_debug_unet_break_meeting_kind": (_i, [_vp, _i]),
     "fc_unet_train_reserve": (_i, [_vp, _i, _i, _i]),
     "fc_unet_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "fc_unet_backward_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _vp]),

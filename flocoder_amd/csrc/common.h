@@ -234,6 +234,12 @@ struct LaArgs {
     float eps2 = 1e-5f;
     float* out = nullptr;
     float* part = nullptr;         // [B][heads][n][C] scratch: every head's share of to_out.0
+    // fused close of the n >= 256 module (linattn_fused.hip, la_apply): with `gran` the apply launch also normalises (to_out.1) and adds x --
+    // the workgroups of a sample exchange their (mean, M2) partials of y as tagged granules and WAIT for each other, so the launch needs
+    // its whole grid resident (exclusive plan only: linattn_fused_meeting_ok); y / stats_out are then not written
+    unsigned long long* gran = nullptr;   // [B][T][2] {epoch << 32 | float bits}, zero when allocated
+    unsigned* sync = nullptr;             // [B] arrival counters (epoch = arrival / T + 1), zero when allocated
+    int* err = nullptr;                   // the handle's error word: set when a wait gives up (the sample's output is NaN then)
     unsigned* tickets = nullptr;   // [B] arrival counters, zero when allocated: with them the module is ONE launch -- the workgroup of a sample that
                                    // arrives last (ticket % heads == heads - 1) adds the shares, normalises and writes `out`; nobody waits
 };
@@ -242,6 +248,7 @@ bool linattn_fused_supported(int n, int C, int heads);
 int linattn_fused_tiles(int n);
 float linattn_fused_nt(int n, int C);
 int linattn_fused_launch(const LaArgs& a, hipStream_t s);
+bool linattn_fused_meeting_ok(int B, int n, int C);   // may LaArgs::gran be set: the apply launch's whole grid is resident at this shape
 // The whole Residual(PreNorm(LinearAttention)) module in two launches, a workgroup per (sample, head) then per sample (n <= 64 positions)
 int linattn_sample_init();
 bool linattn_sample_supported(int n, int C, int heads);

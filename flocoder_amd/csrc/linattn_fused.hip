@@ -427,8 +427,13 @@ __global__ void __launch_bounds__(256) la_apply_fast_kernel(const LaArgs a, int 
     float* ctxl = Wo + LHID * WO;          // [4][32][PS]
     float* xt = ctxl + LHEADS * LDH * PS;  // [4][32][XS]: x tile, then the P / out tile of the head in flight
     __shared__ float red[4];
+    __shared__ unsigned epoch_s;
+    __shared__ float gv[2 * kPartPre];
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int ntiles = (a.n + 127) >> 7;
+    // the fused close (a.gran; one tile per workgroup, T <= kPartPre): this launch's epoch from the sample's arrival counter
+    unsigned arrival = 0;
+    if (a.gran && tid == 0) arrival = __hip_atomic_fetch_add(a.sync + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // every cold operand is requested before anything is waited for: x tile, statistics, norm parameters, to_out bias, weights, context
     float4 pre[NQ];
     fetch_x<NQ>(a, b, blockIdx.x * 128 + wave * 32, lane, pre);
@@ -476,6 +481,7 @@ __global__ void __launch_bounds__(256) la_apply_fast_kernel(const LaArgs a, int 
             Ab[tid] = s;
             Bb[tid] = pbt - mean * s;
         }
+        if (a.gran && tid == 0) epoch_s = arrival / (unsigned)T + 1u;
     }
     __syncthreads();
     float* xw = xt + wave * 32 * XS;
@@ -556,6 +562,67 @@ __global__ void __launch_bounds__(256) la_apply_fast_kernel(const LaArgs a, int 
         }
         const float St = block_sum(S, red);
         const float Qt = block_sum(Q, red);
+        if (a.gran) {
+            // ---- the module closed here: out = GroupNorm(1)(y) * g2 + b2 + x, the statistics completed by the sample's other tiles ----
+            // The partials travel as ONE 8-byte write-through store each, {epoch, bits}: the data is its own flag (the convolution tails'
+            // hand-off, conv_dev.h); sc1 accesses that bypass the per-XCD L2, no fence.  finalize_kernel's arithmetic (stats_dev.h
+            // partials_finish) in the same order, so the exclusive and the shared plan agree to the last bit.
+            const unsigned epoch = epoch_s;
+            if (tid == 0) {
+                const float mt = St / n_t;
+                unsigned long long* gp = a.gran + ((size_t)b * T + tile) * 2;
+                const unsigned long long tag = (unsigned long long)epoch << 32;
+                __hip_atomic_store(gp, tag | __float_as_uint(mt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gp + 1, tag | __float_as_uint(Qt - St * mt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // the residual and the norm parameters are requested BEFORE the wait: they depend on nothing computed here
+            float rs[CT][16], g2[CT], b2[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int c = ct * 32 + l31;
+                g2[ct] = c < C ? a.g2[c] : 0.f;
+                b2[ct] = c < C ? a.b2[c] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int nn = r0 + acc_row(r, half);
+                    rs[ct][r] = (nn < a.n && c < C) ? a.x[((size_t)b * a.n + nn) * C + c] : 0.f;
+                }
+            }
+            if (tid < 2 * T) {          // one granule per thread, polled until it carries this launch's epoch.  Bounded: a residency mistake
+                                        // must not hang the device -- the statistic becomes NaN and the handle's error word is set
+                const unsigned long long* gp = a.gran + (size_t)b * T * 2 + tid;
+                unsigned long long v = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int spins = 0;
+                while ((unsigned)(v >> 32) != epoch) {
+                    if (++spins > (1 << 20)) { if (a.err) *a.err = 1; v = 0x7fc00000ull; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                    v = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                gv[tid] = __uint_as_float((unsigned)v);
+            }
+            __syncthreads();
+            float sm2 = 0.f;
+            for (int t = 0; t < T; ++t) sm2 += gv[2 * t];
+            const float mean = sm2 / (float)T;
+            float m2 = 0.f, dv = 0.f;
+            for (int t = 0; t < T; ++t) {
+                const float d = gv[2 * t] - mean;
+                m2 += gv[2 * t + 1];
+                dv += d * d;
+            }
+            const float rstd = 1.0f / sqrtf((m2 + n_t * dv) / (n_t * (float)T) + a.eps2);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int c = ct * 32 + l31;
+                const float A = rstd * g2[ct], Bc = b2[ct] - mean * A;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int nn = r0 + acc_row(r, half);
+                    if (nn < a.n && c < C) a.out[((size_t)b * a.n + nn) * C + c] = (A * y[ct][r] + Bc) + rs[ct][r];
+                }
+            }
+            continue;                   // (one tile per workgroup: the loop ends here)
+        }
         if (tid == 0) {
             const float mt = St / n_t;
             float* d = a.stats_out + ((size_t)b * T + tile) * 2;
@@ -598,7 +665,7 @@ static int launch_fast(const LaArgs& a, hipStream_t s) {
     // two workgroups share a CU (67 KB of LDS each).  Measured per module at n = 1024: 55.0 -> 51.0 and 50.9 -> 47.0 us; sampler 793 -> 805
     // samples/s on one box (791 / 788 with four-wave la_ctx and two tiles).  FLOCODER_AMD_LA_APPLY_GX=half: the old form.
     static const bool gx_half = [] { const char* e = std::getenv("FLOCODER_AMD_LA_APPLY_GX"); return e && std::string(e) == "half"; }();
-    if (gx_half && tiles >= 2 && (tiles / 2) * a.B >= 256) gx = tiles / 2;
+    if (!a.gran && gx_half && tiles >= 2 && (tiles / 2) * a.B >= 256) gx = tiles / 2;      // (the fused close: one tile per workgroup, always)
     const dim3 grid(gx, a.B);
     if (a.C <= 32) hipLaunchKernelGGL((la_apply_fast_kernel<NQ, 1>), grid, dim3(256), la_apply_fast_lds(a.C, 1), s, a, T, n_t);
     else hipLaunchKernelGGL((la_apply_fast_kernel<NQ, 2>), grid, dim3(256), la_apply_fast_lds(a.C, 2), s, a, T, n_t);
@@ -643,9 +710,33 @@ bool linattn_fused_supported(int n, int C, int heads) {
     return la_ctx_lds(C) <= 160 * 1024;
 }
 
+// May the apply launch close the module itself (LaArgs::gran)?  Its workgroups wait for the other tiles of their sample, so every
+// workgroup of the grid must be resident at once: occupancy of the kernel at this C times the CU count >= tiles * B.  Fast path only.
+template <int NQ>
+static int apply_blocks_per_cu(int C) {
+    int nb = 0;
+    const hipError_t e = C <= 32 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, la_apply_fast_kernel<NQ, 1>, 256, la_apply_fast_lds(C, 1))
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, la_apply_fast_kernel<NQ, 2>, 256, la_apply_fast_lds(C, 2));
+    return e == hipSuccess ? nb : 0;
+}
+bool linattn_fused_meeting_ok(int B, int n, int C) {
+    static const bool off = [] { const char* e = std::getenv("FLOCODER_AMD_LA_CLOSE"); return e && std::string(e) == "0"; }();
+    static const bool no_fast = std::getenv("FLOCODER_AMD_LINATTN_GENERAL") != nullptr;
+    if (off || no_fast || n < 256 || (n & 127) || !(C == 8 || C == 16 || C == 32 || C == 64)) return false;
+    const int T = linattn_fused_tiles(n);
+    if (T != n / 128 || T > kPartPre) return false;
+    if (linattn_fused_init() != FC_OK) return false;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    const int per = C == 8 ? apply_blocks_per_cu<1>(C) : C == 16 ? apply_blocks_per_cu<2>(C) : C == 32 ? apply_blocks_per_cu<4>(C) : apply_blocks_per_cu<8>(C);
+    return (long long)per * cus >= (long long)T * B;
+}
+
 int linattn_fused_launch(const LaArgs& a, hipStream_t s) {
     if (!linattn_fused_supported(a.n, a.C, a.heads)) return fail(FC_E_SHAPE, "linattn_fused: unsupported shape");
     if (a.xf.mode != 1 || a.xf.G != 1 || !a.xf.stats) return fail(FC_E_ARG, "linattn_fused: needs GroupNorm(1) statistics of x");
+    if (a.gran && (!a.sync || !a.out || !a.g2 || !a.b2 || !(a.C == 8 || a.C == 16 || a.C == 32 || a.C == 64) || std::getenv("FLOCODER_AMD_LINATTN_GENERAL")))
+        return fail(FC_E_ARG, "linattn_fused: the fused close needs the fast path, the arrival counters, to_out.1's parameters and the output");
     static const bool no_fast = std::getenv("FLOCODER_AMD_LINATTN_GENERAL") != nullptr;
     if (!no_fast && a.C <= 64 && (a.C & 7) == 0 && (a.C == 8 || a.C == 16 || a.C == 32 || a.C == 64)) {
         switch (a.C) {

@@ -67,6 +67,7 @@ struct Plan {                 // one launch plan + activation arena for up to ma
     Act x0, head;                                   // init_conv output, final_res_block output
     int n_meet = 0;                                 // launches whose workgroups wait for each other (fused Block tails across workgroups)
     std::vector<unsigned*> fin_sync;                // their arrival counters (fc_debug_unet_break_meeting)
+    std::vector<int> fin_kind;                      // ... and what waits on them: 0 a convolution's Block tail, 1 the linear attention's close
     void release() {
         for (void* p : allocs) dev_free(p);
         *this = Plan();
@@ -385,7 +386,7 @@ struct PlanBuilder {
         if (hipMemset(a.fin.gran, 0, ngran * sizeof(unsigned long long)) != hipSuccess) { err = fail(FC_E_HIP, "hipMemset failed"); return false; }   // tag 0 = never a live epoch
         a.fin.sync = sync;
         a.fin.err = fin_err_word ? fin_err_word : reinterpret_cast<int*>(sync + g.groups);   // the handle's error word (one per object)
-        if (!g.fin_local) { ++pl->n_meet; pl->fin_sync.push_back(sync); }
+        if (!g.fin_local) { ++pl->n_meet; pl->fin_sync.push_back(sync); pl->fin_kind.push_back(0); }
         const int tile = g.tile;
         const double fl = 2.0 * out.H * out.W * a.KS * a.KS * (double)a.Cin * a.Cout;
         push([a, tile](const FwdCtx& c, hipStream_t s) { ConvArgs b = a; b.B = c.B; return conv_launch(b, tile, s); }, std::string(kTileNames[tile]) + "+fin", fl,

@@ -250,6 +250,24 @@ struct Builder : PlanBuilder {
         a.wqkv = u->P(p + ".fn.fn.to_qkv.weight"); a.wout = u->P(p + ".fn.fn.to_out.0.weight"); a.bout = u->R(p + ".fn.fn.to_out.0.bias");
         a.ctx = dmalloc((size_t)B * heads * 32 * 32); a.y = yb.p; a.stats_out = sty.p; a.n = n; a.C = x.C; a.heads = heads;
         const double fl = 2.0 * n * (double)x.C * 3 * hid + 2.0 * 2 * n * 32 * 32 * heads + 2.0 * n * (double)hid * x.C;
+        // The module closed by its own apply launch (to_out.1's GroupNorm(1) + the residual on the tile still in registers: no y round trip,
+        // no finalize launch) where the workgroups of a sample may wait for each other: the exclusive plan, the whole grid resident.
+        if (!err && meeting_ok() && linattn_fused_meeting_ok(B, n, x.C)) {
+            const int T = linattn_fused_tiles(n);
+            a.g2 = u->R(p + ".fn.fn.to_out.1.weight"); a.b2 = u->R(p + ".fn.fn.to_out.1.bias"); a.out = out.p;
+            a.gran = reinterpret_cast<unsigned long long*>(dmalloc((size_t)B * T * 2 * 2));
+            a.sync = reinterpret_cast<unsigned*>(dmalloc((size_t)B));
+            if (err) return out;
+            if (hipMemset(a.gran, 0, (size_t)B * T * 2 * sizeof(unsigned long long)) != hipSuccess || hipMemset(a.sync, 0, (size_t)B * sizeof(unsigned)) != hipSuccess) {
+                err = fail(FC_E_HIP, "hipMemset failed");
+                return out;
+            }
+            a.err = fin_err_word;
+            ++pl->n_meet; pl->fin_sync.push_back(a.sync); pl->fin_kind.push_back(1);
+            push([a](const FwdCtx& c, hipStream_t s) { LaArgs b = a; b.B = c.B; return linattn_fused_launch(b, s); }, "linattn_fused+fin", fl);
+            pl->named[p] = out;
+            return out;
+        }
         if (!err) push([a](const FwdCtx& c, hipStream_t s) { LaArgs b = a; b.B = c.B; return linattn_fused_launch(b, s); }, "linattn_fused", fl);
         FinalizeArgs f;
         f.h = yb.p; f.xf = xf_of(sty, 1, u->R(p + ".fn.fn.to_out.1.weight"), u->R(p + ".fn.fn.to_out.1.bias"));
@@ -1379,6 +1397,21 @@ int fc_debug_unet_break_meeting(fc_unet* u) {
     ++v;
     FC_HIP(hipMemcpy(u->plan[0].fin_sync[0], &v, sizeof(unsigned), hipMemcpyHostToDevice));
     return FC_OK;
+}
+
+int fc_debug_unet_break_meeting_kind(fc_unet* u, int kind) {      // the same for the first meeting launch of a kind (0 Block tail, 1 linear attention close)
+    if (!u) return fail(FC_E_ARG, "fc_debug_unet_break_meeting_kind: null handle");
+    const Plan& pl = u->plan[0];
+    for (size_t i = 0; i < pl.fin_sync.size(); ++i)
+        if (pl.fin_kind[i] == kind) {
+            FC_HIP(hipDeviceSynchronize());
+            unsigned v = 0;
+            FC_HIP(hipMemcpy(&v, pl.fin_sync[i], sizeof(unsigned), hipMemcpyDeviceToHost));
+            ++v;
+            FC_HIP(hipMemcpy(pl.fin_sync[i], &v, sizeof(unsigned), hipMemcpyHostToDevice));
+            return FC_OK;
+        }
+    return fail(FC_E_STATE, "fc_debug_unet_break_meeting_kind: the plan has no meeting launch of that kind");
 }
 
 int fc_debug_set_fused_tail(int on) {   // plans built from now on use (1) / do not use (0) the fused Block tails; < 0: back to the default (environment)

@@ -132,6 +132,7 @@ int fc_unet_meeting_launches(const fc_unet* u);
 int fc_unet_check(fc_unet* u, void* stream, int synchronize);
 /* Test hook: makes the next run of the plan's first meeting launch time out. */
 int fc_debug_unet_break_meeting(fc_unet* u);
+int fc_debug_unet_break_meeting_kind(fc_unet* u, int kind);   /* kind: 0 a convolution's Block tail, 1 the linear attention's fused close */
 /* Experiment switch: plans built after the call use (1) / do not use (0) the cross-workgroup Block tails; < 0 restores the default
  * (on, unless FLOCODER_AMD_FUSED_TAIL says otherwise). */
 int fc_debug_set_fused_tail(int on);

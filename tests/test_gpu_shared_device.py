@@ -144,6 +144,36 @@ def test_a_timed_out_meeting_is_loud_not_garbage(reference):
     m.check_errors()
 
 
+def test_linear_attention_closes_itself_on_the_exclusive_plan_and_its_wait_is_bounded(reference):
+    """linattn_fused.hip: at n >= 256 the apply launch of a LinearAttention module normalises (to_out.1) and adds x itself on the exclusive
+    plan -- the tiles of a sample exchange their statistics and wait for each other -- while the shared plan keeps the separate finalize
+    launch; same bits either way (the same arithmetic in the same order).  A wait that cannot end is bounded and loud, like the Block tails'."""
+    from flocoder_amd import _binding as Bn
+    sd, x, ids, want = reference
+    m = _model()
+    t = torch.full((B,), 300.0, device=DEV)
+    with torch.no_grad():
+        excl = m(x.to(DEV), t, {"class_cond": ids.to(DEV)}).clone()
+    kernels = [r["kernel"] for r in m.profile_ops(B, repeats=1)]
+    assert kernels.count("linattn_fused+fin") == 4 and "linattn_fused" not in kernels, kernels
+    m.set_shared_device(True)
+    with torch.no_grad():
+        shared = m(x.to(DEV), t, {"class_cond": ids.to(DEV)}).clone()
+    kernels = [r["kernel"] for r in m.profile_ops(B, repeats=1)]
+    assert kernels.count("linattn_fused") == 4 and "linattn_fused+fin" not in kernels, kernels
+    assert rel_l2(shared, excl) < 1e-6
+    m.set_shared_device(None)
+    with torch.no_grad():
+        assert torch.equal(m(x.to(DEV), t, {"class_cond": ids.to(DEV)}), excl)
+    Bn.check(Bn.lib().fc_debug_unet_break_meeting_kind(m._handle, 1))       # the tiles of sample 0 now disagree about the epoch
+    with torch.no_grad():
+        bad = m(x.to(DEV), t, {"class_cond": ids.to(DEV)})
+    torch.cuda.synchronize()
+    assert torch.isnan(bad[0]).any(), "a timed-out wait must poison its sample"
+    with pytest.raises(RuntimeError, match="timed out"):
+        m.check_errors()
+
+
 def test_the_sampler_raises_inside_the_call_that_waited(reference):
     """Unet.integrate(check=True) (the default behind every sampler entry point) waits for the trajectory and raises itself."""
     from flocoder_amd import _binding as Bn
