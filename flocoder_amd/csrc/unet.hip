@@ -622,7 +622,7 @@ static int build_sample_plan(fc_unet* u, Plan* pl, Builder& b, int maxB, int H, 
         SampleArgs q = a;
         q.x = cx.x; q.x_mod = cx.x_mod; q.mask = mask_cond ? cx.mask : nullptr; q.mask_fuse = cx.mask_fuse;
         q.ss_all = cx.fetch.all; q.evalc = cx.fetch.all ? cx.fetch.evalc : nullptr; q.rows = cx.B; q.out = cx.out; q.euler = cx.euler;
-        q.stamps = conv_stamp_buffer();
+        q.stamps = 5 * q.nsteps + 16 <= 4096 ? conv_stamp_buffer() : nullptr;   // (2 words per step + the phase split of the convolutions; fc_debug_set_conv_stamps: >= 4096 words)
         return unet_sample_launch(q, cx.B, lds, s);
     }, "unet_sample", flops);
     return FC_OK;
