@@ -53,6 +53,7 @@ SIGNATURES = {
     "fc_debug_set_poison": (_i, [_i]),
     "fc_debug_poison_check": (_i, [_pi, _pi]),
     "fc_debug_set_conv_stamps": (_i, [_vp]),
+    "fc_debug_set_stamp_op": (_i, [_i, _vp]),
     "fc_debug_conv": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _pi, _pf, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _pf, _vp]),
     "fc_debug_set_fused_tail": (_i, [_i]),
     "fc_unet_fused_tail_errors": (_i, [_vp, C.POINTER(_i)]),

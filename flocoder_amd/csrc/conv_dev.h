@@ -408,6 +408,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
         const int ngt = p.cpg >= BN ? 1 : BN / p.cpg;
         // The residual is requested BEFORE the wait for the other workgroups' partials: it depends on nothing computed here, it is a cold
         // miss (another kernel wrote it), and behind the meeting it was a second memory round trip on the tail's critical path (round 3).
+        // (Round 4 tried it earlier still -- in front of the statistics, with LDS-only barriers for the accumulator waves so that the
+        // statistics' barriers do not wait for it: every Block-closing launch 0.3-0.7 us SLOWER in the op table, 828-829 against 831-833
+        // samples/s.  The wait that follows a request is in order, so whatever comes first behind it pays its round trip; here that is the
+        // poll, which has to wait anyway.)
         float rs[MT][NT][16];
         if (owner) {
 #pragma unroll
@@ -473,6 +477,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
             }
         }
         lds_only_barrier();
+        if (FL & FL_STAMP) conv_stamp(p, 12);              // (accumulator rows) the statistics of the whole group are in LDS: meeting over, or the local table
         if (owner) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -493,6 +498,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                     }
                 }
         }
+        if (FL & FL_STAMP) conv_stamp(p, 2);               // (accumulator rows) normalised + activated + residual added
         if (LEAN ? bool(FL & FL_GN1) : a.fin.gn1_out != nullptr) {   // GroupNorm(1) partials of the final value for the PreNorm that follows (unet.py:156-160)
             lds_only_barrier();                    // every reader of part* / tab is done
             const int cpg1 = Cout, cpgt1 = Cout < BN ? Cout : BN, NPG1 = Cout >= BN ? Cout / BN : 1;
@@ -504,6 +510,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                 emit(a.fin.gn1_out, 1, cpg1, cpgt1, NPG1, false, false);
             }
         }
+        if (FL & FL_STAMP) conv_stamp(p, 13);              // GroupNorm(1) partials out
     }
 
     // Output stores.  Written flat: the pixel index of every accumulator row first (one 32-bit value per row; -1 = sample beyond B),
@@ -553,6 +560,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
             }
         }
     }
+    if (FL & FL_STAMP) conv_stamp(p, 3);                   // (accumulator rows; a staging wave's slot 3 is its first LDS store and is overwritten here)
     if (LEAN || p.o_out >= 0) {      // lean flavours are only launched when the LDS image fits
         constexpr int OS = BN + 4, Q4 = BN / 4;
         float* ot = smem + p.o_out;

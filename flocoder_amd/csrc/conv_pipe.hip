@@ -701,7 +701,8 @@ static int pipe_attr_ks() {
     X(TILE_M32N32K4, 1, 1, 4, 1, 1, 32, KS, (KS == 1 ? 4 : 8))
 
 #define FC_LEAN_FLAVOURS_3(X) X(0) X(FL_POSTOP) X(FL_STATS) X(FL_STATS | FL_STAMP) X(FL_STATS | FL_CAT | FL_STAMP) X(FL_STATS | FL_RES) X(FL_STATS | FL_CAT) X(FL_STATS | FL_RES | FL_CAT) X(FL_STATS | FL_XF) \
-    X(FL_STATS | FL_XF | FL_FIN) X(FL_STATS | FL_XF | FL_FIN | FL_GN1) X(FL_STATS | FL_XF | FL_FIN | FL_MEET) X(FL_STATS | FL_XF | FL_FIN | FL_GN1 | FL_MEET)
+    X(FL_STATS | FL_XF | FL_FIN) X(FL_STATS | FL_XF | FL_FIN | FL_GN1) X(FL_STATS | FL_XF | FL_FIN | FL_MEET) X(FL_STATS | FL_XF | FL_FIN | FL_GN1 | FL_MEET) \
+    X(FL_STATS | FL_XF | FL_FIN | FL_STAMP) X(FL_STATS | FL_XF | FL_FIN | FL_GN1 | FL_STAMP) X(FL_STATS | FL_XF | FL_FIN | FL_MEET | FL_STAMP) X(FL_STATS | FL_XF | FL_FIN | FL_GN1 | FL_MEET | FL_STAMP)   /* diagnostics: tools/fin_stamps.py */
 #define FC_LEAN_FLAVOURS_1(X) X(0) X(FL_POSTOP) X(FL_XF) X(FL_STATS) X(FL_STATS | FL_XF)
 
 // the 64-column tiles the 1x1 projections of the larger models run on (to_qkv and its data gradient): lean flavours for 1x1 only

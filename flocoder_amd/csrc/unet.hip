@@ -1138,6 +1138,10 @@ uint64_t fc_unet_arena_serial(const fc_unet* u) { return u ? u->arena_serial : 0
 // Time every launch of the current plan on its own: each op is enqueued `repeats` times back to back between two
 // events on `stream` (ops are idempotent: they only read their inputs), so host launch gaps do not pollute kernels
 // that run longer than a launch takes to issue.  ms_out[i] = average milliseconds of op i.
+static int g_stamp_op = -1;                     // diagnostics: fc_unet_profile_ops runs this plan entry once more with the conv stamps on
+static unsigned long long* g_stamp_op_buf = nullptr;
+int fc_debug_set_stamp_op(int op_index, void* buf_dev) { g_stamp_op = buf_dev ? op_index : -1; g_stamp_op_buf = static_cast<unsigned long long*>(buf_dev); return FC_OK; }
+
 int fc_unet_profile_ops(fc_unet* u, int batch, int repeats, float* ms_out, int n_out, void* stream) {
     if (!u || !ms_out || repeats < 1) return fail(FC_E_ARG, "fc_unet_profile_ops: bad argument");
     FC_TRY(check_ready(u, batch, u->H, u->W));
@@ -1158,6 +1162,12 @@ int fc_unet_profile_ops(fc_unet* u, int batch, int repeats, float* ms_out, int n
         (void)hipEventRecord(ev[2 * i], s);
         for (int r = 0; r < repeats && rc == FC_OK; ++r) rc = pl0.ops[i](c, s);
         (void)hipEventRecord(ev[2 * i + 1], s);
+        if (i == g_stamp_op && g_stamp_op_buf && rc == FC_OK) {      // the same launch once more, writing its in-kernel phase stamps
+            conv_set_stamp_buffer(g_stamp_op_buf);
+            rc = pl0.ops[i](c, s);
+            (void)hipStreamSynchronize(s);
+            conv_set_stamp_buffer(nullptr);
+        }
     }
     (void)hipStreamSynchronize(s);
     for (int i = 0; i < n; ++i) {

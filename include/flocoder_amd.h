@@ -169,6 +169,9 @@ int fc_debug_poison_check(int* corrupted, int* live);
 /* Diagnostics: subsequent pipelined-conv launches write shader-clock phase stamps to buf_dev
  * ([block][wave][16] uint64); NULL switches them off again. */
 int fc_debug_set_conv_stamps(void* buf_dev);
+/* Diagnostics: fc_unet_profile_ops runs plan entry `op_index` once more with the stamps of fc_debug_set_conv_stamps going to buf_dev
+ * (the phase timeline of ONE launch of a real plan, fused tail included: tools/fin_stamps.py); NULL switches it off. */
+int fc_debug_set_stamp_op(int op_index, void* buf_dev);
 /* One implicit-GEMM launch on caller tensors (NHWC activations, OIHW weights as torch stores them).
  * Synchronises; allocates a scratch weight buffer. stats_out [B][G][T][2] gets (mean, M2) partials, T and the
  * per-slot count come back through stats_T / stats_nt. tile_cfg = -1 picks automatically.  repeats > 0 additionally
