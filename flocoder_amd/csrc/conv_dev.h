@@ -477,7 +477,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
             }
         }
         lds_only_barrier();
-        if (FL & FL_STAMP) conv_stamp(p, 12);              // (accumulator rows) the statistics of the whole group are in LDS: meeting over, or the local table
+        if ((FL & FL_STAMP) && active) conv_stamp(p, 12);  // (accumulator rows) the statistics of the whole group are in LDS: meeting over, or the local table
         if (owner) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -498,7 +498,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                     }
                 }
         }
-        if (FL & FL_STAMP) conv_stamp(p, 2);               // (accumulator rows) normalised + activated + residual added
+        if ((FL & FL_STAMP) && active) conv_stamp(p, 2);   // (accumulator rows) normalised + activated + residual added
         if (LEAN ? bool(FL & FL_GN1) : a.fin.gn1_out != nullptr) {   // GroupNorm(1) partials of the final value for the PreNorm that follows (unet.py:156-160)
             lds_only_barrier();                    // every reader of part* / tab is done
             const int cpg1 = Cout, cpgt1 = Cout < BN ? Cout : BN, NPG1 = Cout >= BN ? Cout / BN : 1;
@@ -510,7 +510,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
                 emit(a.fin.gn1_out, 1, cpg1, cpgt1, NPG1, false, false);
             }
         }
-        if (FL & FL_STAMP) conv_stamp(p, 13);              // GroupNorm(1) partials out
+        if ((FL & FL_STAMP) && active) conv_stamp(p, 13);  // GroupNorm(1) partials out
     }
 
     // Output stores.  Written flat: the pixel index of every accumulator row first (one 32-bit value per row; -1 = sample beyond B),
@@ -560,7 +560,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[MT
             }
         }
     }
-    if (FL & FL_STAMP) conv_stamp(p, 3);                   // (accumulator rows; a staging wave's slot 3 is its first LDS store and is overwritten here)
+    if ((FL & FL_STAMP) && active) conv_stamp(p, 3);       // (accumulator rows; a staging wave's slot 3 is its first LDS store)
     if (LEAN || p.o_out >= 0) {      // lean flavours are only launched when the LDS image fits
         constexpr int OS = BN + 4, Q4 = BN / 4;
         float* ot = smem + p.o_out;

@@ -221,7 +221,13 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
             gstat[2 * i + 1] = rstd;
         }
        }
-        __syncthreads();
+        if ((FL & FL_STAMP) && worker) conv_stamp(p, 2);      // (staging rows) statistics combined: the first cold round trip is over
+        // LDS-only barriers (round 4): the two tables are LDS data, and __syncthreads() also parks every wave until ALL its global
+        // accesses have returned -- the accumulator waves' epoch atomic, epilogue operands and first weights, a second cold round trip
+        // queued behind the statistics' one (tools/fin_stamps.py: statistics combined at 2.15 us, past this barrier at 3.12).  What a wave
+        // needs from memory it waits for where it uses it; the staging waves' LDS-DMA has its own explicit wait before the hand-over.
+        lds_only_barrier();
+        if ((FL & FL_STAMP) && worker) conv_stamp(p, 4);
        if (worker) {
         if (id < p.TB * Cin) {
             float A = 1.f, Bv = 0.f;
@@ -255,7 +261,8 @@ __global__ void __launch_bounds__(256 + 64 * NL) conv_pipe_kernel(const ConvDev 
             aff[i] = make_float2(A, Bv);
         }
        }
-        __syncthreads();
+        lds_only_barrier();
+        if ((FL & FL_STAMP) && worker) conv_stamp(p, 5);      // (staging rows) the folded affine tables are in LDS
       }
     };
 

@@ -49,7 +49,9 @@ for i, r in enumerate(rows):
     print(f"{r['module']:18s} {r['kernel']:30s} {1e3 * r['ms']:6.1f} us timed, {nb} workgroups; first start -> last end {float(ends.max() - rt.min()) / 1e3:.2f} us; "
           f"starts spread over {float(rt.max() - rt.min()) / 1e3:.2f} us")
     print(f"    tail-running wave, us since its start (median): weights requested {t(1):.2f}, stage 0 ready {t(4):.2f}, mfma done {t(5):.2f}, end {t(8):.2f};  "
-          f"staging wave: first window in LDS {(load[:, :, 3] - load[:, :, 0]).median().item() / 2.4e3:.2f}")
+          f"staging wave: window requested {(load[:, :, 1] - load[:, :, 0]).median().item() / 2.4e3:.2f}, producer's statistics combined {(load[:, :, 2] - load[:, :, 0]).median().item() / 2.4e3:.2f}, "
+          f"past the barrier {(load[:, :, 4] - load[:, :, 0]).median().item() / 2.4e3:.2f}, affine tables in LDS {(load[:, :, 5] - load[:, :, 0]).median().item() / 2.4e3:.2f}, "
+          f"first window in LDS {(load[:, :, 3] - load[:, :, 0]).median().item() / 2.4e3:.2f}")
     print(f"    tail: K-reduce {d(6, 5):.2f} | block sums {d(7, 6):.2f} | publish / local table {d(14, 7):.2f} | wait for the group's statistics {d(12, 14):.2f} | "
           f"normalise + SiLU + residual {d(2, 12):.2f} | GN(1) partials {d(13, 2):.2f} | to the image {d(3, 13):.2f} | LDS image {d(9, 3):.2f} | barrier {d(10, 9):.2f} | stores {d(8, 10):.2f}"
           f"  = {d(8, 5):.2f} us after the last MFMA")
