@@ -299,6 +299,41 @@ def test_folded_upsampling_equals_the_conv_over_the_upsampled_window(tmp_path):
     assert fl == fl0 and abs(ex0 - fl0) < 1e-3 * fl0 and ex < 0.95 * ex0
 
 
+@pytest.mark.parametrize("H,W,kw,need_kernel", [(8, 16, dict(n_classes=10), True), (16, 8, dict(n_classes=0, mask_cond=True), None), (8, 8, dict(n_classes=10), True)])
+def test_one_workgroup_per_sample_kernel_other_shapes_vs_oracle(H, W, kw, need_kernel):
+    """The steps of csrc/unet_sample.hip that the square 8x8 golden model does not reach: non-square latents put TWO positions on the
+    bottleneck (the general full-attention step instead of the one-position closed form), 8x16 a linear attention over 128 positions (the
+    general sequential-heads step), class conditioning the FiLM rows of the embedding table; the mask-conditioned 16x8 model does not fit a
+    CU's LDS and must come out right on the ordinary plan it falls back to.
+    Against the CPU oracle, with perturbed norm parameters so that every parameter matters."""
+    from flocoder_amd.unet import Unet
+    torch.manual_seed(H * 31 + W)
+    m = Unet(dim=8, dim_mults=(1, 2, 4, 8), channels=4, **kw).eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(H * W + 8)
+    for k, v in sd.items():
+        if v.dtype == torch.float32 and v.ndim == 1:
+            sd[k] = v + 0.1 * torch.randn(v.shape, generator=g)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV)
+    Bn = 5
+    x, t = torch.randn(Bn, 4, H, W, generator=g), torch.rand(Bn, generator=g) * 999
+    if kw.get("mask_cond"):
+        cond = {"mask_cond": (torch.rand(Bn, 4, H, W, generator=g) > 0.4).float()}
+    else:
+        cls = torch.arange(Bn) % 10
+        cls[0] = 9
+        cond = {"class_cond": cls}
+    ref = fo.unet_forward(sd, x, t, cond)
+    with torch.no_grad():
+        out = m(x.to(DEV), t.to(DEV), {k: v.to(DEV) for k, v in cond.items()})
+    print(f"{H}x{W} {kw}: {m.launches_per_forward} launches per forward")
+    if need_kernel:
+        assert m.launches_per_forward <= 4, m.launches_per_forward          # conditioning + the ONE U-Net launch
+    err = rel_l2(out.cpu(), ref)
+    assert err < FWD_TOL, f"{H}x{W} {kw}: {err:.3e} with {m.launches_per_forward} launches"
+
+
 def test_one_workgroup_per_sample_kernel_is_the_default_where_it_fits_and_both_plans_match_the_goldens():
     """csrc/unet_sample.hip (the whole forward of a sample in one workgroup, for models whose activations fit a CU's LDS and batches of at
     most one sample per CU): the mask-conditioned dim-8 model runs on it by default (the plan is ONE U-Net launch),
