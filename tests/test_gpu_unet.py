@@ -334,6 +334,37 @@ def test_one_workgroup_per_sample_kernel_other_shapes_vs_oracle(H, W, kw, need_k
     assert err < FWD_TOL, f"{H}x{W} {kw}: {err:.3e} with {m.launches_per_forward} launches"
 
 
+def test_one_workgroup_per_sample_kernel_samplers_vs_oracle():
+    """The integrators on the per-sample kernel: legacy Euler (the kernel's own Euler tail: y += v dt, the counters moved by the workgroup that
+    finishes last) and RK4 with classifier-free guidance (2B rows per evaluation, conditioning rows from the precomputed table), a
+    class-conditioned dim-8 model at 8x8 against the CPU oracle; replays of the cached graph give the same bits."""
+    from flocoder_amd import sampling as S
+    from flocoder_amd.unet import Unet
+    torch.manual_seed(77)
+    m = Unet(dim=8, dim_mults=(1, 2, 4, 8), channels=4, n_classes=10).eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(78)
+    for k, v in sd.items():
+        if v.dtype == torch.float32 and v.ndim == 1:
+            sd[k] = v + 0.1 * torch.randn(v.shape, generator=g)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV)
+    Bn = 6
+    src = torch.randn(Bn, 4, 8, 8, generator=g)
+    cls = torch.tensor([0, 3, 9, 9, 5, 1])
+    ref, _ = fo.euler_sampler(sd, src, 12, cls)
+    lat, nfe = S.euler_sampler(m, (Bn, 4, 8, 8), 12, cond=cls.to(DEV), source=src.to(DEV))
+    assert nfe == 12 and m.launches_per_forward <= 4
+    assert rel_l2(lat.cpu(), ref) < TRAJ_TOL
+    again, _ = S.euler_sampler(m, (Bn, 4, 8, 8), 12, cond=cls.to(DEV), source=src.to(DEV))
+    assert torch.equal(again, lat)
+    ref, _ = fo.generate_latents_rk4(sd, src.clone(), 7, {"class_cond": cls}, 3.0)
+    lat, nfe = S.generate_latents_rk4(m, (Bn, 4, 8, 8), 7, {"class_cond": cls.to(DEV)}, 3.0, source=src.to(DEV))
+    assert nfe == 28 and rel_l2(lat.cpu(), ref) < TRAJ_TOL
+    again, _ = S.generate_latents_rk4(m, (Bn, 4, 8, 8), 7, {"class_cond": cls.to(DEV)}, 3.0, source=src.to(DEV))
+    assert torch.equal(again, lat)
+
+
 def test_one_workgroup_per_sample_kernel_is_the_default_where_it_fits_and_both_plans_match_the_goldens():
     """csrc/unet_sample.hip (the whole forward of a sample in one workgroup, for models whose activations fit a CU's LDS and batches of at
     most one sample per CU): the mask-conditioned dim-8 model runs on it by default (the plan is ONE U-Net launch),
