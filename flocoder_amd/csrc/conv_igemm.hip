@@ -31,7 +31,7 @@ namespace fc {
 
 template <int WM, int WN, int WK, int MT, int NT, int CC>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvDev p) {
-    constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN, CS = CC + 1, KSTEPS = CC / 2, KPW = KSTEPS / WK, Q = CC / 4;
+    constexpr int BN = 32 * NT * WN, CS = CC + 1, KSTEPS = CC / 2, KPW = KSTEPS / WK, Q = CC / 4;
     static_assert(WM * WN * WK == 4, "4 waves per workgroup");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const ConvArgs& a = p.a;

@@ -113,6 +113,10 @@ __device__ __forceinline__ void stash_flat8(const Pre& r, int n4, float* wbuf);
 __device__ __forceinline__ void issue_first(const SStep& s, Pre& r) { if (s.op == S_CONV) issue_conv_chunk(s, 0, r); else if (s.op == S_ATTN1) issue_wv(s, r); else if (s.op == S_LINATTN_W) issue_allheads(s, r); else issue_head(s, 0, r); }
 __device__ __forceinline__ void stash_first(const SStep& s, const Pre& r, float* wbuf) { if (s.op == S_CONV) stash_conv_chunk(s, 0, r, wbuf); else if (s.op == S_ATTN1) stash_flat8(r, s.C0 * 32, wbuf); else if (s.op == S_LINATTN_W) stash_flat8(r, s.C0 * 128, wbuf); else stash_head(s, r, wbuf); }
 
+// (RETIRED as a step of its own -- the host folds every GroupNorm into the convolution in front of it, conv_epilogue below -- and KEPT in the
+// kernel on purpose: without this function and its case in the step switch the compiler's code for the rest is 3.6 % slower, 454 against
+// 438 us per evaluation, two builds alternating on one box (round 4).  The same holds for mean and variance in ONE pairwise (Chan) reduction
+// in conv_epilogue: one barrier instead of four, no faster.)
 // y = [act]( (x - mean_g) * rstd_g * gamma + beta  [* (scale + 1) + shift] ) [+ res]     GroupNorm over (channels of a group) x pixels.
 // A thread's elements e = tid + j NT are the SAME channel c = tid & (C - 1) of different pixels (C <= 64 divides NT), so they lie in one
 // group: a group's sum is reduced over exactly those lane bits that do not select the group (the bits below log2(channels per group) and
