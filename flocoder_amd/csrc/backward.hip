@@ -170,6 +170,22 @@ __global__ void __launch_bounds__(NTH) gn_bwd_small_kernel(const GnBwdArgs a) {
         hv[k] = in ? *reinterpret_cast<const float4*>(a.h + base + i) : make_float4(0.f, 0.f, 0.f, 0.f);
         dv[k] = in ? *reinterpret_cast<const float4*>(a.dy + base + i) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // What the result is added to (the gradient accumulated so far, the residual branch's gradient) depends on nothing computed here either:
+    // requested with the operands above instead of behind the last barrier, where it was one more cold round trip on every launch of the
+    // data-gradient chain (round 4).  Only in the 256-thread form: 1024 threads leave 128 registers per lane, the operands alone take 64.
+    constexpr bool PRE_ADD = NTH == 256;
+    float4 av[PRE_ADD ? 8 : 1];
+    if (PRE_ADD) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = 4 * tid + 4 * NTH * k;
+            const bool in = k < nk && i < total;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (in && a.accumulate) v = *reinterpret_cast<const float4*>(a.dh + base + i);
+            if (in && a.plus) { const float4 p = *reinterpret_cast<const float4*>(a.plus + base + i); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+            av[PRE_ADD ? k : 0] = v;
+        }
+    }
     for (int g = tid; g < a.xf.G; g += NTH) combine_partials(a.xf, b, g, &gt[4 * g], &gt[4 * g + 1]);
     __syncthreads();
     for (int c = tid; c < C; c += NTH) {
@@ -241,8 +257,11 @@ __global__ void __launch_bounds__(NTH) gn_bwd_small_kernel(const GnBwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = gaj[j] * ds[j] - k1[j] - ((hs[j] - mean4[j]) * rstd4[j]) * k2[j];
         float4* dst = reinterpret_cast<float4*>(a.dh + base + i);
-        if (a.accumulate) { const float4 p = *dst; o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w; }
-        if (a.plus) { const float4 p = *reinterpret_cast<const float4*>(a.plus + base + i); o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w; }
+        if (PRE_ADD) { const float4 p = av[PRE_ADD ? k : 0]; o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w; }
+        else {
+            if (a.accumulate) { const float4 p = *dst; o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w; }
+            if (a.plus) { const float4 p = *reinterpret_cast<const float4*>(a.plus + base + i); o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w; }
+        }
         *dst = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
