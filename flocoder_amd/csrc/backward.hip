@@ -186,16 +186,23 @@ __global__ void __launch_bounds__(NTH) gn_bwd_small_kernel(const GnBwdArgs a) {
             av[PRE_ADD ? k : 0] = v;
         }
     }
+    // (the norm's parameters and the FiLM row of this thread's first channel: requested here, in front of the barrier, not behind it)
+    float pgam = 0.f, pbet = 0.f, psc = 0.f, psh = 0.f;
+    if (tid < C) {
+        pgam = a.xf.gamma[tid]; pbet = a.xf.beta[tid];
+        if (a.xf.ss) { psc = a.xf.ss[(size_t)b * a.xf.ss_stride + tid]; psh = a.xf.ss[(size_t)b * a.xf.ss_stride + C + tid]; }
+    }
     for (int g = tid; g < a.xf.G; g += NTH) combine_partials(a.xf, b, g, &gt[4 * g], &gt[4 * g + 1]);
     __syncthreads();
     for (int c = tid; c < C; c += NTH) {
         const int g = c / cpg;
+        const bool pre = c == tid;
         const float mean = gt[4 * g], rstd = gt[4 * g + 1];
-        float gam = a.xf.gamma[c];
-        float s = rstd * gam, t = a.xf.beta[c] - mean * s;
+        float gam = pre ? pgam : a.xf.gamma[c];
+        float s = rstd * gam, t = (pre ? pbet : a.xf.beta[c]) - mean * s;
         if (a.xf.ss) {
-            const float sc = a.xf.ss[(size_t)b * a.xf.ss_stride + c] + 1.0f;
-            const float sh = a.xf.ss[(size_t)b * a.xf.ss_stride + C + c];
+            const float sc = (pre ? psc : a.xf.ss[(size_t)b * a.xf.ss_stride + c]) + 1.0f;
+            const float sh = pre ? psh : a.xf.ss[(size_t)b * a.xf.ss_stride + C + c];
             s *= sc; t = t * sc + sh; gam *= sc;
         }
         A[c] = s; Bv[c] = t; ga[c] = gam * rstd;
