@@ -1,4 +1,8 @@
 #!/bin/bash
+# Two builds of the library alternating on ONE box (boxes of the pool differ by ~1.5 %, a build's effect is often smaller): copy the two
+# libflocoder_amd.so to ab_libs/lib_head.so and ab_libs/lib_new.so (git-ignored, travels with the snapshot), then
+#     gpurun -- 'bash tools/r04_abtrain.sh'
+# runs the training tests on the working-tree build and both training benchmarks on each library, twice (FLOCODER_AMD_LIB selects the library).
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 timeout -k 10 600 python -m pytest tests/test_gpu_train.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -2
